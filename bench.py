@@ -1,0 +1,310 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpixels/s unprojected+fused on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload garden185|scene2000|roofline12mp]
+
+One "step" = one pass of the hot path (cull + unproject + cam->world + stable compaction +
+fuse) over one batch of synthetic views already resident in HBM.  At N=1 the workload is
+BASELINE.json configs[1] ("garden": 185 views, 1920x1080, depth f32 + normal f32x3 + mask u8
++ rgb u8x3; synthetic stand-in).  For N>1 the driver launches one rank per GPU
+(torch.distributed.run); every rank densifies its own 185-view shard of a 185*N-view scene
+(weak scaling; views are independent) and the fuse step exchanges the per-view
+counts (RCCL all-gather) so every rank holds the global view offsets of the distributed cloud.
+The replicated all-gatherv of the clouds is timed separately and reported under "gathered".
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+WORKLOADS = {
+    # name: (views per GPU, H, W, depth dtype, mask, normal, rgb, valid fraction target)
+    "garden185": dict(V=185, H=1080, W=1920, depth="float32", mask=True, normal=True, rgb=True, rho=0.85,
+                      note="BASELINE configs[1] stand-in: 185 views ~1080p, blob mask"),
+    "scene2000": dict(V=2000, H=1080, W=1920, depth="float32", mask=True, normal=True, rgb=True, rho=0.8,
+                      note="BASELINE configs[2]: 2000-view synthetic scene (strong scaling: V is the total)"),
+    "roofline12mp": dict(V=100, H=3024, W=4032, depth="float16", mask=False, normal=False, rgb=False, rho=1.0,
+                         note="BASELINE configs[4] shape: 12 MP f16 depth in / f32 xyz out, dense"),
+}
+
+
+# ------------------------------------------------------------------------------ synthetic scene
+
+def ring_poses(view_ids: np.ndarray, total: int, radius: float = 4.0) -> np.ndarray:
+    """cam_from_world (n,3,4): cameras on a ring of radius 4 looking at the origin."""
+    E = np.zeros((len(view_ids), 3, 4))
+    for i, v in enumerate(view_ids):
+        a = 2 * np.pi * float(v) / total
+        c = np.array([radius * np.cos(a), 0.3 * np.sin(3 * a), radius * np.sin(a)])
+        z = -c / np.linalg.norm(c)
+        x = np.cross([0.0, 1.0, 0.0], z)
+        x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        R = np.stack([x, y, z])
+        E[i, :, :3] = R
+        E[i, :, 3] = -R @ c
+    return E
+
+
+def make_scene(cfg: dict, view_ids: np.ndarray, device) -> dict:
+    """Seeded per-view synthetic maps generated on the device (seed = 1000 + global view id, so
+    sharding does not change the data): smooth depth field 1-8 m, blob mask with the target
+    valid fraction, unit normals, random colours."""
+    V, H, W = len(view_ids), cfg["H"], cfg["W"]
+    ddt = getattr(torch, cfg["depth"])
+    depth = torch.empty((V, H, W), dtype=ddt, device=device)
+    mask = torch.empty((V, H, W), dtype=torch.bool, device=device) if cfg["mask"] else None
+    normal = torch.empty((V, H, W, 3), dtype=torch.float32, device=device) if cfg["normal"] else None
+    rgb = torch.empty((V, H, W, 3), dtype=torch.uint8, device=device) if cfg["rgb"] else None
+    ys = torch.linspace(0, 1, H, device=device)[:, None]
+    xs = torch.linspace(0, 1, W, device=device)[None, :]
+    for i, vid in enumerate(view_ids):
+        g = torch.Generator(device=device).manual_seed(1000 + int(vid))
+        ph = torch.rand(6, generator=g, device=device) * 6.283
+        f = 1.0 + 3.0 * torch.rand(6, generator=g, device=device)
+        field = (torch.sin(f[0] * 6.283 * xs + ph[0]) * torch.sin(f[1] * 6.283 * ys + ph[1])
+                 + 0.5 * torch.sin(f[2] * 6.283 * (xs + ys) + ph[2]) + 0.25 * torch.sin(f[3] * 12.566 * xs + ph[3]))
+        depth[i] = (4.5 + 2.0 * field).clamp(1.0, 8.0).to(ddt)
+        if mask is not None:
+            coarse = torch.rand((1, 1, 18, 32), generator=g, device=device)
+            blob = torch.nn.functional.interpolate(coarse, size=(H, W), mode="bicubic", align_corners=False)[0, 0]
+            thr = torch.quantile(blob.flatten()[:: max(1, (H * W) // 200000)], 1.0 - cfg["rho"])
+            mask[i] = blob > thr
+        if normal is not None:
+            n = torch.randn((H, W, 3), generator=g, device=device)
+            normal[i] = torch.nn.functional.normalize(n, dim=-1)
+        if rgb is not None:
+            rgb[i] = torch.randint(0, 256, (H, W, 3), generator=g, device=device, dtype=torch.uint8)
+    return dict(depth=depth, mask=mask, normal=normal, rgb=rgb)
+
+
+# ------------------------------------------------------------------------------ byte model
+
+def algorithmic_bytes(cfg: dict, V: int, n_valid: int, pixel_index: bool) -> int:
+    """read P*(b_depth+b_mask) + N*(12[normal]+3[rgb]) + 64 B params per view;
+    write N*(12 + 12[normal] + 3[rgb] + 4[pixel_index]) + 8 B offset per view.  Attributes are
+    charged only for surviving pixels; nothing is credited for re-reads."""
+    P = cfg["H"] * cfg["W"]
+    b_depth = 2 if cfg["depth"] == "float16" else 4
+    per_px = b_depth + (1 if cfg["mask"] else 0)
+    per_pt_r = (12 if cfg["normal"] else 0) + (3 if cfg["rgb"] else 0)
+    per_pt_w = 12 + (12 if cfg["normal"] else 0) + (3 if cfg["rgb"] else 0) + (4 if pixel_index else 0)
+    return V * P * per_px + n_valid * (per_pt_r + per_pt_w) + V * (64 + 8)
+
+
+# ------------------------------------------------------------------------------ CPU baseline
+
+def cpu_baseline(cfg: dict, scene: dict, params: np.ndarray, E: np.ndarray, budget_s: float) -> dict:
+    """The oracle (NumPy restatement of scripts/test.py:194-266, kind "port") timed single-process
+    -- exactly how the reference runs -- on the first views of the same workload, for about
+    `budget_s` seconds of CPU work."""
+    from oracle import densify_oracle as orc          # reported baseline only, never the product path
+
+    P = cfg["H"] * cfg["W"]
+    n_views = 0
+    t_total = 0.0
+    pts = 0
+    max_views = scene["depth"].shape[0]
+    while t_total < budget_s and n_views < max_views:
+        i = n_views
+        d = scene["depth"][i].cpu().numpy()
+        m = None if scene["mask"] is None else scene["mask"][i].cpu().numpy()
+        n = None if scene["normal"] is None else scene["normal"][i].cpu().numpy()
+        c = None if scene["rgb"] is None else scene["rgb"][i].cpu().numpy()
+        t0 = time.perf_counter()
+        out = orc.fuse_views([orc.densify_view_script(d, params[i], E[i], mask=m, normal=n, rgb=c)])
+        t_total += time.perf_counter() - t0
+        pts += len(out.points)
+        n_views += 1
+    return {
+        "value": round(n_views * P / t_total / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+        "sample": f"first {n_views} of {max_views} views of the same workload, {t_total:.1f} s single-process NumPy "
+                  f"{np.__version__} (the reference is single-threaded NumPy; oracle/densify_oracle.py)",
+        "mpoints_per_s": round(pts / t_total / 1e6, 3),
+    }
+
+
+# ------------------------------------------------------------------------------ main
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="garden185", choices=sorted(WORKLOADS))
+    ap.add_argument("--views", type=int, default=0, help="override views per GPU (garden185) / total views (scene2000)")
+    ap.add_argument("--pixel-index", action="store_true", help="also emit the int32 pixel index per point")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--gather-steps", type=int, default=2, help="N>1: timed replicated all-gatherv passes (0 = skip)")
+    ap.add_argument("--tuning", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with: python -m torch.distributed.run --nnodes=1 "
+                     "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)     # "nccl" is RCCL on ROCm
+
+    import depthdensifier_amd as dd
+    from depthdensifier_amd import distributed as D
+
+    cfg = dict(WORKLOADS[args.workload])
+    strong = args.workload == "scene2000"
+    if args.views:
+        cfg["V"] = args.views
+    if strong:
+        total_views = cfg["V"]
+        lo, hi = D.shard_views(total_views, world, rank)
+        scaling = "strong"
+    else:
+        total_views = cfg["V"] * world
+        lo, hi = rank * cfg["V"], (rank + 1) * cfg["V"]
+        scaling = "weak"
+    view_ids = np.arange(lo, hi)
+    V = len(view_ids)
+    H, W = cfg["H"], cfg["W"]
+
+    scene = make_scene(cfg, view_ids, device)
+    params = np.tile([0.8 * W, 0.8 * W, W / 2.0, H / 2.0], (V, 1))
+    E = ring_poses(view_ids, total_views)
+    batch = dd.ViewBatch(scene["depth"], params, E, mask=scene["mask"], normal=scene["normal"], rgb=scene["rgb"],
+                         view_index_base=int(lo), device=device, tuning=args.tuning)
+    n_local = int(dd.count_valid(batch).sum().item())
+    builder = dd.CloudBuilder(n_local, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index,
+                              device=device)
+
+    ev_pairs = []
+
+    def step(record: bool):
+        builder.reset()
+        if record:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        offs = builder.append(batch)
+        if record:
+            e1.record()
+            ev_pairs.append((e0, e1))
+        if world > 1:                              # the fuse exchange: global view offsets on every rank
+            counts = offs[1:] - offs[:-1]
+            return D.offsets_from_counts(D.exchange_counts(counts, total_views))
+        return offs
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        goffs = step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    cloud = builder.finish()
+    assert len(cloud) == n_local
+    n_total = int(goffs[-1].item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs]))
+
+    # replicated fuse (the north-star all-gatherv of the per-GPU clouds), timed separately
+    gathered = None
+    if world > 1 and args.gather_steps > 0:
+        sharded = D.fuse_sharded(cloud, total_views)
+        rows = n_total
+        bufs = {"points": torch.empty((rows, 3), dtype=torch.float32, device=device)}
+        if cfg["rgb"]:
+            bufs["colors"] = torch.empty((rows, 3), dtype=torch.uint8, device=device)
+        if cfg["normal"]:
+            bufs["normals"] = torch.empty((rows, 3), dtype=torch.float32, device=device)
+        D.gather_cloud(sharded, out=bufs)
+        fence()
+        g0 = time.perf_counter()
+        for _ in range(args.gather_steps):
+            step(False)
+            D.gather_cloud(sharded, out=bufs)
+        fence()
+        gt = torch.tensor([(time.perf_counter() - g0) / args.gather_steps], dtype=torch.float64, device=device)
+        dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+        rec = 12 + (12 if cfg["normal"] else 0) + (3 if cfg["rgb"] else 0) + (4 if args.pixel_index else 0)
+        gathered = {"value": round(total_views * H * W / float(gt.item()) / 1e6, 1), "unit": "Mpixels/s",
+                    "ms_per_step": round(float(gt.item()) * 1e3, 3), "cloud_bytes": n_total * rec,
+                    "note": "densify + replicated all-gatherv of xyz/rgb/normal to every rank"}
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        pixels = total_views * H * W
+        alg = algorithmic_bytes(cfg, V, n_local, args.pixel_index)
+        achieved = alg / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = ROOT / "profiles" / "traffic.json"
+        if tfile.exists():
+            traffic = json.loads(tfile.read_text()).get(args.workload, {}).get("hbm_bytes_per_launch")
+        line = {
+            "metric": "Mpixels/s unprojected+fused",
+            "value": round(pixels / (elapsed / args.steps) / 1e6, 1),
+            "unit": "Mpixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": "f32" if cfg["depth"] == "float32" else "f16-in/f32-out",
+            "data": "synthetic",
+            "mpoints_per_s": round(n_total / (elapsed / args.steps) / 1e6, 1),
+            "config": {"workload": args.workload, "note": cfg["note"], "views_total": total_views, "views_per_gpu": V,
+                       "height": H, "width": W, "downsample_density": 1, "valid_fraction": round(n_local / (V * H * W), 4),
+                       "inputs": "+".join(k for k in ("depth", "mask", "normal", "rgb") if scene[k] is not None),
+                       "outputs": "xyz f32" + (" + normal f32" if cfg["normal"] else "") + (" + rgb u8" if cfg["rgb"] else "")
+                                  + (" + pixel_index i32" if args.pixel_index else ""),
+                       "fuse": "single GPU: one global scan, points written at final slots" if world == 1 else
+                               "sharded: contiguous view shards + RCCL all-gather of per-view counts (global offsets)"},
+            "roofline": {"bound": "hbm", "kernel": "unproject_compact_kernel", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": traffic, "algorithmic_bytes_per_launch": alg,
+                         "kernel_ms": round(kernel_ms, 4), "timer": "HIP events on the launch stream, mean over timed steps"},
+        }
+        if gathered:
+            line["gathered"] = gathered
+        if args.cpu_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(cfg, scene, params, E, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

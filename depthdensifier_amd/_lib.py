@@ -1,0 +1,113 @@
+"""ctypes binding of ``libddcore.so`` (C ABI declared in ``include/ddcore.h``).
+
+There is no CPU fallback: if the HIP library has not been built, importing this
+module raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C depthdensifier_amd/csrc``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+# torch MUST be imported before libddcore.so is dlopen'ed: libtorch_hip.so asks for its bundled
+# "libamdhip64.so" by file name while libddcore.so asks for the soname "libamdhip64.so.7".  With
+# torch first the loader satisfies our soname from torch's already-loaded runtime (one HIP
+# runtime, shared streams); the other order loads two runtimes and every stream handle torch
+# passes us is foreign (hipMemsetAsync fails with an invalid handle).
+import torch  # noqa: F401  (load order, see above)
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("DDCORE_LIB", _HERE / "libddcore.so"))
+
+DD_ABI_VERSION = 1
+DD_OK = 0
+DD_F32, DD_F16 = 0, 1
+DD_VALID_DEPTH_POSITIVE = 0x1
+DD_VALID_MASK = 0x2
+DD_VALID_CONF = 0x4
+DD_ROTATE_NORMALS = 0x8
+
+#: every symbol include/ddcore.h declares
+EXPORTS = (
+    "dd_abi_version",
+    "dd_last_error",
+    "dd_count_valid",
+    "dd_workspace_bytes",
+    "dd_unproject_compact",
+)
+
+
+class DDViewBatch(C.Structure):
+    _fields_ = [
+        ("num_views", C.c_int32),
+        ("height", C.c_int32),
+        ("width", C.c_int32),
+        ("stride", C.c_int32),
+        ("depth", C.c_void_p),
+        ("mask", C.c_void_p),
+        ("conf", C.c_void_p),
+        ("normal", C.c_void_p),
+        ("rgb", C.c_void_p),
+        ("params", C.c_void_p),
+        ("depth_dtype", C.c_int32),
+        ("conf_dtype", C.c_int32),
+        ("conf_threshold", C.c_float),
+        ("flags", C.c_uint32),
+        ("view_index_base", C.c_int32),
+        ("tuning", C.c_uint32),
+    ]
+
+
+class DDCloudOut(C.Structure):
+    _fields_ = [
+        ("xyz", C.c_void_p),
+        ("normal", C.c_void_p),
+        ("rgb", C.c_void_p),
+        ("pixel_index", C.c_void_p),
+        ("view_index", C.c_void_p),
+        ("capacity", C.c_int64),
+    ]
+
+
+class DDCoreError(RuntimeError):
+    """A negative return code from libddcore.so."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libddcore error {code}: {message}")
+        self.code = code
+
+
+def _load() -> C.CDLL:
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP core is not built. There is no CPU fallback; "
+            "run `python -c \"import __graft_entry__ as g; g.build()\"` at the repo root."
+        )
+    lib = C.CDLL(str(LIB_PATH))
+    lib.dd_abi_version.restype = C.c_int
+    lib.dd_abi_version.argtypes = []
+    lib.dd_last_error.restype = C.c_char_p
+    lib.dd_last_error.argtypes = []
+    lib.dd_count_valid.restype = C.c_int
+    lib.dd_count_valid.argtypes = [C.POINTER(DDViewBatch), C.c_void_p, C.c_void_p]
+    lib.dd_workspace_bytes.restype = C.c_int64
+    lib.dd_workspace_bytes.argtypes = [C.POINTER(DDViewBatch)]
+    lib.dd_unproject_compact.restype = C.c_int
+    lib.dd_unproject_compact.argtypes = [
+        C.POINTER(DDViewBatch), C.POINTER(DDCloudOut), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+    ]
+    got = lib.dd_abi_version()
+    if got != DD_ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {got}, binding expects {DD_ABI_VERSION}; rebuild the library")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise DDCoreError(int(rc), lib.dd_last_error().decode("utf-8", "replace"))
+    return rc

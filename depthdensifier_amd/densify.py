@@ -1,0 +1,379 @@
+"""Host side of the depth->points hot path (PyTorch-ROCm tensors in, fused cloud out).
+
+Mirrors, for this path only, what the reference does inline in
+``scripts/test.py:203-244, 262-266`` ("script" semantics) and in
+``COLMAPVisualizer.add_rgbd_pointcloud`` (``src/depthdensifier/visualizer.py:246-376``,
+"viz" semantics).  All arithmetic runs in ``libddcore.so`` (hand-written HIP for
+gfx950) through the C ABI of ``include/ddcore.h``; PyTorch only owns device
+memory and the stream.  There is no CPU implementation here: without a GPU and
+the built library these functions raise.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import DDCloudOut, DDViewBatch, check, lib
+
+ArrayLike = Union[np.ndarray, torch.Tensor]
+
+SEMANTICS = ("script", "viz")
+
+
+# --------------------------------------------------------------------------------------
+# camera blocks (host, float64 -> float32 once)
+# --------------------------------------------------------------------------------------
+
+def intrinsics_matrix(params_or_K: ArrayLike) -> np.ndarray:
+    """(V,3,3) float64 intrinsics from either (V,4) ``fx,fy,cx,cy`` (``camera.params`` of a
+    PINHOLE camera, ``scripts/test.py:81``) or (V,3,3) calibration matrices
+    (``visualizer.py:320``; skew honoured)."""
+    a = np.asarray(params_or_K.cpu() if isinstance(params_or_K, torch.Tensor) else params_or_K, dtype=np.float64)
+    if a.ndim == 1 and a.shape[0] == 4:
+        a = a[None]
+    if a.ndim == 2 and a.shape == (3, 3):
+        a = a[None]
+    if a.ndim == 2 and a.shape[1] == 4:
+        K = np.zeros((a.shape[0], 3, 3))
+        K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2], K[:, 2, 2] = a[:, 0], a[:, 1], a[:, 2], a[:, 3], 1.0
+        return K
+    if a.ndim == 3 and a.shape[1:] == (3, 3):
+        return a
+    raise ValueError(f"intrinsics must be (V,4) fx,fy,cx,cy or (V,3,3); got {a.shape}")
+
+
+def camera_blocks(intrinsics: ArrayLike, cam_from_world: ArrayLike) -> np.ndarray:
+    """(V,32) float32 ``DDViewParams`` rows (``include/ddcore.h``).
+
+    ``ray_to_world = R^T K^-1``, ``centre = -R^T t``, ``rot = R^T`` computed in
+    float64 -- the fusion of ``scripts/test.py:79-90`` with the ``Rigid3d``
+    inverse of ``:233`` (equivalently ``visualizer.py:320-334``).  Accepts
+    (V,3,4) or (V,4,4) extrinsics like ``visualizer.py:325-327``.
+    """
+    K = intrinsics_matrix(intrinsics)
+    E = np.asarray(cam_from_world.cpu() if isinstance(cam_from_world, torch.Tensor) else cam_from_world, dtype=np.float64)
+    if E.ndim == 2:
+        E = E[None]
+    if E.ndim != 3 or E.shape[1] not in (3, 4) or E.shape[2] != 4:
+        raise ValueError(f"cam_from_world must be (V,3,4) or (V,4,4); got {E.shape}")
+    if K.shape[0] == 1 and E.shape[0] > 1:
+        K = np.repeat(K, E.shape[0], axis=0)
+    if K.shape[0] != E.shape[0]:
+        raise ValueError(f"{K.shape[0]} intrinsics for {E.shape[0]} poses")
+    R = E[:, :3, :3]
+    t = E[:, :3, 3]
+    Rt = np.transpose(R, (0, 2, 1))
+    blocks = np.zeros((E.shape[0], 32), dtype=np.float64)
+    blocks[:, 0:9] = (Rt @ np.linalg.inv(K)).reshape(-1, 9)
+    blocks[:, 9:12] = -np.einsum("vij,vj->vi", Rt, t)
+    blocks[:, 12:21] = Rt.reshape(-1, 9)
+    return blocks.astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# result container
+# --------------------------------------------------------------------------------------
+
+@dataclass
+class FusedCloud:
+    """The fused dense cloud: ``final_point_cloud / final_colors / final_normals`` of
+    ``scripts/test.py:264-266`` and the ``PointCloud`` of ``visualizer.py:71-80``, as device
+    tensors, plus what the reference does not keep: ``view_offsets`` (V+1, int64),
+    ``pixel_index`` (``y*W+x``) and ``view_index`` so order can be checked bit-exactly."""
+
+    points: torch.Tensor                   # (N,3) float32
+    colors: Optional[torch.Tensor]         # (N,3) uint8
+    normals: Optional[torch.Tensor]        # (N,3) float32
+    pixel_index: Optional[torch.Tensor]    # (N,) int32
+    view_index: Optional[torch.Tensor]     # (N,) int32
+    view_offsets: torch.Tensor             # (V+1,) int64
+    name: str = "Dense Cloud"
+
+    def __len__(self) -> int:
+        return int(self.points.shape[0])
+
+    @property
+    def counts(self) -> torch.Tensor:
+        return self.view_offsets[1:] - self.view_offsets[:-1]
+
+    def numpy(self) -> dict:
+        """Host copies with the reference's dtypes (points float64 like ``scripts/test.py:264``)."""
+        f = lambda x: None if x is None else x.cpu().numpy()
+        return {
+            "points": self.points.cpu().numpy().astype(np.float64),
+            "colors": f(self.colors),
+            "normals": f(self.normals),
+            "pixel_index": f(self.pixel_index),
+            "view_index": f(self.view_index),
+            "view_offsets": self.view_offsets.cpu().numpy(),
+        }
+
+
+# --------------------------------------------------------------------------------------
+# batch description
+# --------------------------------------------------------------------------------------
+
+def _gpu(x: Optional[ArrayLike], device: torch.device, dtype: Optional[torch.dtype] = None) -> Optional[torch.Tensor]:
+    if x is None:
+        return None
+    t = torch.from_numpy(np.ascontiguousarray(x)) if isinstance(x, np.ndarray) else x
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t.to(device, non_blocking=True).contiguous()
+
+
+def _require_gpu(device=None) -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("depthdensifier_amd needs an AMD GPU (torch.cuda.is_available() is False); "
+                           "there is no CPU fallback for the densify path")
+    return torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+
+
+class ViewBatch:
+    """A stack of V equally sized views resident in HBM (``DDViewBatch`` of ``include/ddcore.h``).
+
+    ``depth`` (V,H,W) float32/float16; ``mask`` (V,H,W) bool/uint8; ``conf`` (V,H,W)
+    float32/float16; ``normal`` (V,H,W,3) float32; ``rgb`` (V,H,W,3) uint8;
+    ``intrinsics`` (V,4) or (V,3,3); ``cam_from_world`` (V,3,4)/(V,4,4).  A single view may be
+    passed without the leading axis.
+    """
+
+    def __init__(self, depth: ArrayLike, intrinsics: ArrayLike, cam_from_world: ArrayLike, *,
+                 mask: Optional[ArrayLike] = None, conf: Optional[ArrayLike] = None,
+                 conf_threshold: Optional[float] = None, normal: Optional[ArrayLike] = None,
+                 rgb: Optional[ArrayLike] = None, stride: int = 1, semantics: str = "script",
+                 rotate_normals: Optional[bool] = None, view_index_base: int = 0, device=None,
+                 tuning: int = 0):
+        if semantics not in SEMANTICS:
+            raise ValueError(f"semantics must be one of {SEMANTICS}")
+        dev = _require_gpu(device)
+        d = _gpu(depth, dev)
+        if d.dim() == 2:
+            d = d[None]
+            mask, conf, normal, rgb = (None if x is None else x[None] for x in (mask, conf, normal, rgb))
+        if d.dim() != 3:
+            raise ValueError(f"depth must be (V,H,W) or (H,W); got {tuple(d.shape)}")
+        if d.dtype not in (torch.float32, torch.float16):
+            d = d.float()
+        self.depth = d.contiguous()
+        V, H, W = self.depth.shape
+        self.mask = _gpu(mask, dev)
+        if self.mask is not None:
+            if self.mask.dtype == torch.bool:
+                self.mask = self.mask.view(torch.uint8)
+            elif self.mask.dtype != torch.uint8:
+                self.mask = (self.mask > 0).view(torch.uint8)          # visualizer.py:312 "mask > 0"
+        self.conf = _gpu(conf, dev)
+        if self.conf is not None and self.conf.dtype not in (torch.float32, torch.float16):
+            self.conf = self.conf.float()
+        if (self.conf is None) != (conf_threshold is None):
+            raise ValueError("conf and conf_threshold must be given together")
+        self.conf_threshold = 0.0 if conf_threshold is None else float(conf_threshold)
+        self.normal = _gpu(normal, dev, torch.float32)
+        self.rgb = _gpu(rgb, dev)
+        if self.rgb is not None and self.rgb.dtype != torch.uint8:
+            # visualizer.py:341-342: float colours in [0,1] are scaled to uint8
+            self.rgb = (self.rgb * 255).to(torch.uint8) if float(self.rgb.max()) <= 1.0 else self.rgb.to(torch.uint8)
+        for name, t, shape in (("mask", self.mask, (V, H, W)), ("conf", self.conf, (V, H, W)),
+                               ("normal", self.normal, (V, H, W, 3)), ("rgb", self.rgb, (V, H, W, 3))):
+            if t is not None and tuple(t.shape) != shape:
+                raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {shape}")
+        if stride < 1:
+            raise ValueError("stride (downsample_density) must be >= 1")
+        self.stride = int(stride)
+        self.semantics = semantics
+        blocks = camera_blocks(intrinsics, cam_from_world)
+        if blocks.shape[0] != V:
+            raise ValueError(f"{blocks.shape[0]} cameras for {V} views")
+        self.params = torch.from_numpy(blocks).to(dev)
+        self.view_index_base = int(view_index_base)
+        self.tuning = int(tuning)
+
+        flags = 0
+        if semantics == "script":
+            # scripts/test.py:194 + :210 -- mask folded into depth, then depth > 0
+            flags |= _lib.DD_VALID_DEPTH_POSITIVE
+            if self.mask is not None:
+                flags |= _lib.DD_VALID_MASK
+            rot_default = False                      # scripts/test.py:220 camera-frame normals
+        else:
+            # visualizer.py:311-314 -- mask only when given, else depth > 0
+            flags |= _lib.DD_VALID_MASK if self.mask is not None else _lib.DD_VALID_DEPTH_POSITIVE
+            rot_default = True                       # visualizer.py:363-374
+        if self.conf is not None:
+            flags |= _lib.DD_VALID_CONF
+        self.rotate_normals = rot_default if rotate_normals is None else bool(rotate_normals)
+        if self.rotate_normals:
+            flags |= _lib.DD_ROTATE_NORMALS
+        self.flags = flags
+        self.device = dev
+
+    # -- sizes -------------------------------------------------------------------------
+    @property
+    def num_views(self) -> int:
+        return int(self.depth.shape[0])
+
+    @property
+    def visited_per_view(self) -> int:
+        _, H, W = self.depth.shape
+        s = self.stride
+        return ((H + s - 1) // s) * ((W + s - 1) // s)
+
+    @property
+    def max_points(self) -> int:
+        return self.num_views * self.visited_per_view
+
+    def c_struct(self) -> DDViewBatch:
+        V, H, W = self.depth.shape
+        ptr = lambda t: None if t is None else t.data_ptr()
+        return DDViewBatch(
+            num_views=V, height=H, width=W, stride=self.stride,
+            depth=ptr(self.depth), mask=ptr(self.mask), conf=ptr(self.conf), normal=ptr(self.normal),
+            rgb=ptr(self.rgb), params=ptr(self.params),
+            depth_dtype=_lib.DD_F16 if self.depth.dtype == torch.float16 else _lib.DD_F32,
+            conf_dtype=_lib.DD_F16 if (self.conf is not None and self.conf.dtype == torch.float16) else _lib.DD_F32,
+            conf_threshold=self.conf_threshold, flags=self.flags,
+            view_index_base=self.view_index_base, tuning=self.tuning,
+        )
+
+
+def _stream(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def count_valid(batch: ViewBatch) -> torch.Tensor:
+    """(V,) int64 device tensor: valid visited pixels per view (the N of ``scripts/test.py:210-212``)."""
+    counts = torch.empty(batch.num_views, dtype=torch.int64, device=batch.device)
+    cb = batch.c_struct()
+    check(lib.dd_count_valid(C.byref(cb), counts.data_ptr(), _stream(batch.device)))
+    return counts
+
+
+# --------------------------------------------------------------------------------------
+# the cloud under construction
+# --------------------------------------------------------------------------------------
+
+class CloudBuilder:
+    """Pre-allocated fused cloud that batches append to on the GPU.
+
+    Replaces the three Python lists + ``np.concatenate`` of ``scripts/test.py:124-127,
+    238-240, 264-266``: every appended batch writes its points directly at their final
+    slot; a device-side cursor carries the running count, so appends never synchronise
+    the host.  ``finish()`` reads the count once and returns exact-size views.
+    """
+
+    def __init__(self, capacity: int, *, normals: bool = False, colors: bool = False,
+                 pixel_index: bool = True, view_index: bool = False, device=None):
+        dev = _require_gpu(device)
+        self.device = dev
+        self.capacity = int(capacity)
+        n = max(self.capacity, 1)
+        self.xyz = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        self.normal = torch.empty((n, 3), dtype=torch.float32, device=dev) if normals else None
+        self.rgb = torch.empty((n, 3), dtype=torch.uint8, device=dev) if colors else None
+        self.pix = torch.empty((n,), dtype=torch.int32, device=dev) if pixel_index else None
+        self.view = torch.empty((n,), dtype=torch.int32, device=dev) if view_index else None
+        self.cursor = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._offsets: list[torch.Tensor] = []
+        self._workspaces: list[torch.Tensor] = []
+        self._ws_cache: Optional[torch.Tensor] = None
+
+    def reset(self) -> None:
+        self.cursor.zero_()
+        self._offsets.clear()
+        self._workspaces.clear()
+
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws_cache is None or self._ws_cache.numel() < nbytes:
+            self._ws_cache = torch.empty(max(nbytes, 1024), dtype=torch.uint8, device=self.device)
+        return self._ws_cache
+
+    def append(self, batch: ViewBatch) -> torch.Tensor:
+        """Enqueue one batch; returns its (V+1,) absolute view offsets (device, valid once the
+        stream has run)."""
+        if self.normal is not None and batch.normal is None:
+            raise ValueError("this cloud carries normals but the batch has no normal map")
+        if self.rgb is not None and batch.rgb is None:
+            raise ValueError("this cloud carries colours but the batch has no rgb image")
+        cb = batch.c_struct()
+        nbytes = check(lib.dd_workspace_bytes(C.byref(cb)))
+        ws = self._workspace(nbytes)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        out = DDCloudOut(xyz=ptr(self.xyz), normal=ptr(self.normal), rgb=ptr(self.rgb),
+                         pixel_index=ptr(self.pix), view_index=ptr(self.view), capacity=self.capacity)
+        offsets = torch.empty(batch.num_views + 1, dtype=torch.int64, device=self.device)
+        check(lib.dd_unproject_compact(C.byref(cb), C.byref(out), offsets.data_ptr(), self.cursor.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), _stream(self.device)))
+        self._offsets.append(offsets)
+        self._workspaces.append(ws)
+        return offsets
+
+    def finish(self, name: str = "Dense Cloud") -> FusedCloud:
+        """Synchronise once, check the scan status words and the capacity, return exact-size views."""
+        total = int(self.cursor.item())
+        for ws in {id(w): w for w in self._workspaces}.values():
+            if int(ws[:8].view(torch.int32)[1].item()) != 0:
+                raise RuntimeError("libddcore: in-kernel scan timed out (workspace error word set)")
+        if total > self.capacity:
+            raise OverflowError(f"cloud capacity {self.capacity} < {total} valid points; "
+                                "allocate with capacity=batch.max_points or count_valid() first")
+        if self._offsets:
+            offs = torch.cat([self._offsets[0]] + [o[1:] for o in self._offsets[1:]])
+        else:
+            offs = torch.zeros(1, dtype=torch.int64, device=self.device)
+        cut = lambda t: None if t is None else t[:total]
+        return FusedCloud(points=self.xyz[:total], colors=cut(self.rgb), normals=cut(self.normal),
+                          pixel_index=cut(self.pix), view_index=cut(self.view), view_offsets=offs, name=name)
+
+
+# --------------------------------------------------------------------------------------
+# one-call entry points
+# --------------------------------------------------------------------------------------
+
+def unproject_views(depth: ArrayLike, intrinsics: ArrayLike, cam_from_world: ArrayLike, *,
+                    mask: Optional[ArrayLike] = None, conf: Optional[ArrayLike] = None,
+                    conf_threshold: Optional[float] = None, normal: Optional[ArrayLike] = None,
+                    rgb: Optional[ArrayLike] = None, downsample_density: int = 1,
+                    semantics: str = "script", rotate_normals: Optional[bool] = None,
+                    capacity: Union[None, int, str] = None, pixel_index: bool = True,
+                    view_index: bool = False, device=None, tuning: int = 0) -> FusedCloud:
+    """Densify + fuse a stack of views: ``scripts/test.py:203-244`` per view and ``:262-266``.
+
+    ``downsample_density`` is ``ProcessingConfig.downsample_density`` (``scripts/test.py:37``; the
+    reference default is 32, the benchmarks use 1).  ``capacity``: ``None`` counts first
+    (``dd_count_valid``) and allocates exactly; ``"max"`` allocates for every visited pixel and
+    skips the count pass; an int is taken as given.
+    """
+    batch = ViewBatch(depth, intrinsics, cam_from_world, mask=mask, conf=conf, conf_threshold=conf_threshold,
+                      normal=normal, rgb=rgb, stride=downsample_density, semantics=semantics,
+                      rotate_normals=rotate_normals, device=device, tuning=tuning)
+    if capacity is None:
+        cap = int(count_valid(batch).sum().item())
+    elif capacity == "max":
+        cap = batch.max_points
+    else:
+        cap = int(capacity)
+    with_normals = batch.normal is not None and (semantics == "script" or batch.mask is not None)
+    builder = CloudBuilder(cap, normals=with_normals, colors=batch.rgb is not None,
+                           pixel_index=pixel_index, view_index=view_index, device=batch.device)
+    builder.append(batch)
+    return builder.finish()
+
+
+def fuse_batches(batches: Sequence[ViewBatch], capacity: Optional[int] = None, **cloud_fields) -> FusedCloud:
+    """Fuse several batches (e.g. views of different resolutions) into one cloud, in order."""
+    if capacity is None:
+        capacity = sum(int(count_valid(b).sum().item()) for b in batches)
+    base = 0
+    builder = CloudBuilder(capacity, device=batches[0].device, **cloud_fields)
+    for b in batches:
+        b.view_index_base = base
+        builder.append(b)
+        base += b.num_views
+    return builder.finish()

@@ -1,0 +1,133 @@
+/*
+ * ddcore.h -- C ABI of libddcore.so, the MI355X (gfx950) densification core.
+ *
+ * The reference (OpsiClear/DepthDensifier) has no FFI / operator boundary: its
+ * depth->points path is inline NumPy in scripts/test.py:203-244 (+ :262-266) and
+ * a second formulation in src/depthdensifier/visualizer.py:246-376.  This header
+ * is the boundary a maintainer would bind instead of that inline block (see
+ * INTEGRATION.md for the ctypes stub).  Plain pointers and sizes only; no torch
+ * or HIP types.  Conventions:
+ *
+ *  - every function returns DD_OK (0) or a negative DD_ERR_* code and never
+ *    throws; dd_last_error() returns a thread-local message for the last error;
+ *  - the caller owns every buffer (device memory unless stated); the library
+ *    allocates nothing and keeps no global mutable state; calls are re-entrant;
+ *  - all work is enqueued asynchronously on `stream` (a hipStream_t passed as
+ *    void*; NULL = the default stream).  Nothing synchronises the host.
+ */
+#ifndef DDCORE_H
+#define DDCORE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DD_ABI_VERSION 1
+
+enum {
+    DD_OK = 0,
+    DD_ERR_INVALID_ARG = -1,  /* NULL / out-of-range field, see dd_last_error() */
+    DD_ERR_LAUNCH = -2,       /* HIP reported an error at enqueue time */
+    DD_ERR_WORKSPACE = -3,    /* workspace too small or mis-aligned */
+    DD_ERR_UNSUPPORTED = -4
+};
+
+/* element type of a depth / confidence map */
+enum { DD_F32 = 0, DD_F16 = 1 };
+
+/* DDViewBatch.flags */
+#define DD_VALID_DEPTH_POSITIVE 0x1u /* depth > 0            scripts/test.py:210, visualizer.py:314 */
+#define DD_VALID_MASK           0x2u /* mask  != 0           scripts/test.py:194, visualizer.py:312 */
+#define DD_VALID_CONF           0x4u /* conf  > threshold    (build-defined)          */
+#define DD_ROTATE_NORMALS       0x8u /* n_w = R^T n / (|R^T n| + 1e-8)   visualizer.py:363-374      */
+
+/*
+ * Per-view camera block, 32 floats (128 B), device memory, built on the host in
+ * float64 and rounded once.  With cam_from_world = [R|t] and intrinsics K:
+ *   ray_to_world = R^T * K^-1   (row-major 3x3)
+ *   centre       = -R^T t
+ *   rot          = R^T          (row-major 3x3, used only with DD_ROTATE_NORMALS)
+ * so that  p_world = depth * (ray_to_world * [u, v, 1]^T) + centre, which is
+ * scripts/test.py:79-90 followed by :233 (and visualizer.py:320-334) fused.
+ */
+typedef struct DDViewParams {
+    float ray_to_world[9];
+    float centre[3];
+    float rot[9];
+    float reserved[11];
+} DDViewParams;
+
+/*
+ * A stack of V equally sized views, each map contiguous row-major, view v at
+ * element offset v*H*W (x3 for normal / rgb).  Replaces the per-image locals of
+ * scripts/test.py:166-168 (depth, normal, mask), :215 (rgb) and :172-178 (camera).
+ */
+typedef struct DDViewBatch {
+    int32_t num_views;
+    int32_t height;
+    int32_t width;
+    int32_t stride;           /* downsample_density, scripts/test.py:37,206; >= 1 */
+    const void *depth;        /* (V,H,W) DD_F32 or DD_F16 */
+    const uint8_t *mask;      /* (V,H,W) bytes, non-zero = keep; required iff DD_VALID_MASK */
+    const void *conf;         /* (V,H,W) DD_F32 or DD_F16;      required iff DD_VALID_CONF */
+    const float *normal;      /* (V,H,W,3) camera-frame unit normals, or NULL */
+    const uint8_t *rgb;       /* (V,H,W,3) or NULL */
+    const DDViewParams *params; /* (V) */
+    int32_t depth_dtype;
+    int32_t conf_dtype;
+    float conf_threshold;
+    uint32_t flags;
+    int32_t view_index_base;  /* added to the per-point view index (global view id of view 0) */
+    uint32_t tuning;          /* 0 = default kernel configuration */
+} DDViewBatch;
+
+/*
+ * The fused cloud (scripts/test.py:264-266 final_point_cloud / final_colors /
+ * final_normals; visualizer.py:71-80 PointCloud), array-of-structs rows exactly
+ * like the reference's (N,3) arrays.  NULL members are not produced.  Points
+ * whose slot is >= capacity are counted but not written.
+ */
+typedef struct DDCloudOut {
+    float *xyz;           /* (capacity,3) */
+    float *normal;        /* (capacity,3); needs DDViewBatch.normal */
+    uint8_t *rgb;         /* (capacity,3); needs DDViewBatch.rgb */
+    int32_t *pixel_index; /* (capacity)  y*W + x inside the view */
+    int32_t *view_index;  /* (capacity)  view_index_base + v */
+    int64_t capacity;
+} DDCloudOut;
+
+int dd_abi_version(void);
+const char *dd_last_error(void);
+
+/* Per-view number of valid visited pixels (the N of scripts/test.py:210-212).
+ * counts_dev: (V) int64, overwritten. */
+int dd_count_valid(const DDViewBatch *batch, int64_t *counts_dev, void *stream);
+
+/* Bytes of scratch dd_unproject_compact needs for this batch (>= 0), or a negative error. */
+int64_t dd_workspace_bytes(const DDViewBatch *batch);
+
+/*
+ * The hot path in one pass: cull, unproject, transform, compact in stable
+ * (view-major, then row-major) order and append to the cloud.
+ *
+ *  cursor_dev       (1) int64, device, in/out: number of points already in the
+ *                   cloud; this batch's points go to slots [cursor, cursor+N)
+ *                   and cursor is advanced by N.  Chaining calls on one stream
+ *                   fuses any number of batches without a host round trip
+ *                   (scripts/test.py:238-240 list append + :264-266 concatenate).
+ *  view_offsets_dev (V+1) int64, device, out: slot of the first point of each
+ *                   view; [V] = cursor after the batch.
+ *  workspace        dd_workspace_bytes() bytes of device scratch, 16-B aligned.
+ *                   After the stream has drained, ((int32_t*)workspace)[1] != 0
+ *                   means the in-kernel scan gave up (should never happen).
+ */
+int dd_unproject_compact(const DDViewBatch *batch, const DDCloudOut *out,
+                         int64_t *view_offsets_dev, int64_t *cursor_dev,
+                         void *workspace, int64_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDCORE_H */

@@ -90,7 +90,8 @@ def unproject_pinhole(px: np.ndarray, py: np.ndarray, depth_values: np.ndarray, 
     fx, fy, cx, cy = (float(p) for p in params)
     xn = (px - cx) / fx
     yn = (py - cy) / fy
-    return np.stack([xn * depth_values, yn * depth_values, depth_values * np.float64(1.0)], axis=-1)
+    with np.errstate(invalid="ignore", over="ignore"):      # inf / NaN depths pass through like in NumPy
+        return np.stack([xn * depth_values, yn * depth_values, depth_values * np.float64(1.0)], axis=-1)
 
 
 def rigid_inverse_apply(cam_from_world: np.ndarray, points_cam: np.ndarray) -> np.ndarray:
@@ -102,7 +103,8 @@ def rigid_inverse_apply(cam_from_world: np.ndarray, points_cam: np.ndarray) -> n
     E = np.asarray(cam_from_world, dtype=np.float64)
     R, t = E[:3, :3], E[:3, 3]
     t_inv = -(R.T @ t)
-    return points_cam @ R + t_inv      # rows: (R^T p)^T = p^T R
+    with np.errstate(invalid="ignore", over="ignore"):
+        return points_cam @ R + t_inv      # rows: (R^T p)^T = p^T R
 
 
 def densify_view_script(depth: np.ndarray,

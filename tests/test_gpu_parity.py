@@ -1,0 +1,342 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the reference goldens.
+
+Bar (BASELINE.json north_star / SURVEY.md 8d): counts, view offsets, pixel / view indices and
+colours bit-exact; pass-through normals bit-exact; rotated normals <= 1e-6 abs; xyz within
+1e-4 relative, measured per point as  max|d| / max(|p_ref|_inf, scene_radius)  with
+scene_radius = max |camera centre| + max finite depth (guards cancellation when |t| >> |p|).
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+XYZ_RTOL = 1e-4
+NORMAL_ATOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def dd():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import depthdensifier_amd
+    return depthdensifier_amd
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import densify_oracle
+    return densify_oracle
+
+
+def scene_radius(cam_from_world, depth):
+    E = np.asarray(cam_from_world, np.float64)
+    centres = -np.einsum("vji,vj->vi", E[:, :3, :3], E[:, :3, 3])
+    d = np.asarray(depth, np.float64)
+    fin = np.isfinite(d)
+    return float(np.abs(centres).max() + (np.abs(d[fin]).max() if fin.any() else 0.0))
+
+
+def assert_xyz(got, ref, radius, rtol=XYZ_RTOL):
+    assert got.shape == ref.shape
+    fin = np.isfinite(ref).all(axis=1)
+    # non-finite reference rows (inf / NaN depth kept by the mask-only or depth>0 rule): the fused
+    # f32 formula need not reproduce which component is inf vs NaN, only that the row is not finite
+    assert not np.isfinite(got[~fin]).all(axis=1).any()
+    if fin.any():
+        denom = np.maximum(np.abs(ref[fin]).max(axis=1), radius)
+        err = np.abs(got[fin] - ref[fin]).max(axis=1) / denom
+        assert err.max() <= rtol, f"xyz rel err {err.max():.3e}"
+
+
+def assert_cloud(cloud, ref, radius, normals="exact"):
+    c = cloud.numpy()
+    assert np.array_equal(c["view_offsets"], ref.view_offsets)
+    assert np.array_equal(c["pixel_index"].astype(np.int64), ref.pixel_index)
+    if c["view_index"] is not None:
+        assert np.array_equal(c["view_index"].astype(np.int64), ref.view_index)
+    assert_xyz(c["points"], ref.points, radius)
+    if ref.colors is not None:
+        assert np.array_equal(c["colors"], ref.colors)
+    if ref.normals is not None:
+        if normals == "exact":
+            assert np.array_equal(c["normals"], ref.normals, equal_nan=True)
+        else:
+            assert np.abs(c["normals"] - ref.normals).max() <= NORMAL_ATOL
+    else:
+        assert c["normals"] is None
+
+
+def _inputs(g, c):
+    keys = ("depth", "mask", "normal", "rgb", "conf", "cam_from_world", "params", "strides", "Kskew")
+    return {k: g[f"{c}_in_{k}"] for k in keys}
+
+
+# ------------------------------------------------------------------ reference goldens
+
+@pytest.mark.parametrize("c", ("a", "b", "c"))
+@pytest.mark.parametrize("tuning", (0, 1))
+def test_golden_script(dd, golden_small, c, tuning):
+    """HIP vs arrays returned by the reference's own _depth_to_pointcloud (see make_goldens.py)."""
+    i = _inputs(golden_small, c)
+    V = i["depth"].shape[0]
+    rad = scene_radius(i["cam_from_world"], i["depth"])
+    for s in i["strides"]:
+        cloud = dd.unproject_views(i["depth"], np.tile(i["params"], (V, 1)), i["cam_from_world"], mask=i["mask"],
+                                   normal=i["normal"], rgb=i["rgb"], downsample_density=int(s), tuning=tuning).numpy()
+        assert np.array_equal(np.diff(cloud["view_offsets"]), golden_small[f"{c}_exp_script_s{s}_counts"])
+        assert_xyz(cloud["points"], golden_small[f"{c}_exp_script_s{s}_points__depth_to_pointcloud"], rad)
+        assert np.array_equal(cloud["colors"], golden_small[f"{c}_exp_script_s{s}_colors__depth_to_pointcloud"])
+
+
+@pytest.mark.parametrize("c", ("a", "b", "c"))
+def test_golden_conf_cull(dd, golden_small, c):
+    i = _inputs(golden_small, c)
+    V = i["depth"].shape[0]
+    cloud = dd.unproject_views(i["depth"], np.tile(i["params"], (V, 1)), i["cam_from_world"], mask=i["mask"],
+                               conf=i["conf"], conf_threshold=0.5).numpy()
+    assert np.array_equal(np.diff(cloud["view_offsets"]), golden_small[f"{c}_exp_conf_s1_counts"])
+    assert_xyz(cloud["points"], golden_small[f"{c}_exp_conf_s1_points__depth_to_pointcloud"],
+               scene_radius(i["cam_from_world"], i["depth"]))
+
+
+@pytest.mark.parametrize("c", ("a", "b", "c"))
+def test_golden_package_formulation(dd, golden_small, c):
+    """visualizer.py semantics: mask-only validity, skewed K, rotated + renormalised normals."""
+    i = _inputs(golden_small, c)
+    V = i["depth"].shape[0]
+    d32 = i["depth"].astype(np.float32)
+    K = np.tile(i["Kskew"], (V, 1, 1))
+    rad = scene_radius(i["cam_from_world"], d32)
+    cloud = dd.unproject_views(d32, K, i["cam_from_world"], mask=i["mask"], normal=i["normal"], rgb=i["rgb"],
+                               semantics="viz").numpy()
+    assert np.array_equal(np.diff(cloud["view_offsets"]), golden_small[f"{c}_exp_viz_counts"])
+    assert_xyz(cloud["points"], golden_small[f"{c}_exp_viz_points__depth_to_pointcloud"], rad)
+    assert np.array_equal(cloud["colors"], golden_small[f"{c}_exp_viz_colors__depth_to_pointcloud"])
+    assert np.abs(cloud["normals"] - golden_small[f"{c}_exp_viz_normals__transform_normals"]).max() <= NORMAL_ATOL
+    nomask = dd.unproject_views(d32, K, i["cam_from_world"], normal=i["normal"], semantics="viz").numpy()
+    assert np.array_equal(np.diff(nomask["view_offsets"]), golden_small[f"{c}_exp_viznomask_counts"])
+    assert_xyz(nomask["points"], golden_small[f"{c}_exp_viznomask_points__depth_to_pointcloud"], rad)
+    assert nomask["normals"] is None          # visualizer.py:276: normals only with a mask
+
+
+@pytest.mark.parametrize("kname", ("ident", "real"))
+@pytest.mark.parametrize("tag", ("dense", "masked"))
+@pytest.mark.parametrize("s", (1, 32))
+def test_vga_config1(dd, orc, golden_vga, vga_inputs, kname, tag, s):
+    """BASELINE config 1 (4 synthetic 640x480 views): HIP vs reference golden and vs the oracle."""
+    g, d = golden_vga, vga_inputs
+    V = d["depth"].shape[0]
+    params = np.tile(g[f"{kname}_params"], (V, 1))
+    mask = None if tag == "dense" else d["mask"]
+    cloud = dd.unproject_views(d["depth"], params, d["cam_from_world"], mask=mask, normal=d["normal"], rgb=d["rgb"],
+                               downsample_density=s, view_index=True)
+    rad = scene_radius(d["cam_from_world"], d["depth"])
+    key = f"{kname}_{tag}_s{s}"
+    c = cloud.numpy()
+    assert np.array_equal(np.diff(c["view_offsets"]), g[f"{key}_counts"])
+    assert_xyz(c["points"][::int(g["sub"])], g[f"{key}_points_sub__depth_to_pointcloud"], rad)
+    ref = orc.densify_scene_script(d["depth"], params, d["cam_from_world"], mask=mask, normal=d["normal"],
+                                   rgb=d["rgb"], stride=s)
+    assert_cloud(cloud, ref, rad)
+
+
+# ------------------------------------------------------------------ oracle sweeps
+
+def _rand_case(seed, V, H, W, dtype=np.float32, rho=0.8, specials=True):
+    from synth import make_views
+    d = make_views(seed, V, H, W, rho=rho, specials=specials, depth_dtype=dtype)
+    rng = np.random.default_rng(seed + 1)
+    d["params"] = np.stack([[W * rng.uniform(0.6, 1.2), W * rng.uniform(0.6, 1.2),
+                             W / 2 + rng.uniform(-3, 3), H / 2 + rng.uniform(-3, 3)] for _ in range(V)])
+    return d
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1), (2, 3, 5), (3, 67, 129), (2, 128, 256), (1, 255, 257), (5, 64, 64)])
+@pytest.mark.parametrize("dtype", (np.float32, np.float16))
+@pytest.mark.parametrize("stride", (1, 2, 7))
+def test_oracle_sweep_script(dd, orc, shape, dtype, stride):
+    """Ragged sizes (scalar path), vector path (H*W % 8 == 0), both depth dtypes, strides."""
+    V, H, W = shape
+    d = _rand_case(1000 + H * W + stride, V, H, W, dtype)
+    cloud = dd.unproject_views(d["depth"], d["params"], d["cam_from_world"], mask=d["mask"], normal=d["normal"],
+                               rgb=d["rgb"], downsample_density=stride, view_index=True)
+    ref = orc.densify_scene_script(d["depth"], d["params"], d["cam_from_world"], mask=d["mask"], normal=d["normal"],
+                                   rgb=d["rgb"], stride=stride)
+    assert_cloud(cloud, ref, scene_radius(d["cam_from_world"], d["depth"]))
+
+
+@pytest.mark.parametrize("conf_dtype", (np.float32, np.float16))
+@pytest.mark.parametrize("dtype", (np.float32, np.float16))
+def test_oracle_conf_dtypes(dd, orc, dtype, conf_dtype):
+    d = _rand_case(77, 2, 96, 160, dtype)
+    conf = d["conf"].astype(conf_dtype)
+    cloud = dd.unproject_views(d["depth"], d["params"], d["cam_from_world"], mask=d["mask"], conf=conf,
+                               conf_threshold=0.5, rgb=d["rgb"])
+    ref = orc.densify_scene_script(d["depth"], d["params"], d["cam_from_world"], mask=d["mask"], rgb=d["rgb"],
+                                   conf=conf, conf_threshold=0.5)
+    assert_cloud(cloud, ref, scene_radius(d["cam_from_world"], d["depth"]))
+
+
+def test_no_mask_dense_and_all_invalid(dd, orc):
+    d = _rand_case(5, 3, 48, 64, specials=False)
+    d["depth"][1] = 0.0                                   # whole view culled by depth > 0
+    cloud = dd.unproject_views(d["depth"], d["params"], d["cam_from_world"], normal=d["normal"])
+    ref = orc.densify_scene_script(d["depth"], d["params"], d["cam_from_world"], normal=d["normal"])
+    assert_cloud(cloud, ref, scene_radius(d["cam_from_world"], d["depth"]))
+    assert int(cloud.counts[1]) == 0 and int(cloud.counts[0]) == 48 * 64
+    empty = dd.unproject_views(np.zeros((2, 8, 8), np.float32), d["params"][:2], d["cam_from_world"][:2])
+    assert len(empty) == 0 and list(empty.view_offsets.cpu().numpy()) == [0, 0, 0]
+
+
+def test_viz_oracle_rotated_normals(dd, orc):
+    d = _rand_case(9, 2, 120, 200, specials=False)
+    K = dd.intrinsics_matrix(d["params"])
+    K[:, 0, 1] = 0.25
+    cloud = dd.unproject_views(d["depth"], K, d["cam_from_world"], mask=d["mask"], normal=d["normal"], rgb=d["rgb"],
+                               semantics="viz")
+    ref = orc.densify_scene_viz(d["depth"], K, d["cam_from_world"], mask=d["mask"], normal=d["normal"], rgb=d["rgb"])
+    assert_cloud(cloud, ref, scene_radius(d["cam_from_world"], d["depth"]), normals="close")
+
+
+def test_script_with_rotated_normals_option(dd, orc):
+    """rotate_normals=True on the script path = a9 normals on a4 validity."""
+    d = _rand_case(10, 1, 64, 64, specials=False)
+    cloud = dd.unproject_views(d["depth"], d["params"], d["cam_from_world"], mask=d["mask"], normal=d["normal"],
+                               rotate_normals=True).numpy()
+    exp = orc.transform_normals_viz(d["normal"][0], d["cam_from_world"][0], d["mask"][0])
+    assert np.abs(cloud["normals"] - exp).max() <= NORMAL_ATOL
+
+
+# ------------------------------------------------------------------ fuse / capacity
+
+def test_chained_batches_equal_one_batch(dd, orc):
+    """scripts/test.py:238-240, 264-266: appending batch after batch == one concatenated cloud."""
+    d = _rand_case(21, 6, 72, 96)
+    ref = orc.densify_scene_script(d["depth"], d["params"], d["cam_from_world"], mask=d["mask"], normal=d["normal"],
+                                   rgb=d["rgb"])
+    parts = [(0, 1), (1, 4), (4, 6)]
+    batches = [dd.ViewBatch(d["depth"][a:b], d["params"][a:b], d["cam_from_world"][a:b], mask=d["mask"][a:b],
+                            normal=d["normal"][a:b], rgb=d["rgb"][a:b]) for a, b in parts]
+    cloud = dd.fuse_batches(batches, normals=True, colors=True, view_index=True)
+    assert_cloud(cloud, ref, scene_radius(d["cam_from_world"], d["depth"]))
+
+
+def test_capacity_overflow_is_detected_and_safe(dd):
+    import torch
+    d = _rand_case(22, 2, 64, 64, specials=False)
+    batch = dd.ViewBatch(d["depth"], d["params"], d["cam_from_world"], mask=d["mask"])
+    n = int(dd.count_valid(batch).sum())
+    builder = dd.CloudBuilder(n - 100)
+    guard = builder.xyz.clone()
+    builder.append(batch)
+    with pytest.raises(OverflowError):
+        builder.finish()
+    torch.cuda.synchronize()
+    assert int(builder.cursor.item()) == n      # the count is still exact
+    full = dd.unproject_views(d["depth"], d["params"], d["cam_from_world"], mask=d["mask"], capacity="max")
+    assert torch.equal(builder.xyz[: n - 100], full.points[: n - 100])
+    assert guard.shape == builder.xyz.shape
+
+
+def test_count_valid_matches_oracle(dd, orc):
+    d = _rand_case(23, 4, 100, 164)
+    for s in (1, 3):
+        batch = dd.ViewBatch(d["depth"], d["params"], d["cam_from_world"], mask=d["mask"], stride=s)
+        ref = orc.densify_scene_script(d["depth"], d["params"], d["cam_from_world"], mask=d["mask"], stride=s)
+        assert np.array_equal(dd.count_valid(batch).cpu().numpy(), np.diff(ref.view_offsets))
+
+
+def test_error_codes(dd):
+    with pytest.raises(ValueError):
+        dd.ViewBatch(np.ones((1, 4, 4), np.float32), np.ones((2, 4)), np.eye(4)[None, :3])
+    with pytest.raises(ValueError):
+        dd.ViewBatch(np.ones((1, 4, 4), np.float32), np.ones((1, 4)), np.eye(4)[None, :3], stride=0)
+    with pytest.raises(ValueError):   # visualizer.py:266-267 raises ValueError without K / E
+        dd.ViewBatch(np.ones((1, 4, 4), np.float32), np.ones((1, 5)), np.eye(4)[None, :3])
+
+
+# ------------------------------------------------------------------ full BASELINE sizes
+
+def _device_stack(V, H, W, seed, depth_dtype="float32"):
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    depth = torch.empty((V, H, W), device="cuda").uniform_(0.5, 8.0, generator=g).to(getattr(torch, depth_dtype))
+    mask = torch.rand((V, H, W), device="cuda", generator=g) < 0.8
+    normal = torch.nn.functional.normalize(torch.randn((V, H, W, 3), device="cuda", generator=g), dim=-1)
+    rgb = torch.randint(0, 256, (V, H, W, 3), device="cuda", generator=g, dtype=torch.uint8)
+    return depth, mask, normal, rgb
+
+
+def _ring_poses(V, radius=4.0):
+    E = np.zeros((V, 3, 4))
+    for v in range(V):
+        a = 2 * np.pi * v / V
+        c = np.array([radius * np.cos(a), 0.3 * np.sin(3 * a), radius * np.sin(a)])
+        z = -c / np.linalg.norm(c)
+        x = np.cross([0, 1.0, 0], z); x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        R = np.stack([x, y, z])                 # cam_from_world rotation
+        E[v, :, :3] = R
+        E[v, :, 3] = -R @ c
+    return E
+
+
+def test_full_size_1080p_properties_and_oracle_sample(dd, orc):
+    """BASELINE configs 2/3 shape (1920x1080, depth+normal+mask+rgb): size-independent properties
+    on all views, full oracle comparison on two of them."""
+    import torch
+    V, H, W = 6, 1080, 1920
+    depth, mask, normal, rgb = _device_stack(V, H, W, 1234)
+    params = np.tile([0.8 * W, 0.8 * W, W / 2, H / 2], (V, 1))
+    E = _ring_poses(V)
+    cloud = dd.unproject_views(depth, params, E, mask=mask, normal=normal, rgb=rgb, view_index=True, capacity="max")
+    counts = cloud.counts.cpu().numpy()
+    assert np.array_equal(counts, mask.sum(dim=(1, 2)).cpu().numpy())           # depth > 0 everywhere
+    offs = cloud.view_offsets.cpu().numpy()
+    pix = cloud.pixel_index.cpu().numpy()
+    for v in range(V):                                                           # sorted inside each view
+        assert np.all(np.diff(pix[offs[v]:offs[v + 1]]) > 0)
+    # pixel_index is exactly the set of kept pixels
+    v = 3
+    assert np.array_equal(pix[offs[v]:offs[v + 1]], np.nonzero(mask[v].reshape(-1).cpu().numpy())[0])
+    # round trip: project the points back through [R|t] and K -> original pixel and depth
+    P = cloud.points[offs[v]:offs[v + 1]].double().cpu().numpy()
+    cam = P @ E[v, :, :3].T + E[v, :, 3]
+    u = cam[:, 0] / cam[:, 2] * params[v, 0] + params[v, 2]
+    w_ = cam[:, 1] / cam[:, 2] * params[v, 1] + params[v, 3]
+    assert np.abs(u - pix[offs[v]:offs[v + 1]] % W).max() < 2e-2
+    assert np.abs(w_ - pix[offs[v]:offs[v + 1]] // W).max() < 2e-2
+    dsel = depth[v].reshape(-1).cpu().numpy()[pix[offs[v]:offs[v + 1]]]
+    assert np.abs(cam[:, 2] - dsel).max() < 1e-4 * 12
+    # idempotence: a second run is bit-identical
+    again = dd.unproject_views(depth, params, E, mask=mask, normal=normal, rgb=rgb, view_index=True, capacity="max")
+    assert torch.equal(again.points, cloud.points) and torch.equal(again.colors, cloud.colors)
+    assert torch.equal(again.normals, cloud.normals) and torch.equal(again.view_offsets, cloud.view_offsets)
+    # oracle on views 0 and 5 (about 1.5 s of NumPy each)
+    dn, mn, nn, cn = (t.cpu().numpy() for t in (depth, mask, normal, rgb))
+    rad = scene_radius(E, dn)
+    for v in (0, 5):
+        ref = orc.densify_view_script(dn[v], params[v], E[v], mask=mn[v], normal=nn[v], rgb=cn[v])
+        sl = slice(offs[v], offs[v + 1])
+        assert np.array_equal(pix[sl], ref["pixel_index"])
+        assert_xyz(cloud.points[sl].double().cpu().numpy(), ref["points"], rad)
+        assert np.array_equal(cloud.colors[sl].cpu().numpy(), ref["colors"])
+        assert np.array_equal(cloud.normals[sl].cpu().numpy(), ref["normals"])
+
+
+def test_full_size_12mp_f16(dd, orc):
+    """BASELINE config 5 shape: 4032x3024 float16 depth in, float32 xyz out, dense (depth > 0)."""
+    import torch
+    V, H, W = 2, 3024, 4032
+    g = torch.Generator(device="cuda").manual_seed(99)
+    depth = torch.empty((V, H, W), device="cuda").uniform_(0.5, 8.0, generator=g).half()
+    params = np.tile([0.8 * W, 0.8 * W, W / 2, H / 2], (V, 1))
+    E = _ring_poses(V)
+    cloud = dd.unproject_views(depth, params, E, capacity="max", pixel_index=True)
+    assert len(cloud) == V * H * W
+    assert torch.equal(cloud.pixel_index[: H * W], torch.arange(H * W, device="cuda", dtype=torch.int32))
+    dn = depth[1].cpu().numpy()
+    ref = orc.densify_view_script(dn, params[1], E[1])
+    assert_xyz(cloud.points[H * W:].double().cpu().numpy(), ref["points"], scene_radius(E, dn))

@@ -1,0 +1,116 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol of include/ddcore.h,
+argument validation returns error codes without touching a GPU, and the host camera-block
+math agrees with the oracle's float64 formulation."""
+
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def libmod():
+    import __graft_entry__ as g
+    g.build()
+    from depthdensifier_amd import _lib
+    return _lib
+
+
+def test_header_symbols_are_exported(libmod):
+    header = (ROOT / "include" / "ddcore.h").read_text()
+    declared = set(re.findall(r"\b(dd_[a-z_]+)\s*\(", header))
+    assert declared == set(libmod.EXPORTS)
+    handle = C.CDLL(str(libmod.LIB_PATH))
+    for sym in declared:
+        assert getattr(handle, sym) is not None
+    assert libmod.lib.dd_abi_version() == libmod.DD_ABI_VERSION
+
+
+def test_struct_layout_matches_header(libmod):
+    # DDViewParams is 32 floats; DDViewBatch / DDCloudOut sizes for the LP64 layout in the header
+    assert C.sizeof(libmod.DDViewBatch) == 4 * 4 + 6 * 8 + 6 * 4
+    assert C.sizeof(libmod.DDCloudOut) == 5 * 8 + 8
+
+
+def _batch(libmod, **kw):
+    b = libmod.DDViewBatch(num_views=2, height=8, width=8, stride=1, depth=0x1000, params=0x2000,
+                           depth_dtype=libmod.DD_F32, flags=libmod.DD_VALID_DEPTH_POSITIVE)
+    for k, v in kw.items():
+        setattr(b, k, v)
+    return b
+
+
+@pytest.mark.parametrize("kw, text", [
+    (dict(num_views=0), "positive"),
+    (dict(stride=0), "stride"),
+    (dict(depth=None), "depth is NULL"),
+    (dict(params=None), "params is NULL"),
+    (dict(depth_dtype=7), "depth_dtype"),
+    (dict(flags=0), "no validity rule"),
+    (dict(flags=0x2), "mask is NULL"),
+    (dict(flags=0x4), "conf is NULL"),
+])
+def test_invalid_arguments_return_codes(libmod, kw, text):
+    b = _batch(libmod, **kw)
+    rc = libmod.lib.dd_workspace_bytes(C.byref(b))
+    assert rc == -1
+    assert text in libmod.lib.dd_last_error().decode()
+    with pytest.raises(libmod.DDCoreError):
+        libmod.check(rc)
+    assert libmod.lib.dd_count_valid(C.byref(b), None, None) == -1
+
+
+def test_workspace_size_and_null_outputs(libmod):
+    b = _batch(libmod, height=1080, width=1920, num_views=3)
+    n = libmod.lib.dd_workspace_bytes(C.byref(b))
+    tiles = -(-1080 * 1920 // 2048) * 3
+    assert n == 16 + 8 * tiles
+    out = libmod.DDCloudOut(capacity=10)
+    assert libmod.lib.dd_unproject_compact(C.byref(b), C.byref(out), None, None, None, 0, None) == -1
+    assert "xyz" in libmod.lib.dd_last_error().decode()
+    assert libmod.lib.dd_count_valid(C.byref(b), None, None) == -1
+
+
+def test_camera_blocks_against_oracle():
+    import depthdensifier_amd as dd
+    from oracle import densify_oracle as orc
+    from synth import random_pose
+
+    rng = np.random.default_rng(3)
+    V = 5
+    E = np.stack([random_pose(rng) for _ in range(V)])
+    params = np.stack([[500 + v, 510 - v, 320.5, 240.25] for v in range(V)]).astype(np.float64)
+    blocks = dd.camera_blocks(params, E).astype(np.float64)
+    px = rng.integers(0, 640, 50)
+    py = rng.integers(0, 480, 50)
+    d = rng.uniform(0.5, 5, 50)
+    for v in range(V):
+        ref = orc.rigid_inverse_apply(E[v], orc.unproject_pinhole(px, py, d, params[v]))
+        M, c = blocks[v, :9].reshape(3, 3), blocks[v, 9:12]
+        got = d[:, None] * (np.stack([px, py, np.ones_like(px)], -1) @ M.T) + c
+        assert np.abs(got - ref).max() < 5e-6 * np.abs(ref).max()
+        assert np.allclose(blocks[v, 12:21].reshape(3, 3), E[v, :, :3].T, atol=1e-7)
+    # (4,4) extrinsics and a single (3,3) K broadcast over views
+    E4 = np.concatenate([E, np.tile([[[0, 0, 0, 1.0]]], (V, 1, 1))], axis=1)
+    K = np.array([[500.0, 0.3, 320], [0, 510, 240], [0, 0, 1]])
+    assert dd.camera_blocks(K, E4).shape == (V, 32)
+    with pytest.raises(ValueError):
+        dd.camera_blocks(np.ones((V, 5)), E)
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    import depthdensifier_amd as dd
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dd.unproject_views(np.ones((1, 4, 4), np.float32), np.array([[1.0, 1, 0, 0]]), np.eye(4)[None, :3])
+
+
+def test_product_never_imports_oracle():
+    for f in (ROOT / "depthdensifier_amd").rglob("*.py"):
+        assert "oracle" not in f.read_text(), f
