@@ -11,6 +11,7 @@ __version__ = "0.1.0"
 
 from ._lib import DDCoreError  # noqa: F401
 from .densify import (  # noqa: F401
+    BatchPlan,
     CloudBuilder,
     FusedCloud,
     ViewBatch,
@@ -18,10 +19,11 @@ from .densify import (  # noqa: F401
     count_valid,
     fuse_batches,
     intrinsics_matrix,
+    plan_batch,
     unproject_views,
 )
 
 __all__ = [
     "CloudBuilder", "FusedCloud", "ViewBatch", "camera_blocks", "count_valid", "fuse_batches",
-    "intrinsics_matrix", "unproject_views", "DDCoreError", "__version__",
+    "intrinsics_matrix", "plan_batch", "BatchPlan", "unproject_views", "DDCoreError", "__version__",
 ]

@@ -21,7 +21,7 @@ import torch  # noqa: F401  (load order, see above)
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("DDCORE_LIB", _HERE / "libddcore.so"))
 
-DD_ABI_VERSION = 1
+DD_ABI_VERSION = 2
 DD_OK = 0
 DD_F32, DD_F16 = 0, 1
 DD_VALID_DEPTH_POSITIVE = 0x1
@@ -35,6 +35,8 @@ EXPORTS = (
     "dd_last_error",
     "dd_count_valid",
     "dd_workspace_bytes",
+    "dd_plan",
+    "dd_scatter",
     "dd_unproject_compact",
 )
 
@@ -94,6 +96,10 @@ def _load() -> C.CDLL:
     lib.dd_count_valid.argtypes = [C.POINTER(DDViewBatch), C.c_void_p, C.c_void_p]
     lib.dd_workspace_bytes.restype = C.c_int64
     lib.dd_workspace_bytes.argtypes = [C.POINTER(DDViewBatch)]
+    lib.dd_plan.restype = C.c_int
+    lib.dd_plan.argtypes = [C.POINTER(DDViewBatch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.dd_scatter.restype = C.c_int
+    lib.dd_scatter.argtypes = [C.POINTER(DDViewBatch), C.POINTER(DDCloudOut), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.dd_unproject_compact.restype = C.c_int
     lib.dd_unproject_compact.argtypes = [
         C.POINTER(DDViewBatch), C.POINTER(DDCloudOut), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,

@@ -59,7 +59,10 @@ struct KArgs {
     const long long *cursor;
     WsHeader *hdr;
     unsigned long long *tile_state;
-    unsigned long long *counts;   // count kernel only
+    unsigned long long *counts;   // per-view counts (dd_count_valid)
+    unsigned *tile_cnt;           // two-pass: valid pixels per tile
+    unsigned *tile_off;           // two-pass: first row of the tile inside its view
+    long long *view_tot;          // two-pass: valid pixels per view
     long long hw;                 // H*W
     int V, H, W, stride;
     int Hs, Ws;                   // visited grid
@@ -248,7 +251,7 @@ __device__ __forceinline__ long long lookback(unsigned long long *state, unsigne
 }
 
 // ---- the hot kernel ------------------------------------------------------------------------------
-template <typename DepthT, int VEC, int CHUNKS, bool CONTIG>
+template <typename DepthT, int VEC, int CHUNKS, bool CONTIG, bool SINGLE_PASS>
 __global__ __launch_bounds__(BLOCK) void unproject_compact_kernel(const KArgs a) {
     constexpr int TILE = BLOCK * VEC * CHUNKS;
     static_assert(TILE <= 65536, "tile-local index is 16 bit");
@@ -262,10 +265,15 @@ __global__ __launch_bounds__(BLOCK) void unproject_compact_kernel(const KArgs a)
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
-    if (tid == 0) s_ticket = atomicAdd(&a.hdr->ticket, 1u);
-    __syncthreads();
-    const unsigned t = __builtin_amdgcn_readfirstlane(s_ticket);
-    if (t >= a.num_tiles) return;
+    unsigned t;
+    if constexpr (SINGLE_PASS) {
+        if (tid == 0) s_ticket = atomicAdd(&a.hdr->ticket, 1u);
+        __syncthreads();
+        t = __builtin_amdgcn_readfirstlane(s_ticket);
+        if (t >= a.num_tiles) return;
+    } else {
+        t = blockIdx.x;
+    }
     const int v = (int)(t / a.tiles_per_view);
     const unsigned tv = t - (unsigned)v * a.tiles_per_view;
     const unsigned q0 = tv * (unsigned)TILE;
@@ -308,17 +316,21 @@ __global__ __launch_bounds__(BLOCK) void unproject_compact_kernel(const KArgs a)
         }
     }
 
-    if (wave == 0) {
-        const long long base = *a.cursor;
-        const long long excl = lookback(a.tile_state, t, n, base, lane, &a.hdr->error);
-        if (lane == 0) {
-            s_excl = excl;
-            if (tv == 0) a.view_offsets[v] = excl;
-            if (t == a.num_tiles - 1) a.view_offsets[a.V] = excl + n;
+    if constexpr (SINGLE_PASS) {
+        if (wave == 0) {
+            const long long base = *a.cursor;
+            const long long e = lookback(a.tile_state, t, n, base, lane, &a.hdr->error);
+            if (lane == 0) {
+                s_excl = e;
+                if (tv == 0) a.view_offsets[v] = e;
+                if (t == a.num_tiles - 1) a.view_offsets[a.V] = e + n;
+            }
         }
     }
     __syncthreads();
-    const long long excl = s_excl;
+    long long excl;
+    if constexpr (SINGLE_PASS) excl = s_excl;
+    else excl = a.view_offsets[v] + (long long)a.tile_off[t];
 
     // ---- one lane per output point ----
     const DDViewParams *vp = a.params + v;
@@ -369,6 +381,397 @@ __global__ __launch_bounds__(BLOCK) void unproject_compact_kernel(const KArgs a)
     }
 }
 
+// ==================================================================================================
+// Lean path (stride 1, vector-aligned maps).  Sized for latency tolerance: <= 80 VGPRs and 24 KiB of
+// LDS per 256-thread workgroup -> 6 workgroups (24 waves) per CU, every load of a tile issued
+// back to back, gathers of the next group of points in flight while the current group is stored.
+//
+//  * a tile is 4096 consecutive pixels of one view; wave w owns the contiguous span
+//    [q0 + 1024 w, +1024); lane l owns CH groups of VEC pixels, group ch at
+//    q0 + 1024 w + (64 ch + l) VEC, so each load instruction of a wave is one contiguous run;
+//  * validity -> wave ballots -> tile-local rank; surviving pixels are listed in LDS (16-bit pixel
+//    index + depth) in output order; then ONE LANE PER OUTPUT POINT computes xyz and copies the
+//    attributes, so consecutive lanes write consecutive rows of the (N,3) outputs;
+//  * SINGLE_PASS: the tile's first output row comes from a ticket + decoupled look-back;
+//    otherwise (two-pass) from the offsets produced by count_lean + the two scan kernels, and
+//    the workgroup has no dependency on any other workgroup.
+// ==================================================================================================
+constexpr int L_PXT = 16;                    // pixels per lane per tile
+constexpr int L_WSPAN = 64 * L_PXT;          // 1024 pixels per wave
+constexpr int L_TILE = WAVES * L_WSPAN;      // 4096
+
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+typedef u32x3 u32x3_unaligned __attribute__((aligned(1)));
+typedef unsigned u32_unaligned __attribute__((aligned(1)));
+
+template <typename DepthT> __device__ __forceinline__ float raw_depth(const uint4 &d, int k);
+template <> __device__ __forceinline__ float raw_depth<float>(const uint4 &d, int k) {
+    return __uint_as_float(k == 0 ? d.x : k == 1 ? d.y : k == 2 ? d.z : d.w);
+}
+template <> __device__ __forceinline__ float raw_depth<_Float16>(const uint4 &d, int k) {
+    const unsigned w = (k >> 1) == 0 ? d.x : (k >> 1) == 1 ? d.y : (k >> 1) == 2 ? d.z : d.w;
+    const unsigned short h = (unsigned short)((k & 1) ? (w >> 16) : (w & 0xffffu));
+    _Float16 f;
+    __builtin_memcpy(&f, &h, 2);
+    return (float)f;
+}
+
+// Loads + validity bits of the CH groups a lane owns.  Addresses of out-of-range groups are clamped
+// (P % VEC == 0, so a group is entirely in or out) to keep every load unconditional: the compiler
+// then issues them all before the first use.
+template <typename DepthT, bool HAS_MASK>
+__device__ __forceinline__ void lean_load_test(const KArgs &a, long long vbase, unsigned qw, int lane,
+                                               uint4 (&d)[L_PXT / (16 / (int)sizeof(DepthT))],
+                                               unsigned (&bits)[L_PXT / (16 / (int)sizeof(DepthT))]) {
+    constexpr int VEC = 16 / (int)sizeof(DepthT), CH = L_PXT / VEC;
+    unsigned mk[CH][VEC / 4];
+    bool inside[CH];
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+        unsigned qb = qw + (unsigned)(ch * 64 + lane) * VEC;
+        inside[ch] = qb < a.P;
+        if (!inside[ch]) qb = a.P - VEC;
+        const long long e = vbase + qb;
+        d[ch] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const DepthT *>(a.depth) + e);
+        if constexpr (HAS_MASK) {
+#pragma unroll
+            for (int i = 0; i < VEC / 4; ++i) mk[ch][i] = *reinterpret_cast<const unsigned *>(a.mask + e + 4 * i);
+        }
+    }
+    const bool use_depth = a.flags & DD_VALID_DEPTH_POSITIVE;
+    const bool use_conf = a.flags & DD_VALID_CONF;
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+        unsigned b = inside[ch] ? ((1u << VEC) - 1u) : 0u;
+        if constexpr (HAS_MASK) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k)
+                if (((mk[ch][k >> 2] >> (8 * (k & 3))) & 0xffu) == 0) b &= ~(1u << k);
+        }
+        if (use_depth) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k)
+                if (!(raw_depth<DepthT>(d[ch], k) > 0.0f)) b &= ~(1u << k);
+        }
+        if (use_conf && inside[ch]) {          // rare: confidence map (scalar loads, not on the benchmark path)
+            const long long e = vbase + qw + (unsigned)(ch * 64 + lane) * VEC;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float cf = a.conf_f16 ? (float)reinterpret_cast<const _Float16 *>(a.conf)[e + k]
+                                            : reinterpret_cast<const float *>(a.conf)[e + k];
+                if (!(cf > a.conf_thr)) b &= ~(1u << k);
+            }
+        }
+        bits[ch] = b;
+    }
+}
+
+// Look-back for tiles of <= 4096 pixels: aggregates fit 13 bits, so their wave sum is taken with
+// bit-sliced ballots (scalar popcounts) and the single inclusive value with a readlane.
+__device__ __forceinline__ long long lookback13(unsigned long long *state, unsigned t, unsigned agg,
+                                                long long base, int lane, int *err) {
+    long long excl = 0;
+    long long look = (long long)t - 1;
+    unsigned spins = 0;
+    for (;;) {
+        const long long idx = look - lane;
+        const unsigned long long s = (idx >= 0) ? ld_state(&state[idx]) : (ST_INCL | (unsigned long long)base);
+        const unsigned st = (unsigned)(s >> 62);
+        const unsigned long long incl_b = __ballot(st == 2u);
+        const unsigned long long empty_b = __ballot(st == 0u);
+        const int first_incl = incl_b ? __builtin_ctzll(incl_b) : 64;
+        const unsigned long long need = (first_incl >= 63) ? ~0ull : ((2ull << first_incl) - 1ull);
+        if (empty_b & need) {
+            if (++spins > SPIN_LIMIT) {
+                if (lane == 0) atomicExch(err, 1);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+        }
+        const unsigned aggv = (lane < first_incl) ? (unsigned)s : 0u;
+        unsigned sum = 0;
+#pragma unroll
+        for (int b = 0; b < 13; ++b) sum += (unsigned)__popcll(__ballot((aggv >> b) & 1u)) << b;
+        excl += sum;
+        if (incl_b) {
+            const unsigned lo = __builtin_amdgcn_readlane((unsigned)s, first_incl);
+            const unsigned hi = __builtin_amdgcn_readlane((unsigned)(s >> 32), first_incl);
+            excl += (long long)((((unsigned long long)hi << 32) | lo) & VAL_MASK);
+            break;
+        }
+        look -= 64;
+    }
+    if (lane == 0) st_state(&state[t], ST_INCL | (unsigned long long)(excl + agg));
+    return excl;
+}
+
+template <typename DepthT, bool HAS_MASK, bool SINGLE_PASS, bool HAS_NORMAL, bool HAS_RGB>
+__global__ __launch_bounds__(BLOCK, 6) void compact_lean(const KArgs a) {
+    constexpr int VEC = 16 / (int)sizeof(DepthT), CH = L_PXT / VEC, CSPAN = 64 * VEC;
+    __shared__ float s_d[L_TILE];              // 16 KiB
+    __shared__ unsigned short s_q[L_TILE];     //  8 KiB
+    __shared__ unsigned s_tot[WAVES];
+    __shared__ long long s_excl;
+    __shared__ unsigned s_ticket;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    unsigned t;
+    if constexpr (SINGLE_PASS) {
+        if (tid == 0) s_ticket = atomicAdd(&a.hdr->ticket, 1u);
+        __syncthreads();
+        t = __builtin_amdgcn_readfirstlane(s_ticket);
+        if (t >= a.num_tiles) return;
+    } else {
+        t = blockIdx.x;
+    }
+    const unsigned v = t / a.tiles_per_view;
+    const unsigned tv = t - v * a.tiles_per_view;
+    const long long vbase = (long long)v * a.hw;
+    const unsigned q0 = tv * (unsigned)L_TILE;
+    const unsigned qw = q0 + (unsigned)wave * L_WSPAN;
+
+    uint4 d[CH];
+    unsigned bits[CH];
+    lean_load_test<DepthT, HAS_MASK>(a, vbase, qw, lane, d, bits);
+
+    int lane_pre[CH], tot[CH], m = 0;
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+        wave_rank<VEC>(bits[ch], lane, lane_pre[ch], tot[ch]);
+        m += tot[ch];
+    }
+    if (lane == 0) s_tot[wave] = (unsigned)m;
+    __syncthreads();   // #1
+
+    unsigned wbase = 0, n = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+        if (w < wave) wbase += s_tot[w];
+        n += s_tot[w];
+    }
+    if constexpr (SINGLE_PASS) {                       // publish the aggregate as early as possible
+        if (tid == 0) st_state(&a.tile_state[t], ST_AGG | (unsigned long long)n);
+    }
+    {   // tile-local list of surviving pixels, in output order
+        int cum = (int)wbase;
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) {
+            int r = cum + lane_pre[ch];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                if ((bits[ch] >> k) & 1u) {
+                    s_q[r] = (unsigned short)(wave * L_WSPAN + ch * CSPAN + lane * VEC + k);
+                    s_d[r] = raw_depth<DepthT>(d[ch], k);
+                    ++r;
+                }
+            }
+            cum += tot[ch];
+        }
+    }
+    if constexpr (SINGLE_PASS) {
+        if (wave == 0) {
+            const long long e = lookback13(a.tile_state, t, n, *a.cursor, lane, &a.hdr->error);
+            if (lane == 0) {
+                s_excl = e;
+                if (tv == 0) a.view_offsets[v] = e;
+                if (t == a.num_tiles - 1) a.view_offsets[a.V] = e + n;
+            }
+        }
+    }
+    __syncthreads();   // #2
+    long long excl;
+    if constexpr (SINGLE_PASS) excl = s_excl;
+    else excl = a.view_offsets[v] + (long long)a.tile_off[t];
+    if (n == 0) return;
+
+    // ---- one lane per output point; gathers of group i+1 in flight while group i is stored ----
+    // Gathers are unconditional and branch-free (lanes past the end re-read point 0) so that the
+    // loop is straight-line code and the compiler can keep counted vmcnt waits.
+    const float *par = reinterpret_cast<const float *>(a.params + v);
+    const float m00 = par[0], m01 = par[1], m02 = par[2], m10 = par[3], m11 = par[4], m12 = par[5];
+    const float m20 = par[6], m21 = par[7], m22 = par[8], c0 = par[9], c1 = par[10], c2 = par[11];
+    const float r00 = par[12], r01 = par[13], r02 = par[14], r10 = par[15], r11 = par[16], r12 = par[17];
+    const float r20 = par[18], r21 = par[19], r22 = par[20];
+    const bool rotate = a.flags & DD_ROTATE_NORMALS;
+    const unsigned W = (unsigned)a.W;
+    const unsigned y0 = q0 / W;
+    const unsigned rowstart = y0 * W;
+    const float invW = 1.0f / (float)W;
+    const float *__restrict__ nsrc = a.normal + vbase * 3;
+    const unsigned char *__restrict__ csrc = a.rgb + vbase * 3;
+
+    struct Pt { float x, y, z; f32x3 nr; unsigned rgbw; unsigned q; };
+    auto prep = [&](int i, Pt &p) {
+        const int j = i * BLOCK + tid;
+        const int jj = j < (int)n ? j : 0;
+        const unsigned q = q0 + s_q[jj];
+        const float dd = s_d[jj];
+        const unsigned r = q - rowstart;                 // < 4096 + W
+        unsigned yo = (unsigned)((float)r * invW);
+        if (yo * W > r) --yo; else if ((yo + 1) * W <= r) ++yo;
+        const float fy = (float)(y0 + yo), fx = (float)(r - yo * W);
+        p.x = fmaf(dd, fmaf(m00, fx, fmaf(m01, fy, m02)), c0);
+        p.y = fmaf(dd, fmaf(m10, fx, fmaf(m11, fy, m12)), c1);
+        p.z = fmaf(dd, fmaf(m20, fx, fmaf(m21, fy, m22)), c2);
+        p.q = q;
+        if constexpr (HAS_NORMAL) p.nr = *reinterpret_cast<const f32x3 *>(nsrc + (size_t)q * 3);
+        if constexpr (HAS_RGB) {
+            // the 3 colour bytes with ONE unaligned dword load that stays inside the view's image:
+            // bytes [3q-1, 3q+3) for q > 0 (colour in the upper 3 bytes), [0, 4) for q == 0
+            p.rgbw = *reinterpret_cast<const u32_unaligned *>(csrc + (size_t)q * 3 - (q ? 1 : 0));
+        }
+    };
+    auto emit = [&](int i, const Pt &p) {
+        const int j = i * BLOCK + tid;
+        const long long slot = excl + j;
+        const bool act = (j < (int)n) && (slot < a.capacity);
+        if (act) {
+            f32x3 o; o.x = p.x; o.y = p.y; o.z = p.z;
+            *reinterpret_cast<f32x3 *>(a.out_xyz + slot * 3) = o;
+            if (a.out_pix) a.out_pix[slot] = (int)p.q;
+            if (a.out_view) a.out_view[slot] = a.view_base + (int)v;
+        }
+        if constexpr (HAS_NORMAL) {
+            f32x3 nv = p.nr;
+            if (rotate) {
+                const float w0 = r00 * nv.x + r01 * nv.y + r02 * nv.z;
+                const float w1 = r10 * nv.x + r11 * nv.y + r12 * nv.z;
+                const float w2 = r20 * nv.x + r21 * nv.y + r22 * nv.z;
+                const float inv = 1.0f / (sqrtf(w0 * w0 + w1 * w1 + w2 * w2) + 1e-8f);
+                nv.x = w0 * inv; nv.y = w1 * inv; nv.z = w2 * inv;
+            }
+            if (act) *reinterpret_cast<f32x3 *>(a.out_normal + slot * 3) = nv;
+        }
+        if constexpr (HAS_RGB) {
+            // rows of 4 consecutive lanes -> 12 contiguous bytes, stored by the quad's first lane
+            const unsigned c0w = p.q ? (p.rgbw >> 8) : (p.rgbw & 0xffffffu);
+            const unsigned c1w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)c0w, 0xF9, 0xF, 0xF, false);  // quad_perm [1,2,3,3]
+            const unsigned c2w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)c0w, 0xFE, 0xF, 0xF, false);  // quad_perm [2,3,3,3]
+            const unsigned c3w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)c0w, 0xFF, 0xF, 0xF, false);  // quad_perm [3,3,3,3]
+            const unsigned long long am = __ballot(act);
+            const unsigned quad = (unsigned)(am >> (lane & ~3)) & 0xFu;
+            unsigned char *dst = a.out_rgb + slot * 3;
+            if (quad == 0xFu) {
+                if ((lane & 3) == 0) {
+                    u32x3 w;
+                    w.x = c0w | (c1w << 24);
+                    w.y = (c1w >> 8) | (c2w << 16);
+                    w.z = (c2w >> 16) | (c3w << 8);
+                    *reinterpret_cast<u32x3_unaligned *>(dst) = w;
+                }
+            } else if (act) {        // ragged end of the run (or capacity cut): byte stores
+                dst[0] = (unsigned char)c0w; dst[1] = (unsigned char)(c0w >> 8); dst[2] = (unsigned char)(c0w >> 16);
+            }
+        }
+    };
+
+    constexpr int NI = L_TILE / BLOCK;       // 16 point slots per lane at most
+    Pt pa, pb;
+    prep(0, pa);
+#pragma unroll
+    for (int i = 0; i < NI; i += 2) {
+        prep(i + 1, pb);
+        emit(i, pa);
+        if ((i + 1) * BLOCK >= (int)n) break;
+        if (i + 2 < NI) prep(i + 2, pa);
+        emit(i + 1, pb);
+        if ((i + 2) * BLOCK >= (int)n) break;
+    }
+}
+
+// ---- pass 1 of the two-pass mode (and dd_count_valid on aligned maps) ----------------------------
+template <typename DepthT, bool HAS_MASK>
+__global__ __launch_bounds__(BLOCK) void count_lean(const KArgs a) {
+    constexpr int VEC = 16 / (int)sizeof(DepthT), CH = L_PXT / VEC;
+    __shared__ unsigned s_tot[WAVES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned t = blockIdx.x;
+    const unsigned v = t / a.tiles_per_view;
+    const unsigned tv = t - v * a.tiles_per_view;
+    uint4 d[CH];
+    unsigned bits[CH];
+    lean_load_test<DepthT, HAS_MASK>(a, (long long)v * a.hw, tv * (unsigned)L_TILE + (unsigned)wave * L_WSPAN, lane, d, bits);
+    unsigned cnt = 0;
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) cnt += __popc(bits[ch]);
+    unsigned tot = 0;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) tot += (unsigned)__popcll(__ballot((cnt >> b) & 1u)) << b;   // cnt <= 16
+    if (lane == 0) s_tot[wave] = tot;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned n = 0;
+        for (int w = 0; w < WAVES; ++w) n += s_tot[w];
+        if (a.tile_cnt) a.tile_cnt[t] = n;
+        if (a.counts && n) atomicAdd(&a.counts[v], (unsigned long long)n);
+    }
+}
+
+// Exclusive scan of one view's tile counts (one workgroup per view) + the view's total.
+__global__ __launch_bounds__(BLOCK) void scan_view_tiles(const KArgs a) {
+    __shared__ unsigned s_w[WAVES];
+    __shared__ unsigned s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned v = blockIdx.x;
+    const unsigned *cnt = a.tile_cnt + (size_t)v * a.tiles_per_view;
+    unsigned *off = a.tile_off + (size_t)v * a.tiles_per_view;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (unsigned b = 0; b < a.tiles_per_view; b += BLOCK) {
+        const unsigned i = b + tid;
+        const unsigned x = i < a.tiles_per_view ? cnt[i] : 0u;
+        unsigned incl = x;                           // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        unsigned pre = s_carry;
+        for (int w = 0; w < wave; ++w) pre += s_w[w];
+        if (i < a.tiles_per_view) off[i] = pre + incl - x;
+        __syncthreads();
+        if (tid == BLOCK - 1) s_carry = pre + incl;
+        __syncthreads();
+    }
+    if (tid == 0) a.view_tot[v] = (long long)s_carry;
+}
+
+// Exclusive scan of the per-view totals (one workgroup): absolute first row of every view.
+__global__ __launch_bounds__(BLOCK) void scan_views(const KArgs a) {
+    __shared__ long long s_w[WAVES];
+    __shared__ long long s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = *a.cursor;
+    __syncthreads();
+    for (int b = 0; b < a.V; b += BLOCK) {
+        const int i = b + tid;
+        const long long x = i < a.V ? a.view_tot[i] : 0ll;
+        long long incl = x;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const long long y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        long long pre = s_carry;
+        for (int w = 0; w < wave; ++w) pre += s_w[w];
+        if (i < a.V) a.view_offsets[i] = pre + incl - x;
+        __syncthreads();
+        if (tid == BLOCK - 1) s_carry = pre + incl;
+        __syncthreads();
+    }
+    if (tid == 0) a.view_offsets[a.V] = s_carry;
+}
+
 // ---- per-view counts (scripts/test.py:210-212 "valid_pixels", without producing points) ----------
 template <typename DepthT, int VEC, int CHUNKS, bool CONTIG>
 __global__ __launch_bounds__(BLOCK) void count_valid_kernel(const KArgs a) {
@@ -391,7 +794,8 @@ __global__ __launch_bounds__(BLOCK) void count_valid_kernel(const KArgs a) {
     if (tid == 0) {
         int tot = 0;
         for (int w = 0; w < WAVES; ++w) tot += s_part[w];
-        if (tot) atomicAdd(&a.counts[v], (unsigned long long)tot);
+        if (a.tile_cnt) a.tile_cnt[t] = (unsigned)tot;
+        if (a.counts && tot) atomicAdd(&a.counts[v], (unsigned long long)tot);
     }
 }
 
@@ -403,10 +807,15 @@ int fail(int code, const char *msg) {
     return code;
 }
 
+// DDViewBatch.tuning bits (0 = defaults)
+constexpr unsigned TUNE_FORCE_GENERIC = 1u;   // scalar kernels even on aligned stride-1 maps (testing)
+constexpr unsigned TUNE_SINGLE_PASS = 8u;     // dd_unproject_compact: ticket + decoupled look-back instead of plan + scatter
+
 struct Plan {
     bool f16;
-    bool contig;
-    int vec, chunks, tile;
+    bool lean;      // stride-1, vector-aligned maps -> lean kernels; otherwise the generic scalar kernels
+    bool single;    // single-pass requested (dd_unproject_compact only)
+    int tile;
 };
 
 int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
@@ -438,15 +847,13 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
 
     p.f16 = (b->depth_dtype == DD_F16);
     const int vec = p.f16 ? 8 : 4;
-    const uintptr_t dp = (uintptr_t)b->depth, mp = (uintptr_t)b->mask, cp = (uintptr_t)b->conf;
-    bool ok = (b->stride == 1) && (hw % vec == 0) && (dp % 16 == 0);
-    if (b->flags & DD_VALID_MASK) ok = ok && (mp % vec == 0);
-    if (b->flags & DD_VALID_CONF) ok = ok && (cp % 16 == 0);
-    if (b->tuning & 1u) ok = false;   // tuning bit 0: force the scalar path (testing)
-    p.contig = ok;
-    p.vec = ok ? vec : 1;
-    p.chunks = ok ? (p.f16 ? 1 : 2) : 8;
-    p.tile = BLOCK * p.vec * p.chunks;
+    bool aligned = (b->stride == 1) && (hw % vec == 0) && ((uintptr_t)b->depth % 16 == 0);
+    if (b->flags & DD_VALID_MASK) aligned = aligned && ((uintptr_t)b->mask % 4 == 0);
+    if (b->flags & DD_VALID_CONF) aligned = aligned && ((uintptr_t)b->conf % 16 == 0);
+    if (b->tuning & TUNE_FORCE_GENERIC) aligned = false;
+    p.lean = aligned;
+    p.single = (b->tuning & TUNE_SINGLE_PASS) != 0;
+    p.tile = p.lean ? L_TILE : BLOCK * 8;
     a.tiles_per_view = (a.P + p.tile - 1) / p.tile;
     const unsigned long long nt = (unsigned long long)a.tiles_per_view * (unsigned)a.V;
     if (nt >= (1ull << 31)) return fail(DD_ERR_UNSUPPORTED, "too many tiles in one batch; split the batch");
@@ -454,32 +861,87 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
     return DD_OK;
 }
 
-int launch_compact(const Plan &p, const KArgs &a, hipStream_t s) {
-    const dim3 grid(a.num_tiles), block(BLOCK);
-    if (p.contig) {
-        if (p.f16) hipLaunchKernelGGL((unproject_compact_kernel<_Float16, 8, 1, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((unproject_compact_kernel<float, 4, 2, true>), grid, block, 0, s, a);
-    } else {
-        if (p.f16) hipLaunchKernelGGL((unproject_compact_kernel<_Float16, 1, 8, false>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((unproject_compact_kernel<float, 1, 8, false>), grid, block, 0, s, a);
-    }
-    return hipGetLastError() == hipSuccess ? DD_OK : DD_ERR_LAUNCH;
+// workspace: [WsHeader][8 B per tile: look-back granules | (tile_cnt u32[T], tile_off u32[T])][8 B per view]
+int64_t ws_bytes(const KArgs &a) {
+    return (int64_t)sizeof(WsHeader) + (int64_t)a.num_tiles * 8 + (int64_t)a.V * 8;
 }
 
-int launch_count(const Plan &p, const KArgs &a, hipStream_t s) {
+int bind_workspace(KArgs &a, void *workspace, int64_t workspace_bytes) {
+    if (!workspace || ((uintptr_t)workspace % 16) != 0) return fail(DD_ERR_WORKSPACE, "workspace is NULL or not 16-byte aligned");
+    if (workspace_bytes < ws_bytes(a)) return fail(DD_ERR_WORKSPACE, "workspace too small (see dd_workspace_bytes)");
+    char *w = reinterpret_cast<char *>(workspace);
+    a.hdr = reinterpret_cast<WsHeader *>(w);
+    a.tile_state = reinterpret_cast<unsigned long long *>(w + sizeof(WsHeader));
+    a.tile_cnt = reinterpret_cast<unsigned *>(w + sizeof(WsHeader));
+    a.tile_off = a.tile_cnt + a.num_tiles;
+    a.view_tot = reinterpret_cast<long long *>(w + sizeof(WsHeader) + (size_t)a.num_tiles * 8);
+    return DD_OK;
+}
+
+int bind_output(KArgs &a, const DDViewBatch *batch, const DDCloudOut *out) {
+    if (!out || !out->xyz) return fail(DD_ERR_INVALID_ARG, "out / out->xyz is NULL");
+    if (out->capacity < 0) return fail(DD_ERR_INVALID_ARG, "capacity is negative");
+    if (out->normal && !batch->normal) return fail(DD_ERR_INVALID_ARG, "out->normal requested but batch->normal is NULL");
+    if (out->rgb && !batch->rgb) return fail(DD_ERR_INVALID_ARG, "out->rgb requested but batch->rgb is NULL");
+    a.out_xyz = out->xyz; a.out_normal = out->normal; a.out_rgb = out->rgb;
+    a.out_pix = out->pixel_index; a.out_view = out->view_index; a.capacity = out->capacity;
+    return DD_OK;
+}
+
+template <typename DepthT, bool SP, bool HM, bool HN>
+void launch_lean3(const KArgs &a, hipStream_t s) {
     const dim3 grid(a.num_tiles), block(BLOCK);
-    if (p.contig) {
-        if (p.f16) hipLaunchKernelGGL((count_valid_kernel<_Float16, 8, 1, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((count_valid_kernel<float, 4, 2, true>), grid, block, 0, s, a);
+    if (a.out_rgb) hipLaunchKernelGGL((compact_lean<DepthT, HM, SP, HN, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((compact_lean<DepthT, HM, SP, HN, false>), grid, block, 0, s, a);
+}
+
+template <typename DepthT, bool SP>
+void launch_lean(const KArgs &a, hipStream_t s) {
+    const bool hm = a.flags & DD_VALID_MASK, hn = a.out_normal != nullptr;
+    if (hm && hn) launch_lean3<DepthT, SP, true, true>(a, s);
+    else if (hm) launch_lean3<DepthT, SP, true, false>(a, s);
+    else if (hn) launch_lean3<DepthT, SP, false, true>(a, s);
+    else launch_lean3<DepthT, SP, false, false>(a, s);
+}
+
+template <bool SP>
+void launch_scatter(const Plan &p, const KArgs &a, hipStream_t s) {
+    if (p.lean) {
+        if (p.f16) launch_lean<_Float16, SP>(a, s); else launch_lean<float, SP>(a, s);
+    } else {
+        const dim3 grid(a.num_tiles), block(BLOCK);
+        if (p.f16) hipLaunchKernelGGL((unproject_compact_kernel<_Float16, 1, 8, false, SP>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((unproject_compact_kernel<float, 1, 8, false, SP>), grid, block, 0, s, a);
+    }
+}
+
+void launch_count(const Plan &p, const KArgs &a, hipStream_t s) {
+    const dim3 grid(a.num_tiles), block(BLOCK);
+    const bool hm = a.flags & DD_VALID_MASK;
+    if (p.lean) {
+        if (p.f16) { if (hm) hipLaunchKernelGGL((count_lean<_Float16, true>), grid, block, 0, s, a);
+                     else hipLaunchKernelGGL((count_lean<_Float16, false>), grid, block, 0, s, a); }
+        else { if (hm) hipLaunchKernelGGL((count_lean<float, true>), grid, block, 0, s, a);
+               else hipLaunchKernelGGL((count_lean<float, false>), grid, block, 0, s, a); }
     } else {
         if (p.f16) hipLaunchKernelGGL((count_valid_kernel<_Float16, 1, 8, false>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((count_valid_kernel<float, 1, 8, false>), grid, block, 0, s, a);
     }
-    return hipGetLastError() == hipSuccess ? DD_OK : DD_ERR_LAUNCH;
 }
 
-int64_t ws_bytes(const KArgs &a) {
-    return (int64_t)sizeof(WsHeader) + (int64_t)a.num_tiles * 8;
+int check_launch(const char *what) {
+    if (hipGetLastError() == hipSuccess) return DD_OK;
+    snprintf(g_err, sizeof(g_err), "%s: kernel launch failed", what);
+    return DD_ERR_LAUNCH;
+}
+
+// pass 1: tile counts -> per-view tile offsets + view totals -> absolute view offsets
+int enqueue_plan(const Plan &p, const KArgs &a, hipStream_t s) {
+    if (hipMemsetAsync(a.hdr, 0, sizeof(WsHeader), s) != hipSuccess) return fail(DD_ERR_LAUNCH, "hipMemsetAsync(workspace) failed");
+    launch_count(p, a, s);
+    hipLaunchKernelGGL(scan_view_tiles, dim3(a.V), dim3(BLOCK), 0, s, a);
+    hipLaunchKernelGGL(scan_views, dim3(1), dim3(BLOCK), 0, s, a);
+    return check_launch("dd_plan");
 }
 
 }  // namespace
@@ -499,9 +961,8 @@ int dd_count_valid(const DDViewBatch *batch, int64_t *counts_dev, void *stream) 
     a.counts = reinterpret_cast<unsigned long long *>(counts_dev);
     if (hipMemsetAsync(counts_dev, 0, sizeof(int64_t) * (size_t)a.V, s) != hipSuccess)
         return fail(DD_ERR_LAUNCH, "hipMemsetAsync(counts) failed");
-    rc = launch_count(p, a, s);
-    if (rc != DD_OK) return fail(rc, "count_valid kernel launch failed");
-    return DD_OK;
+    launch_count(p, a, s);
+    return check_launch("dd_count_valid");
 }
 
 int64_t dd_workspace_bytes(const DDViewBatch *batch) {
@@ -511,33 +972,54 @@ int64_t dd_workspace_bytes(const DDViewBatch *batch) {
     return ws_bytes(a);
 }
 
+int dd_plan(const DDViewBatch *batch, const int64_t *cursor_dev, int64_t *view_offsets_dev,
+            void *workspace, int64_t workspace_bytes, void *stream) {
+    KArgs a; Plan p;
+    int rc = make_plan(batch, a, p);
+    if (rc != DD_OK) return rc;
+    if (!view_offsets_dev || !cursor_dev) return fail(DD_ERR_INVALID_ARG, "view_offsets_dev / cursor_dev is NULL");
+    if ((rc = bind_workspace(a, workspace, workspace_bytes)) != DD_OK) return rc;
+    a.view_offsets = reinterpret_cast<long long *>(view_offsets_dev);
+    a.cursor = reinterpret_cast<const long long *>(cursor_dev);
+    return enqueue_plan(p, a, (hipStream_t)stream);
+}
+
+int dd_scatter(const DDViewBatch *batch, const DDCloudOut *out, const int64_t *view_offsets_dev,
+               void *workspace, int64_t workspace_bytes, void *stream) {
+    KArgs a; Plan p;
+    int rc = make_plan(batch, a, p);
+    if (rc != DD_OK) return rc;
+    if ((rc = bind_output(a, batch, out)) != DD_OK) return rc;
+    if (!view_offsets_dev) return fail(DD_ERR_INVALID_ARG, "view_offsets_dev is NULL");
+    if ((rc = bind_workspace(a, workspace, workspace_bytes)) != DD_OK) return rc;
+    a.view_offsets = const_cast<long long *>(reinterpret_cast<const long long *>(view_offsets_dev));
+    launch_scatter<false>(p, a, (hipStream_t)stream);
+    return check_launch("dd_scatter");
+}
+
 int dd_unproject_compact(const DDViewBatch *batch, const DDCloudOut *out, int64_t *view_offsets_dev,
                          int64_t *cursor_dev, void *workspace, int64_t workspace_bytes, void *stream) {
     KArgs a; Plan p;
     int rc = make_plan(batch, a, p);
     if (rc != DD_OK) return rc;
-    if (!out || !out->xyz) return fail(DD_ERR_INVALID_ARG, "out / out->xyz is NULL");
-    if (out->capacity < 0) return fail(DD_ERR_INVALID_ARG, "capacity is negative");
-    if (out->normal && !batch->normal) return fail(DD_ERR_INVALID_ARG, "out->normal requested but batch->normal is NULL");
-    if (out->rgb && !batch->rgb) return fail(DD_ERR_INVALID_ARG, "out->rgb requested but batch->rgb is NULL");
+    if ((rc = bind_output(a, batch, out)) != DD_OK) return rc;
     if (!view_offsets_dev || !cursor_dev) return fail(DD_ERR_INVALID_ARG, "view_offsets_dev / cursor_dev is NULL");
-    if (!workspace || ((uintptr_t)workspace % 16) != 0) return fail(DD_ERR_WORKSPACE, "workspace is NULL or not 16-byte aligned");
-    const int64_t need = ws_bytes(a);
-    if (workspace_bytes < need) return fail(DD_ERR_WORKSPACE, "workspace too small (see dd_workspace_bytes)");
-
+    if ((rc = bind_workspace(a, workspace, workspace_bytes)) != DD_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    a.out_xyz = out->xyz; a.out_normal = out->normal; a.out_rgb = out->rgb;
-    a.out_pix = out->pixel_index; a.out_view = out->view_index; a.capacity = out->capacity;
     a.view_offsets = reinterpret_cast<long long *>(view_offsets_dev);
     a.cursor = reinterpret_cast<const long long *>(cursor_dev);
-    a.hdr = reinterpret_cast<WsHeader *>(workspace);
-    a.tile_state = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(workspace) + sizeof(WsHeader));
 
-    if (hipMemsetAsync(workspace, 0, (size_t)need, s) != hipSuccess)
-        return fail(DD_ERR_LAUNCH, "hipMemsetAsync(workspace) failed");
-    rc = launch_compact(p, a, s);
-    if (rc != DD_OK) return fail(rc, "unproject_compact kernel launch failed");
-    // cursor <- slot after the batch (kept out of the kernel: tiles read the old cursor)
+    if (p.single) {
+        // every look-back granule, the ticket and the error word start from zero on every call
+        if (hipMemsetAsync(workspace, 0, (size_t)(sizeof(WsHeader) + (size_t)a.num_tiles * 8), s) != hipSuccess)
+            return fail(DD_ERR_LAUNCH, "hipMemsetAsync(workspace) failed");
+        launch_scatter<true>(p, a, s);
+    } else {
+        if ((rc = enqueue_plan(p, a, s)) != DD_OK) return rc;
+        launch_scatter<false>(p, a, s);
+    }
+    if ((rc = check_launch("dd_unproject_compact")) != DD_OK) return rc;
+    // cursor <- row after the batch (kept out of the kernels: they read the old cursor)
     if (hipMemcpyAsync(cursor_dev, view_offsets_dev + a.V, sizeof(int64_t), hipMemcpyDeviceToDevice, s) != hipSuccess)
         return fail(DD_ERR_LAUNCH, "hipMemcpyAsync(cursor) failed");
     return DD_OK;

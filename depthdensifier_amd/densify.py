@@ -255,6 +255,37 @@ def count_valid(batch: ViewBatch) -> torch.Tensor:
     return counts
 
 
+@dataclass
+class BatchPlan:
+    """Result of pass 1 (``dd_plan``): absolute rows of every view and the per-tile rows kept in
+    ``workspace`` for ``dd_scatter``."""
+
+    view_offsets: torch.Tensor      # (V+1,) int64 device
+    workspace: torch.Tensor         # uint8 device scratch, consumed by dd_scatter
+
+    @property
+    def num_points(self) -> torch.Tensor:
+        return self.view_offsets[-1] - self.view_offsets[0]
+
+
+def plan_batch(batch: ViewBatch, cursor: Optional[torch.Tensor] = None,
+               reuse: Optional[BatchPlan] = None) -> BatchPlan:
+    """Pass 1: one streaming read of depth/mask/conf -> exact row of every view and tile.  The
+    replacement of ``valid_pixels`` bookkeeping (``scripts/test.py:210-212``) that lets the cloud
+    be allocated exactly before a single point is written."""
+    if cursor is None:
+        cursor = torch.zeros(1, dtype=torch.int64, device=batch.device)
+    cb = batch.c_struct()
+    nbytes = check(lib.dd_workspace_bytes(C.byref(cb)))
+    if reuse is not None and reuse.workspace.numel() >= nbytes and reuse.view_offsets.numel() == batch.num_views + 1:
+        ws, offsets = reuse.workspace, reuse.view_offsets        # steady-state: no allocation per step
+    else:
+        ws = torch.empty(max(nbytes, 1024), dtype=torch.uint8, device=batch.device)
+        offsets = torch.empty(batch.num_views + 1, dtype=torch.int64, device=batch.device)
+    check(lib.dd_plan(C.byref(cb), cursor.data_ptr(), offsets.data_ptr(), ws.data_ptr(), ws.numel(), _stream(batch.device)))
+    return BatchPlan(offsets, ws)
+
+
 # --------------------------------------------------------------------------------------
 # the cloud under construction
 # --------------------------------------------------------------------------------------
@@ -304,15 +335,31 @@ class CloudBuilder:
         cb = batch.c_struct()
         nbytes = check(lib.dd_workspace_bytes(C.byref(cb)))
         ws = self._workspace(nbytes)
-        ptr = lambda t: None if t is None else t.data_ptr()
-        out = DDCloudOut(xyz=ptr(self.xyz), normal=ptr(self.normal), rgb=ptr(self.rgb),
-                         pixel_index=ptr(self.pix), view_index=ptr(self.view), capacity=self.capacity)
+        out = self._out_struct()
         offsets = torch.empty(batch.num_views + 1, dtype=torch.int64, device=self.device)
         check(lib.dd_unproject_compact(C.byref(cb), C.byref(out), offsets.data_ptr(), self.cursor.data_ptr(),
                                        ws.data_ptr(), ws.numel(), _stream(self.device)))
         self._offsets.append(offsets)
         self._workspaces.append(ws)
         return offsets
+
+    def _out_struct(self) -> DDCloudOut:
+        ptr = lambda t: None if t is None else t.data_ptr()
+        return DDCloudOut(xyz=ptr(self.xyz), normal=ptr(self.normal), rgb=ptr(self.rgb),
+                          pixel_index=ptr(self.pix), view_index=ptr(self.view), capacity=self.capacity)
+
+    def scatter(self, batch: ViewBatch, plan: "BatchPlan") -> torch.Tensor:
+        """Pass 2 only (``dd_scatter``) for a batch planned with :func:`plan_batch` against this
+        cloud's cursor; advances the cursor.  Used by ``unproject_views`` (exact allocation) and
+        by ``bench.py`` to time the dominant kernel on its own."""
+        cb = batch.c_struct()
+        out = self._out_struct()
+        check(lib.dd_scatter(C.byref(cb), C.byref(out), plan.view_offsets.data_ptr(), plan.workspace.data_ptr(),
+                             plan.workspace.numel(), _stream(self.device)))
+        self.cursor.copy_(plan.view_offsets[-1:], non_blocking=True)
+        self._offsets.append(plan.view_offsets)
+        self._workspaces.append(plan.workspace)
+        return plan.view_offsets
 
     def finish(self, name: str = "Dense Cloud") -> FusedCloud:
         """Synchronise once, check the scan status words and the capacity, return exact-size views."""
@@ -346,22 +393,29 @@ def unproject_views(depth: ArrayLike, intrinsics: ArrayLike, cam_from_world: Arr
     """Densify + fuse a stack of views: ``scripts/test.py:203-244`` per view and ``:262-266``.
 
     ``downsample_density`` is ``ProcessingConfig.downsample_density`` (``scripts/test.py:37``; the
-    reference default is 32, the benchmarks use 1).  ``capacity``: ``None`` counts first
-    (``dd_count_valid``) and allocates exactly; ``"max"`` allocates for every visited pixel and
-    skips the count pass; an int is taken as given.
+    reference default is 32, the benchmarks use 1).  ``capacity``: ``None`` runs pass 1
+    (``dd_plan``), reads the exact count, allocates exactly and runs pass 2 (``dd_scatter``);
+    ``"max"`` allocates for every visited pixel and enqueues both passes without a host round
+    trip; an int is taken as given.
     """
     batch = ViewBatch(depth, intrinsics, cam_from_world, mask=mask, conf=conf, conf_threshold=conf_threshold,
                       normal=normal, rgb=rgb, stride=downsample_density, semantics=semantics,
                       rotate_normals=rotate_normals, device=device, tuning=tuning)
+    with_normals = batch.normal is not None and (semantics == "script" or batch.mask is not None)
+    fields = dict(normals=with_normals, colors=batch.rgb is not None, pixel_index=pixel_index,
+                  view_index=view_index, device=batch.device)
+    if capacity is None and not (tuning & 8):
+        plan = plan_batch(batch)
+        builder = CloudBuilder(int(plan.num_points.item()), **fields)
+        builder.scatter(batch, plan)
+        return builder.finish()
     if capacity is None:
         cap = int(count_valid(batch).sum().item())
     elif capacity == "max":
         cap = batch.max_points
     else:
         cap = int(capacity)
-    with_normals = batch.normal is not None and (semantics == "script" or batch.mask is not None)
-    builder = CloudBuilder(cap, normals=with_normals, colors=batch.rgb is not None,
-                           pixel_index=pixel_index, view_index=view_index, device=batch.device)
+    builder = CloudBuilder(cap, **fields)
     builder.append(batch)
     return builder.finish()
 

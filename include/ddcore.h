@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 1
+#define DD_ABI_VERSION 2
 
 enum {
     DD_OK = 0,
@@ -80,7 +80,7 @@ typedef struct DDViewBatch {
     float conf_threshold;
     uint32_t flags;
     int32_t view_index_base;  /* added to the per-point view index (global view id of view 0) */
-    uint32_t tuning;          /* 0 = default kernel configuration */
+    uint32_t tuning;          /* 0 = default; 1 = force the scalar kernels; 8 = single-pass look-back variant */
 } DDViewBatch;
 
 /*
@@ -105,23 +105,43 @@ const char *dd_last_error(void);
  * counts_dev: (V) int64, overwritten. */
 int dd_count_valid(const DDViewBatch *batch, int64_t *counts_dev, void *stream);
 
-/* Bytes of scratch dd_unproject_compact needs for this batch (>= 0), or a negative error. */
+/* Bytes of device scratch the calls below need for this batch (>= 0), or a negative error. */
 int64_t dd_workspace_bytes(const DDViewBatch *batch);
 
 /*
- * The hot path in one pass: cull, unproject, transform, compact in stable
- * (view-major, then row-major) order and append to the cloud.
+ * Pass 1 of the hot path: count the valid visited pixels of every tile (one streaming read of
+ * depth / mask / conf) and scan the counts, so that every view -- and, in the workspace, every
+ * tile -- knows the row of its first point.  Lets the caller size the cloud exactly
+ * (view_offsets_dev[V] - *cursor_dev points) before anything is written.
  *
- *  cursor_dev       (1) int64, device, in/out: number of points already in the
- *                   cloud; this batch's points go to slots [cursor, cursor+N)
- *                   and cursor is advanced by N.  Chaining calls on one stream
- *                   fuses any number of batches without a host round trip
- *                   (scripts/test.py:238-240 list append + :264-266 concatenate).
- *  view_offsets_dev (V+1) int64, device, out: slot of the first point of each
- *                   view; [V] = cursor after the batch.
- *  workspace        dd_workspace_bytes() bytes of device scratch, 16-B aligned.
- *                   After the stream has drained, ((int32_t*)workspace)[1] != 0
- *                   means the in-kernel scan gave up (should never happen).
+ *  cursor_dev       (1) int64, device, read: number of points already in the cloud.
+ *  view_offsets_dev (V+1) int64, device, out: row of the first point of each view;
+ *                   [V] = row after the batch.
+ *  workspace        dd_workspace_bytes() bytes, 16-B aligned; must be handed unchanged to
+ *                   dd_scatter for the same batch.
+ */
+int dd_plan(const DDViewBatch *batch, const int64_t *cursor_dev, int64_t *view_offsets_dev,
+            void *workspace, int64_t workspace_bytes, void *stream);
+
+/*
+ * Pass 2: cull, unproject (scripts/test.py:79-90), camera-to-world (:233), gather colour/normal
+ * (:215-220) and write every surviving pixel at its final row -- stable order: views in batch
+ * order, row-major inside a view (:205-212), i.e. exactly the order of the reference's
+ * np.concatenate (:264-266).  No workgroup depends on another one.
+ */
+int dd_scatter(const DDViewBatch *batch, const DDCloudOut *out, const int64_t *view_offsets_dev,
+               void *workspace, int64_t workspace_bytes, void *stream);
+
+/*
+ * The whole hot path for one batch, appended to the cloud: dd_plan + dd_scatter + cursor update,
+ * all enqueued on `stream` without a host round trip, so chaining calls fuses any number of
+ * batches (scripts/test.py:238-240 list append + :264-266 concatenate).
+ *
+ *  cursor_dev       (1) int64, device, in/out: advanced by the batch's number of points.
+ *  view_offsets_dev (V+1) int64, device, out.
+ *  workspace        as above.  With tuning bit 8 (single-pass look-back variant)
+ *                   ((int32_t*)workspace)[1] != 0 after the stream has drained means the
+ *                   in-kernel scan gave up (should never happen).
  */
 int dd_unproject_compact(const DDViewBatch *batch, const DDCloudOut *out,
                          int64_t *view_offsets_dev, int64_t *cursor_dev,

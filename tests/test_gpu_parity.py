@@ -75,8 +75,13 @@ def _inputs(g, c):
 
 # ------------------------------------------------------------------ reference goldens
 
+# tuning words: 0 = default (lean two-pass kernels on aligned maps), 1 = generic scalar kernels,
+# 8 = single-pass look-back variant of the lean kernel, 9 = single-pass generic kernel
+TUNINGS = (0, 1, 8, 9)
+
+
 @pytest.mark.parametrize("c", ("a", "b", "c"))
-@pytest.mark.parametrize("tuning", (0, 1))
+@pytest.mark.parametrize("tuning", TUNINGS)
 def test_golden_script(dd, golden_small, c, tuning):
     """HIP vs arrays returned by the reference's own _depth_to_pointcloud (see make_goldens.py)."""
     i = _inputs(golden_small, c)
@@ -153,15 +158,17 @@ def _rand_case(seed, V, H, W, dtype=np.float32, rho=0.8, specials=True):
     return d
 
 
-@pytest.mark.parametrize("shape", [(1, 1, 1), (2, 3, 5), (3, 67, 129), (2, 128, 256), (1, 255, 257), (5, 64, 64)])
+@pytest.mark.parametrize("shape", [(1, 1, 1), (2, 3, 5), (3, 67, 129), (2, 128, 256), (1, 255, 257), (5, 64, 64), (2, 96, 172)])
 @pytest.mark.parametrize("dtype", (np.float32, np.float16))
 @pytest.mark.parametrize("stride", (1, 2, 7))
-def test_oracle_sweep_script(dd, orc, shape, dtype, stride):
-    """Ragged sizes (scalar path), vector path (H*W % 8 == 0), both depth dtypes, strides."""
+@pytest.mark.parametrize("tuning", (0, 8))
+def test_oracle_sweep_script(dd, orc, shape, dtype, stride, tuning):
+    """Ragged sizes (scalar path), vector path (H*W % 8 == 0), both depth dtypes, strides,
+    two-pass and single-pass variants."""
     V, H, W = shape
     d = _rand_case(1000 + H * W + stride, V, H, W, dtype)
     cloud = dd.unproject_views(d["depth"], d["params"], d["cam_from_world"], mask=d["mask"], normal=d["normal"],
-                               rgb=d["rgb"], downsample_density=stride, view_index=True)
+                               rgb=d["rgb"], downsample_density=stride, view_index=True, tuning=tuning)
     ref = orc.densify_scene_script(d["depth"], d["params"], d["cam_from_world"], mask=d["mask"], normal=d["normal"],
                                    rgb=d["rgb"], stride=stride)
     assert_cloud(cloud, ref, scene_radius(d["cam_from_world"], d["depth"]))
@@ -257,6 +264,40 @@ def test_error_codes(dd):
         dd.ViewBatch(np.ones((1, 4, 4), np.float32), np.ones((1, 5)), np.eye(4)[None, :3])
 
 
+@pytest.mark.parametrize("fields", [(), ("normal",), ("rgb",), ("normal", "rgb")])
+@pytest.mark.parametrize("use_mask", (True, False))
+@pytest.mark.parametrize("tuning", (0, 8))
+def test_field_subsets(dd, orc, fields, use_mask, tuning):
+    """Every template instantiation of the lean kernel: {mask} x {normal} x {rgb} x {two-pass, single-pass}.
+    320x240 views span several 4096-pixel tiles with ragged last tiles; the valid-pixel run ends
+    mid-quad so the byte-store tail of the colour path is exercised."""
+    d = _rand_case(31 + len(fields), 3, 240, 324)
+    kw = {k: d[k] for k in fields}
+    mask = d["mask"] if use_mask else None
+    cloud = dd.unproject_views(d["depth"], d["params"], d["cam_from_world"], mask=mask, view_index=True, tuning=tuning, **kw)
+    ref = orc.densify_scene_script(d["depth"], d["params"], d["cam_from_world"], mask=mask, **kw)
+    assert_cloud(cloud, ref, scene_radius(d["cam_from_world"], d["depth"]))
+
+
+def test_plan_then_scatter_api(dd, orc):
+    """dd_plan gives the exact rows before anything is written; dd_scatter fills them."""
+    import torch
+    d = _rand_case(41, 4, 120, 160)
+    batch = dd.ViewBatch(d["depth"], d["params"], d["cam_from_world"], mask=d["mask"], rgb=d["rgb"])
+    ref = orc.densify_scene_script(d["depth"], d["params"], d["cam_from_world"], mask=d["mask"], rgb=d["rgb"])
+    cursor = torch.full((1,), 1000, dtype=torch.int64, device="cuda")      # cloud already holds 1000 points
+    plan = dd.plan_batch(batch, cursor)
+    assert np.array_equal(plan.view_offsets.cpu().numpy(), ref.view_offsets + 1000)
+    assert int(plan.num_points) == len(ref.points)
+    builder = dd.CloudBuilder(1000 + len(ref.points), colors=True)
+    builder.cursor.fill_(1000)
+    builder.scatter(batch, plan)
+    cloud = builder.finish()
+    assert len(cloud) == 1000 + len(ref.points)
+    assert np.array_equal(cloud.colors[1000:].cpu().numpy(), ref.colors)
+    assert np.array_equal(cloud.pixel_index[1000:].cpu().numpy().astype(np.int64), ref.pixel_index)
+
+
 # ------------------------------------------------------------------ full BASELINE sizes
 
 def _device_stack(V, H, W, seed, depth_dtype="float32"):
@@ -310,10 +351,13 @@ def test_full_size_1080p_properties_and_oracle_sample(dd, orc):
     assert np.abs(w_ - pix[offs[v]:offs[v + 1]] // W).max() < 2e-2
     dsel = depth[v].reshape(-1).cpu().numpy()[pix[offs[v]:offs[v + 1]]]
     assert np.abs(cam[:, 2] - dsel).max() < 1e-4 * 12
-    # idempotence: a second run is bit-identical
-    again = dd.unproject_views(depth, params, E, mask=mask, normal=normal, rgb=rgb, view_index=True, capacity="max")
-    assert torch.equal(again.points, cloud.points) and torch.equal(again.colors, cloud.colors)
-    assert torch.equal(again.normals, cloud.normals) and torch.equal(again.view_offsets, cloud.view_offsets)
+    # idempotence: a second run is bit-identical; so are the single-pass and the scalar kernels
+    for tuning in (0, 8, 1):
+        again = dd.unproject_views(depth, params, E, mask=mask, normal=normal, rgb=rgb, view_index=True,
+                                   capacity="max", tuning=tuning)
+        assert torch.equal(again.points, cloud.points) and torch.equal(again.colors, cloud.colors)
+        assert torch.equal(again.normals, cloud.normals) and torch.equal(again.view_offsets, cloud.view_offsets)
+        assert torch.equal(again.pixel_index, cloud.pixel_index) and torch.equal(again.view_index, cloud.view_index)
     # oracle on views 0 and 5 (about 1.5 s of NumPy each)
     dn, mn, nn, cn = (t.cpu().numpy() for t in (depth, mask, normal, rgb))
     rad = scene_radius(E, dn)
