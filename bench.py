@@ -169,8 +169,14 @@ def main() -> None:
     device = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
-    if world > 1:
+    # DD_BENCH_FORCE_DIST=1 runs the N>1 code path (RCCL group, count exchange, all-gatherv) with a
+    # single rank, so it can be rehearsed on a 1-GPU box.
+    use_dist = world > 1 or os.environ.get("DD_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)     # "nccl" is RCCL on ROCm
 
     import depthdensifier_amd as dd
@@ -225,14 +231,14 @@ def main() -> None:
                 e[2].record()
         if record:
             ev.append(e)
-        if world > 1:                              # the fuse exchange: global view offsets on every rank
+        if use_dist:                               # the fuse exchange: global view offsets on every rank
             counts = offs[1:] - offs[:-1]
             return D.offsets_from_counts(D.exchange_counts(counts, total_views))
         return offs
 
     def fence():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -244,7 +250,7 @@ def main() -> None:
         goffs = step(True)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -259,7 +265,7 @@ def main() -> None:
 
     # replicated fuse (the north-star all-gatherv of the per-GPU clouds), timed separately
     gathered = None
-    if world > 1 and args.gather_steps > 0:
+    if use_dist and args.gather_steps > 0:
         sharded = D.fuse_sharded(cloud, total_views)
         rows = n_total
         bufs = {"points": torch.empty((rows, 3), dtype=torch.float32, device=device)}
@@ -290,7 +296,9 @@ def main() -> None:
         traffic = None
         tfile = ROOT / "profiles" / "traffic.json"
         if tfile.exists():
-            traffic = json.loads(tfile.read_text()).get(args.workload, {}).get("hbm_bytes_per_launch")
+            rec = json.loads(tfile.read_text()).get(args.workload)
+            if rec:     # PMC bytes were collected on the full workload; a launch over fewer views moves proportionally fewer
+                traffic = int(rec["hbm_bytes_per_launch"] * V / rec["views"])
         line = {
             "metric": "Mpixels/s unprojected+fused",
             "value": round(pixels / (elapsed / args.steps) / 1e6, 1),
@@ -324,7 +332,7 @@ def main() -> None:
             line["cpu_baseline"] = cpu_baseline(cfg, scene, params, E, args.cpu_seconds)
         print(json.dumps(line), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

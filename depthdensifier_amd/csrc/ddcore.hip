@@ -396,7 +396,22 @@ __global__ __launch_bounds__(BLOCK) void unproject_compact_kernel(const KArgs a)
 //    otherwise (two-pass) from the offsets produced by count_lean + the two scan kernels, and
 //    the workgroup has no dependency on any other workgroup.
 // ==================================================================================================
-constexpr int L_PXT = 16;                    // pixels per lane per tile
+#ifndef DD_L_PXT
+#define DD_L_PXT 16
+#endif
+#ifndef DD_NT_STORE
+#define DD_NT_STORE 0
+#endif
+#ifndef DD_NT_LOAD
+#define DD_NT_LOAD 1
+#endif
+#ifndef DD_XCD_SWIZZLE
+#define DD_XCD_SWIZZLE 0
+#endif
+#ifndef DD_LEAN_WGS
+#define DD_LEAN_WGS 6
+#endif
+constexpr int L_PXT = DD_L_PXT;              // pixels per lane per tile
 constexpr int L_WSPAN = 64 * L_PXT;          // 1024 pixels per wave
 constexpr int L_TILE = WAVES * L_WSPAN;      // 4096
 
@@ -433,11 +448,23 @@ __device__ __forceinline__ void lean_load_test(const KArgs &a, long long vbase, 
         inside[ch] = qb < a.P;
         if (!inside[ch]) qb = a.P - VEC;
         const long long e = vbase + qb;
+#if DD_NT_LOAD
+        {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 w = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(reinterpret_cast<const DepthT *>(a.depth) + e));
+            d[ch].x = w.x; d[ch].y = w.y; d[ch].z = w.z; d[ch].w = w.w;
+        }
+        if constexpr (HAS_MASK) {
+#pragma unroll
+            for (int i = 0; i < VEC / 4; ++i) mk[ch][i] = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(a.mask + e + 4 * i));
+        }
+#else
         d[ch] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const DepthT *>(a.depth) + e);
         if constexpr (HAS_MASK) {
 #pragma unroll
             for (int i = 0; i < VEC / 4; ++i) mk[ch][i] = *reinterpret_cast<const unsigned *>(a.mask + e + 4 * i);
         }
+#endif
     }
     const bool use_depth = a.flags & DD_VALID_DEPTH_POSITIVE;
     const bool use_conf = a.flags & DD_VALID_CONF;
@@ -508,7 +535,7 @@ __device__ __forceinline__ long long lookback13(unsigned long long *state, unsig
 }
 
 template <typename DepthT, bool HAS_MASK, bool SINGLE_PASS, bool HAS_NORMAL, bool HAS_RGB>
-__global__ __launch_bounds__(BLOCK, 6) void compact_lean(const KArgs a) {
+__global__ __launch_bounds__(BLOCK, DD_LEAN_WGS) void compact_lean(const KArgs a) {
     constexpr int VEC = 16 / (int)sizeof(DepthT), CH = L_PXT / VEC, CSPAN = 64 * VEC;
     __shared__ float s_d[L_TILE];              // 16 KiB
     __shared__ unsigned short s_q[L_TILE];     //  8 KiB
@@ -527,7 +554,14 @@ __global__ __launch_bounds__(BLOCK, 6) void compact_lean(const KArgs a) {
         t = __builtin_amdgcn_readfirstlane(s_ticket);
         if (t >= a.num_tiles) return;
     } else {
+#if DD_XCD_SWIZZLE
+        {   // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous range of tiles
+            const unsigned nt = a.num_tiles, b = blockIdx.x, x = b & 7u, q = nt >> 3, r = nt & 7u;
+            t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+        }
+#else
         t = blockIdx.x;
+#endif
     }
     const unsigned v = t / a.tiles_per_view;
     const unsigned tv = t - v * a.tiles_per_view;
@@ -632,7 +666,11 @@ __global__ __launch_bounds__(BLOCK, 6) void compact_lean(const KArgs a) {
         const bool act = (j < (int)n) && (slot < a.capacity);
         if (act) {
             f32x3 o; o.x = p.x; o.y = p.y; o.z = p.z;
+#if DD_NT_STORE
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x3 *>(a.out_xyz + slot * 3));
+#else
             *reinterpret_cast<f32x3 *>(a.out_xyz + slot * 3) = o;
+#endif
             if (a.out_pix) a.out_pix[slot] = (int)p.q;
             if (a.out_view) a.out_view[slot] = a.view_base + (int)v;
         }
@@ -645,7 +683,11 @@ __global__ __launch_bounds__(BLOCK, 6) void compact_lean(const KArgs a) {
                 const float inv = 1.0f / (sqrtf(w0 * w0 + w1 * w1 + w2 * w2) + 1e-8f);
                 nv.x = w0 * inv; nv.y = w1 * inv; nv.z = w2 * inv;
             }
+#if DD_NT_STORE
+            if (act) __builtin_nontemporal_store(nv, reinterpret_cast<f32x3 *>(a.out_normal + slot * 3));
+#else
             if (act) *reinterpret_cast<f32x3 *>(a.out_normal + slot * 3) = nv;
+#endif
         }
         if constexpr (HAS_RGB) {
             // rows of 4 consecutive lanes -> 12 contiguous bytes, stored by the quad's first lane

@@ -1,0 +1,57 @@
+// Micro-benchmark of the memory access shapes used by the scatter kernel (GPU box only):
+//   hipcc --offload-arch=gfx950 -O3 -o ubench tools/ubench.hip && ./ubench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef float f3 __attribute__((ext_vector_type(3)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned u3 __attribute__((ext_vector_type(3)));
+typedef u3 u3u __attribute__((aligned(1)));
+typedef unsigned u1u __attribute__((aligned(1)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+// each thread handles `per` elements strided by the grid (grid-stride keeps every instruction contiguous)
+__global__ void w_x4(f4 *o, size_t n) { for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { f4 v = {1.f, 2.f, 3.f, (float)i}; o[i] = v; } }
+__global__ void w_x3(float *o, size_t n) { for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { f3 v = {1.f, 2.f, (float)i}; *reinterpret_cast<f3 *>(o + i * 3) = v; } }
+__global__ void w_x1(float *o, size_t n) { for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) o[i] = (float)i; }
+__global__ void w_rgb(unsigned char *o, size_t n) {   // n points, 3 B each, stored as 12 B by every 4th lane (unaligned)
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    if ((threadIdx.x & 3) == 0) { u3 v = {(unsigned)i, 2u, 3u}; *reinterpret_cast<u3u *>(o + i * 3 + 1) = v; } } }
+__global__ void w_rgb_bytes(unsigned char *o, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { o[i*3] = 1; o[i*3+1] = 2; o[i*3+2] = (unsigned char)i; } }
+__global__ void r_x4(const f4 *in, float *o, size_t n) { float s = 0; for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { f4 v = in[i]; s += v.x + v.y + v.z + v.w; } if (s == 123.f) o[0] = s; }
+__global__ void r_x3(const float *in, float *o, size_t n) { float s = 0; for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { f3 v = *reinterpret_cast<const f3 *>(in + i * 3); s += v.x + v.y + v.z; } if (s == 123.f) o[0] = s; }
+__global__ void r_rgb(const unsigned char *in, float *o, size_t n) { unsigned s = 0; for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { s += *reinterpret_cast<const u1u *>(in + i * 3 + 2); } if (s == 123u) o[0] = s; }
+__global__ void c_x4(const f4 *in, f4 *o, size_t n) { for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) o[i] = in[i]; }
+__global__ void c_x3(const float *in, float *o, size_t n) { for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) *reinterpret_cast<f3 *>(o + i * 3) = *reinterpret_cast<const f3 *>(in + i * 3); }
+// unrolled x4 copy, 4 loads in flight per thread
+__global__ void c_x4u(const f4 *in, f4 *o, size_t n) { const size_t st = (size_t)gridDim.x * blockDim.x; for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i + 3 * st < n; i += 4 * st) { f4 a = in[i], b = in[i + st], c = in[i + 2 * st], d = in[i + 3 * st]; o[i] = a; o[i + st] = b; o[i + 2 * st] = c; o[i + 3 * st] = d; } }
+
+template <typename F> double run(const char *name, double bytes, F f) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 2; ++i) f();
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0)); const int it = 8; for (int i = 0; i < it; ++i) f(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  double gbps = bytes * it / (ms * 1e-3) / 1e9; printf("%-34s %8.1f GB/s  (%.3f ms)\n", name, gbps, ms / it); return gbps; }
+
+int main(int argc, char **argv) {
+  const size_t BYTES = (size_t)3 << 30;   // 3 GiB per buffer
+  void *a, *b; CK(hipMalloc(&a, BYTES + 256)); CK(hipMalloc(&b, BYTES + 256)); CK(hipMemset(a, 1, BYTES)); CK(hipMemset(b, 2, BYTES));
+  for (int wg : {2048, 8192}) {
+    printf("-- grid %d x 256\n", wg);
+    dim3 g(wg), blk(256);
+    run("write dwordx4 contiguous", BYTES, [&] { w_x4<<<g, blk>>>((f4 *)b, BYTES / 16); });
+    run("write dwordx3 (12 B stride)", BYTES, [&] { w_x3<<<g, blk>>>((float *)b, BYTES / 12); });
+    run("write dword contiguous", BYTES, [&] { w_x1<<<g, blk>>>((float *)b, BYTES / 4); });
+    run("write rgb 12B/4 lanes unaligned", BYTES / 4, [&] { w_rgb<<<g, blk>>>((unsigned char *)b, BYTES / 12); });
+    run("write rgb 3 byte stores", BYTES / 4, [&] { w_rgb_bytes<<<g, blk>>>((unsigned char *)b, BYTES / 12); });
+    run("read  dwordx4 contiguous", BYTES, [&] { r_x4<<<g, blk>>>((const f4 *)a, (float *)b, BYTES / 16); });
+    run("read  dwordx3 (12 B stride)", BYTES, [&] { r_x3<<<g, blk>>>((const float *)a, (float *)b, BYTES / 12); });
+    run("read  rgb unaligned dword/3B", BYTES / 4, [&] { r_rgb<<<g, blk>>>((const unsigned char *)a, (float *)b, BYTES / 12); });
+    run("copy  dwordx4", 2.0 * BYTES, [&] { c_x4<<<g, blk>>>((const f4 *)a, (f4 *)b, BYTES / 16); });
+    run("copy  dwordx4 unrolled x4", 2.0 * BYTES, [&] { c_x4u<<<g, blk>>>((const f4 *)a, (f4 *)b, BYTES / 16); });
+    run("copy  dwordx3", 2.0 * BYTES, [&] { c_x3<<<g, blk>>>((const float *)a, (float *)b, BYTES / 12); });
+  }
+  return 0;
+}
