@@ -38,8 +38,12 @@ WORKLOADS = {
                       note="BASELINE configs[1] stand-in: 185 views ~1080p, blob mask"),
     "scene2000": dict(V=2000, H=1080, W=1920, depth="float32", mask=True, normal=True, rgb=True, rho=0.8,
                       note="BASELINE configs[2]: 2000-view synthetic scene (strong scaling: V is the total)"),
-    "roofline12mp": dict(V=100, H=3024, W=4032, depth="float16", mask=False, normal=False, rgb=False, rho=1.0,
-                         note="BASELINE configs[4] shape: 12 MP f16 depth in / f32 xyz out, dense"),
+    "mip360conf": dict(V=232, H=1080, W=1920, depth="float32", mask=True, normal=True, rgb=True, rho=0.85, conf=0.5,
+                       scenes=[194, 292, 240, 185, 279, 311, 125],
+                       note="BASELINE configs[3]: the 7 Mip-NeRF 360 scene sizes back to back (1626 views, synthetic "
+                            "stand-ins), mask AND conf > 0.5; V is the per-GPU share at 7..8 GPUs, use --views to change"),
+    "roofline12mp": dict(V=500, H=3024, W=4032, depth="float16", mask=False, normal=False, rgb=False, rho=1.0,
+                         note="BASELINE configs[4]: 500 views 12 MP, f16 depth in / f32 xyz out, dense"),
 }
 
 
@@ -71,6 +75,7 @@ def make_scene(cfg: dict, view_ids: np.ndarray, device) -> dict:
     mask = torch.empty((V, H, W), dtype=torch.bool, device=device) if cfg["mask"] else None
     normal = torch.empty((V, H, W, 3), dtype=torch.float32, device=device) if cfg["normal"] else None
     rgb = torch.empty((V, H, W, 3), dtype=torch.uint8, device=device) if cfg["rgb"] else None
+    conf = torch.empty((V, H, W), dtype=torch.float32, device=device) if cfg.get("conf") else None
     ys = torch.linspace(0, 1, H, device=device)[:, None]
     xs = torch.linspace(0, 1, W, device=device)[None, :]
     for i, vid in enumerate(view_ids):
@@ -90,7 +95,9 @@ def make_scene(cfg: dict, view_ids: np.ndarray, device) -> dict:
             normal[i] = torch.nn.functional.normalize(n, dim=-1)
         if rgb is not None:
             rgb[i] = torch.randint(0, 256, (H, W, 3), generator=g, device=device, dtype=torch.uint8)
-    return dict(depth=depth, mask=mask, normal=normal, rgb=rgb)
+        if conf is not None:
+            conf[i].uniform_(0.0, 1.0, generator=g)
+    return dict(depth=depth, mask=mask, normal=normal, rgb=rgb, conf=conf)
 
 
 # ------------------------------------------------------------------------------ byte model
@@ -101,7 +108,7 @@ def algorithmic_bytes(cfg: dict, V: int, n_valid: int, pixel_index: bool) -> int
     charged only for surviving pixels; nothing is credited for re-reads."""
     P = cfg["H"] * cfg["W"]
     b_depth = 2 if cfg["depth"] == "float16" else 4
-    per_px = b_depth + (1 if cfg["mask"] else 0)
+    per_px = b_depth + (1 if cfg["mask"] else 0) + (4 if cfg.get("conf") else 0)
     per_pt_r = (12 if cfg["normal"] else 0) + (3 if cfg["rgb"] else 0)
     per_pt_w = 12 + (12 if cfg["normal"] else 0) + (3 if cfg["rgb"] else 0) + (4 if pixel_index else 0)
     return V * P * per_px + n_valid * (per_pt_r + per_pt_w) + V * (64 + 8)
@@ -127,7 +134,9 @@ def cpu_baseline(cfg: dict, scene: dict, params: np.ndarray, E: np.ndarray, budg
         n = None if scene["normal"] is None else scene["normal"][i].cpu().numpy()
         c = None if scene["rgb"] is None else scene["rgb"][i].cpu().numpy()
         t0 = time.perf_counter()
-        out = orc.fuse_views([orc.densify_view_script(d, params[i], E[i], mask=m, normal=n, rgb=c)])
+        cf = None if scene.get("conf") is None else scene["conf"][i].cpu().numpy()
+        out = orc.fuse_views([orc.densify_view_script(d, params[i], E[i], mask=m, normal=n, rgb=c, conf=cf,
+                                                      conf_threshold=cfg.get("conf"))])
         t_total += time.perf_counter() - t0
         pts += len(out.points)
         n_views += 1
@@ -202,6 +211,7 @@ def main() -> None:
     params = np.tile([0.8 * W, 0.8 * W, W / 2.0, H / 2.0], (V, 1))
     E = ring_poses(view_ids, total_views)
     batch = dd.ViewBatch(scene["depth"], params, E, mask=scene["mask"], normal=scene["normal"], rgb=scene["rgb"],
+                         conf=scene["conf"], conf_threshold=cfg.get("conf"),
                          view_index_base=int(lo), device=device, tuning=args.tuning)
     n_local = int(dd.count_valid(batch).sum().item())
     builder = dd.CloudBuilder(n_local, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index,
@@ -312,7 +322,7 @@ def main() -> None:
             "mpoints_per_s": round(n_total / (elapsed / args.steps) / 1e6, 1),
             "config": {"workload": args.workload, "note": cfg["note"], "views_total": total_views, "views_per_gpu": V,
                        "height": H, "width": W, "downsample_density": 1, "valid_fraction": round(n_local / (V * H * W), 4),
-                       "inputs": "+".join(k for k in ("depth", "mask", "normal", "rgb") if scene[k] is not None),
+                       "inputs": "+".join(k for k in ("depth", "mask", "conf", "normal", "rgb") if scene[k] is not None),
                        "outputs": "xyz f32" + (" + normal f32" if cfg["normal"] else "") + (" + rgb u8" if cfg["rgb"] else "")
                                   + (" + pixel_index i32" if args.pixel_index else ""),
                        "fuse": "single GPU: one global scan, points written at final slots" if world == 1 else

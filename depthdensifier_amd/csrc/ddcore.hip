@@ -466,8 +466,27 @@ __device__ __forceinline__ void lean_load_test(const KArgs &a, long long vbase, 
         }
 #endif
     }
-    const bool use_depth = a.flags & DD_VALID_DEPTH_POSITIVE;
+    // confidence map (BASELINE config 4): vector loads issued with the others, under a uniform branch
     const bool use_conf = a.flags & DD_VALID_CONF;
+    uint4 cfa[CH], cfb[CH];
+    if (use_conf) {
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) {
+            unsigned qb = qw + (unsigned)(ch * 64 + lane) * VEC;
+            if (!inside[ch]) qb = a.P - VEC;
+            const long long e = vbase + qb;
+            if (a.conf_f16) {
+                const unsigned short *c = reinterpret_cast<const unsigned short *>(a.conf) + e;
+                if constexpr (VEC == 8) cfa[ch] = *reinterpret_cast<const uint4 *>(c);
+                else { const uint2 w = *reinterpret_cast<const uint2 *>(c); cfa[ch].x = w.x; cfa[ch].y = w.y; }
+            } else {
+                const float *c = reinterpret_cast<const float *>(a.conf) + e;
+                cfa[ch] = *reinterpret_cast<const uint4 *>(c);
+                if constexpr (VEC == 8) cfb[ch] = *reinterpret_cast<const uint4 *>(c + 4);
+            }
+        }
+    }
+    const bool use_depth = a.flags & DD_VALID_DEPTH_POSITIVE;
 #pragma unroll
     for (int ch = 0; ch < CH; ++ch) {
         unsigned b = inside[ch] ? ((1u << VEC) - 1u) : 0u;
@@ -481,12 +500,12 @@ __device__ __forceinline__ void lean_load_test(const KArgs &a, long long vbase, 
             for (int k = 0; k < VEC; ++k)
                 if (!(raw_depth<DepthT>(d[ch], k) > 0.0f)) b &= ~(1u << k);
         }
-        if (use_conf && inside[ch]) {          // rare: confidence map (scalar loads, not on the benchmark path)
-            const long long e = vbase + qw + (unsigned)(ch * 64 + lane) * VEC;
+        if (use_conf) {
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                const float cf = a.conf_f16 ? (float)reinterpret_cast<const _Float16 *>(a.conf)[e + k]
-                                            : reinterpret_cast<const float *>(a.conf)[e + k];
+                float cf;
+                if (a.conf_f16) cf = raw_depth<_Float16>(cfa[ch], k);
+                else cf = raw_depth<float>(k < 4 ? cfa[ch] : cfb[ch], k & 3);
                 if (!(cf > a.conf_thr)) b &= ~(1u << k);
             }
         }
