@@ -23,7 +23,10 @@ from .densify import (  # noqa: F401
     unproject_views,
 )
 
+from .filtering import FilteringConfig, filter_cameras, filter_floaters, floater_votes  # noqa: F401,E402
+
 __all__ = [
+    "FilteringConfig", "filter_cameras", "filter_floaters", "floater_votes",
     "CloudBuilder", "FusedCloud", "ViewBatch", "camera_blocks", "count_valid", "fuse_batches",
     "intrinsics_matrix", "plan_batch", "BatchPlan", "unproject_views", "DDCoreError", "__version__",
 ]

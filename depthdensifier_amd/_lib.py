@@ -21,7 +21,7 @@ import torch  # noqa: F401  (load order, see above)
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("DDCORE_LIB", _HERE / "libddcore.so"))
 
-DD_ABI_VERSION = 2
+DD_ABI_VERSION = 3
 DD_OK = 0
 DD_F32, DD_F16 = 0, 1
 DD_VALID_DEPTH_POSITIVE = 0x1
@@ -38,6 +38,8 @@ EXPORTS = (
     "dd_plan",
     "dd_scatter",
     "dd_unproject_compact",
+    "dd_floater_votes",
+    "dd_filter_last_error",
 )
 
 
@@ -73,6 +75,21 @@ class DDCloudOut(C.Structure):
     ]
 
 
+class DDFilterViews(C.Structure):
+    _fields_ = [
+        ("num_views", C.c_int32),
+        ("height", C.c_int32),
+        ("width", C.c_int32),
+        ("reserved", C.c_int32),
+        ("depth", C.c_void_p),
+        ("mask", C.c_void_p),
+        ("cams", C.c_void_p),
+        ("grazing_cos", C.c_double),
+        ("depth_threshold", C.c_float),
+        ("reserved2", C.c_float),
+    ]
+
+
 class DDCoreError(RuntimeError):
     """A negative return code from libddcore.so."""
 
@@ -104,6 +121,10 @@ def _load() -> C.CDLL:
     lib.dd_unproject_compact.argtypes = [
         C.POINTER(DDViewBatch), C.POINTER(DDCloudOut), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
     ]
+    lib.dd_floater_votes.restype = C.c_int
+    lib.dd_floater_votes.argtypes = [C.POINTER(DDFilterViews), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.dd_filter_last_error.restype = C.c_char_p
+    lib.dd_filter_last_error.argtypes = []
     got = lib.dd_abi_version()
     if got != DD_ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI version {got}, binding expects {DD_ABI_VERSION}; rebuild the library")

@@ -1,0 +1,109 @@
+"""Multi-view floater filter on the GPU.
+
+Mirrors ``scripts/test.py:269-335`` of the reference: every fused point is projected into every
+cached view (``project_points``, ``:58-76``) and collects a vote when it lies clearly in front of
+that view's refined depth; points with ``votes >= vote_threshold`` are dropped.  The O(N*V) vote
+loop runs in ``libddcore.so`` (``dd_floater_votes``, float64 decisions like NumPy's); PyTorch owns
+the memory.  No CPU fallback.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from ._lib import DDFilterViews, DDCoreError, lib
+from .densify import ArrayLike, FusedCloud, _gpu, _require_gpu, _stream, intrinsics_matrix
+
+
+@dataclass
+class FilteringConfig:
+    """``FilteringConfig`` of ``scripts/test.py:40-46``."""
+
+    vote_threshold: int = 5
+    """Number of votes required to remove a 'floater' point."""
+    depth_threshold: float = 0.7
+    """Threshold to identify a floater (projected_depth < T * refined_depth)."""
+
+
+GRAZING_COS = 0.087   # scripts/test.py:295
+
+
+def filter_cameras(intrinsics: ArrayLike, cam_from_world: ArrayLike) -> np.ndarray:
+    """(V,24) float64 camera blocks of ``DDFilterViews.cams``: ``[R|t]`` row-major, the first two rows
+    of the calibration matrix, the projection centre ``-R^T t``."""
+    K = intrinsics_matrix(intrinsics)
+    E = np.asarray(cam_from_world.cpu() if isinstance(cam_from_world, torch.Tensor) else cam_from_world, dtype=np.float64)
+    if E.ndim == 2:
+        E = E[None]
+    E = E[:, :3, :]
+    if K.shape[0] == 1 and E.shape[0] > 1:
+        K = np.repeat(K, E.shape[0], axis=0)
+    if K.shape[0] != E.shape[0]:
+        raise ValueError(f"{K.shape[0]} intrinsics for {E.shape[0]} poses")
+    cams = np.zeros((E.shape[0], 24))
+    cams[:, 0:12] = E.reshape(-1, 12)
+    cams[:, 12:18] = K[:, :2, :].reshape(-1, 6)
+    cams[:, 18:21] = -np.einsum("vji,vj->vi", E[:, :, :3], E[:, :, 3])
+    return cams
+
+
+def floater_votes(points: torch.Tensor, normals: torch.Tensor, depth: ArrayLike, intrinsics: ArrayLike,
+                  cam_from_world: ArrayLike, mask: Optional[ArrayLike] = None, depth_threshold: float = 0.7,
+                  votes: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(N,) int32 votes of ``scripts/test.py:273-328``.  ``depth`` (V,H,W) float32 is the refined depth
+    of the cached views (``:197-201``); with ``mask`` given, masked-out pixels read as 0 (``:194``).
+    Pass ``votes`` to accumulate over several calls (views in chunks)."""
+    dev = _require_gpu(points.device if isinstance(points, torch.Tensor) and points.is_cuda else None)
+    pts = _gpu(points, dev, torch.float32)
+    nrm = _gpu(normals, dev, torch.float32)
+    if pts.dim() != 2 or pts.shape[1] != 3 or nrm.shape != pts.shape:
+        raise ValueError("points and normals must both be (N,3)")
+    d = _gpu(depth, dev, torch.float32)
+    if d.dim() == 2:
+        d = d[None]
+    m = _gpu(mask, dev)
+    if m is not None:
+        if m.dim() == 2:
+            m = m[None]
+        m = m.view(torch.uint8) if m.dtype == torch.bool else (m > 0).view(torch.uint8)
+        if m.shape != d.shape:
+            raise ValueError("mask and depth shapes differ")
+    cams = torch.from_numpy(filter_cameras(intrinsics, cam_from_world)).to(dev)
+    if cams.shape[0] != d.shape[0]:
+        raise ValueError(f"{cams.shape[0]} cameras for {d.shape[0]} depth maps")
+    accumulate = votes is not None
+    if votes is None:
+        votes = torch.empty(pts.shape[0], dtype=torch.int32, device=dev)
+    V, H, W = d.shape
+    fv = DDFilterViews(num_views=V, height=H, width=W, depth=d.data_ptr(), mask=None if m is None else m.data_ptr(),
+                       cams=cams.data_ptr(), grazing_cos=GRAZING_COS, depth_threshold=float(depth_threshold))
+    rc = lib.dd_floater_votes(C.byref(fv), pts.data_ptr(), nrm.data_ptr(), pts.shape[0], votes.data_ptr(),
+                              1 if accumulate else 0, _stream(dev))
+    if rc < 0:
+        raise DDCoreError(rc, lib.dd_filter_last_error().decode())
+    # asynchronous: temporaries freed here are only reused by later work on the same stream
+    return votes
+
+
+def filter_floaters(cloud: FusedCloud, depth: ArrayLike, intrinsics: ArrayLike, cam_from_world: ArrayLike,
+                    mask: Optional[ArrayLike] = None, config: Optional[FilteringConfig] = None):
+    """``scripts/test.py:269-335``: returns ``(filtered_cloud, votes)``.  The reference filters points and
+    colours (``:331-332``) and leaves ``final_normals`` untouched; here every per-point field is
+    filtered so the cloud stays consistent."""
+    cfg = config or FilteringConfig()
+    if cloud.normals is None:
+        raise ValueError("the floater filter needs per-point normals (scripts/test.py:291)")
+    votes = floater_votes(cloud.points, cloud.normals, depth, intrinsics, cam_from_world, mask, cfg.depth_threshold)
+    keep = votes < cfg.vote_threshold                                   # :330
+    csum = torch.zeros(len(cloud) + 1, dtype=torch.int64, device=keep.device)
+    torch.cumsum(keep, 0, out=csum[1:])
+    pick = lambda t: None if t is None else t[keep]
+    out = FusedCloud(points=cloud.points[keep], colors=pick(cloud.colors), normals=pick(cloud.normals),
+                     pixel_index=pick(cloud.pixel_index), view_index=pick(cloud.view_index),
+                     view_offsets=csum[cloud.view_offsets], name=cloud.name)
+    return out, votes

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 2
+#define DD_ABI_VERSION 3
 
 enum {
     DD_OK = 0,
@@ -146,6 +146,33 @@ int dd_scatter(const DDViewBatch *batch, const DDCloudOut *out, const int64_t *v
 int dd_unproject_compact(const DDViewBatch *batch, const DDCloudOut *out,
                          int64_t *view_offsets_dev, int64_t *cursor_dev,
                          void *workspace, int64_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * multi-view floater votes, scripts/test.py:269-335 (+ project_points :58-76).
+ * ------------------------------------------------------------------------------------------- */
+
+/* The cached views of scripts/test.py:197-201 as device stacks. */
+typedef struct DDFilterViews {
+    int32_t num_views;
+    int32_t height;
+    int32_t width;
+    int32_t reserved;
+    const float *depth;     /* (V,H,W) refined depth */
+    const uint8_t *mask;    /* (V,H,W) or NULL; mask == 0 reads as depth 0 (scripts/test.py:194) */
+    const double *cams;     /* (V,24) float64 per view: cam_from_world 3x4 row-major [0..11]
+                               (image.cam_from_world().matrix(), :63), calibration rows 0 and 1 [12..17]
+                               (camera.calibration_matrix(), :73), projection centre -R^T t [18..20] (:284) */
+    double grazing_cos;     /* 0.087, scripts/test.py:295 */
+    float depth_threshold;  /* FilteringConfig.depth_threshold = 0.7, scripts/test.py:45-46, 320 */
+    float reserved2;
+} DDFilterViews;
+
+/* votes_dev[i] (= or +=, by `accumulate`) the number of views in which point i is a floater
+ * (scripts/test.py:273-328).  xyz / normal: (n,3) float32 rows of the fused cloud; decisions are taken
+ * in float64 exactly as NumPy promotes them.  The caller then keeps votes < vote_threshold (:330). */
+int dd_floater_votes(const DDFilterViews *views, const float *xyz, const float *normal, int64_t n,
+                     int32_t *votes_dev, int32_t accumulate, void *stream);
+const char *dd_filter_last_error(void);
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,7 @@ of a function imported from the reference tree:
 * ``COLMAPVisualizer._transform_normals``    (src/depthdensifier/visualizer.py:346-376)
 * ``COLMAPVisualizer.add_rgbd_pointcloud``   (src/depthdensifier/visualizer.py:246-289)
 * ``unproject_points``                       (scripts/test.py:79-90)
+* ``project_points``                         (scripts/test.py:58-76)   -> filter_small.npz
 
 The densify block of ``scripts/test.py:203-233`` is inline in ``main`` and not
 callable.  Its validity/order/stride semantics are pinned through the package
@@ -213,9 +214,56 @@ def build_vga():
     return g
 
 
+class _Rigid:
+    def __init__(self, E):
+        self._E = np.asarray(E, np.float64)
+
+    def matrix(self):
+        return self._E
+
+
+class _Image:
+    """Duck-typed image for ``project_points`` (it only calls ``cam_from_world().matrix()``)."""
+
+    def __init__(self, E):
+        self._E = E
+
+    def cam_from_world(self):
+        return _Rigid(self._E)
+
+
+class _CamK:
+    def __init__(self, K):
+        self._K = np.asarray(K, np.float64)
+
+    def calibration_matrix(self):
+        return self._K
+
+
+def build_filter():
+    """``project_points`` (scripts/test.py:58-76) of the reference on seeded points/poses."""
+    g = {}
+    rng = np.random.default_rng(77)
+    V, N = 3, 600
+    E = np.stack([random_pose(rng) for _ in range(V)])
+    K = np.stack([pinhole_K((60.0 + v, 61.0, 32.0, 24.0)) for v in range(V)])
+    pts64 = rng.standard_normal((N, 3)) * 3.0
+    pts32 = pts64.astype(np.float32)
+    g["in_cam_from_world"], g["in_K"], g["in_points64"], g["in_points32"] = E, K, pts64, pts32
+    for tag, pts in (("f64", pts64), ("f32", pts32)):
+        for v in range(V):
+            with np.errstate(divide="ignore", invalid="ignore"):
+                p2, d = REF_SCRIPT.project_points(pts, _Image(E[v]), _CamK(K[v]))
+            g[f"exp_{tag}_v{v}_points2d__project_points"] = p2
+            g[f"exp_{tag}_v{v}_depths__project_points"] = d
+    np.savez_compressed(OUT / "filter_small.npz", **g)
+    return g
+
+
 if __name__ == "__main__":
     a = build_small()
     b = build_vga()
-    for f in ("densify_small.npz", "densify_vga.npz"):
+    build_filter()
+    for f in ("densify_small.npz", "densify_vga.npz", "filter_small.npz"):
         print(f, (OUT / f).stat().st_size, "bytes")
     print("keys:", len(a), len(b))

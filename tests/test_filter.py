@@ -1,0 +1,114 @@
+"""Floater filter: oracle vs the reference's project_points golden (CPU) and the
+HIP vote kernel vs the oracle (GPU; votes are integers -> bit-exact)."""
+
+import numpy as np
+import pytest
+
+from oracle import filter_oracle as forc
+
+
+@pytest.fixture(scope="module")
+def gfilter():
+    from pathlib import Path
+    return dict(np.load(Path(__file__).parent / "golden" / "filter_small.npz"))
+
+
+@pytest.mark.parametrize("tag", ("f64", "f32"))
+def test_project_points_against_reference(gfilter, tag):
+    """scripts/test.py:58-76 as returned by the reference itself (make_goldens.build_filter)."""
+    pts = gfilter["in_points64"] if tag == "f64" else gfilter["in_points32"]
+    for v in range(gfilter["in_K"].shape[0]):
+        p2, d = forc.project_points(pts, gfilter["in_cam_from_world"][v], gfilter["in_K"][v])
+        e2, ed = gfilter[f"exp_{tag}_v{v}_points2d__project_points"], gfilter[f"exp_{tag}_v{v}_depths__project_points"]
+        assert p2.dtype == e2.dtype == np.float64
+        assert np.abs(d - ed).max() <= 1e-12 * np.abs(ed).max()
+        rel = np.abs(p2 - e2) / np.maximum(1.0, np.abs(e2))
+        assert rel.max() <= 1e-9            # points near depth ~ 0 amplify the last-bit matmul difference
+
+
+def test_votes_small_scene_cpu():
+    """Hand-checkable case: a wall at depth 4 seen by two identical cameras; a point at depth 2 is a
+    floater in both (2 < 0.7*4), a point on the wall in neither, a point behind the camera in neither."""
+    E = np.tile(np.hstack([np.eye(3), np.zeros((3, 1))]), (2, 1, 1))
+    K = np.tile(np.array([[50.0, 0, 16], [0, 50.0, 12], [0, 0, 1]]), (2, 1, 1))
+    depth = np.full((2, 24, 32), 4.0, np.float32)
+    pts = np.array([[0, 0, 2.0], [0, 0, 4.0], [0, 0, -1.0], [100.0, 0, 2.0]])
+    nrm = np.tile([0, 0, -1.0], (4, 1)).astype(np.float32)     # facing the cameras
+    assert list(forc.floater_votes(pts, nrm, depth, K, E)) == [2, 0, 0, 0]
+    grazing = np.tile([1.0, 0, 0], (4, 1)).astype(np.float32)
+    assert list(forc.floater_votes(pts, grazing, depth, K, E)) == [0, 0, 0, 0]
+    depth[1] = 0                                                # second view has no valid depth there
+    assert list(forc.floater_votes(pts, nrm, depth, K, E)) == [1, 0, 0, 0]
+
+
+def _scene(seed, V, H, W):
+    from synth import make_views
+    d = make_views(seed, V, H, W, rho=0.85, specials=True)
+    rng = np.random.default_rng(seed)
+    params = np.tile([0.9 * W, 0.95 * W, W / 2.0, H / 2.0], (V, 1))
+    E = np.zeros((V, 3, 4))
+    for v in range(V):                        # cameras on a ring looking at the origin: views overlap
+        a = 2 * np.pi * v / V + rng.uniform(-0.05, 0.05)
+        c = np.array([3.5 * np.cos(a), 0.2 * rng.standard_normal(), 3.5 * np.sin(a)])
+        z = -c / np.linalg.norm(c); x = np.cross([0, 1.0, 0], z); x /= np.linalg.norm(x); y = np.cross(z, x)
+        R = np.stack([x, y, z]); E[v, :, :3] = R; E[v, :, 3] = -R @ c
+    d["cam_from_world"] = E
+    d["params"] = params
+    return d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_mask", (True, False))
+def test_gpu_votes_match_oracle(with_mask):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import depthdensifier_amd as dd
+    from oracle import densify_oracle as orc
+
+    d = _scene(5, 7, 72, 96)
+    mask = d["mask"] if with_mask else None
+    cloud = dd.unproject_views(d["depth"], d["params"], d["cam_from_world"], mask=mask, normal=d["normal"], rgb=d["rgb"])
+    K = dd.intrinsics_matrix(d["params"])
+    culled = np.stack([orc.fold_cull_into_depth(d["depth"][v], None if mask is None else mask[v]) for v in range(7)])
+    with np.errstate(invalid="ignore", over="ignore"):
+        culled = np.where(np.isfinite(culled), culled, 0).astype(np.float32)   # keep the scene finite
+    depth_in = np.where(np.isfinite(d["depth"]), d["depth"], 0).astype(np.float32)
+    pts = cloud.points.cpu().numpy()
+    fin = np.isfinite(pts).all(axis=1)
+    votes = dd.floater_votes(cloud.points, cloud.normals, depth_in, K, d["cam_from_world"], mask=mask).cpu().numpy()
+    ref = forc.floater_votes(pts[fin], cloud.normals.cpu().numpy()[fin], culled, K, d["cam_from_world"])
+    assert ref.max() >= 3, "scene too tame to exercise the vote path"
+    assert np.array_equal(votes[fin], ref)
+    # accumulate over view chunks == one call
+    v2 = dd.floater_votes(cloud.points, cloud.normals, depth_in[:3], K[:3], d["cam_from_world"][:3], mask=None if mask is None else mask[:3])
+    v2 = dd.floater_votes(cloud.points, cloud.normals, depth_in[3:], K[3:], d["cam_from_world"][3:], mask=None if mask is None else mask[3:], votes=v2)
+    assert np.array_equal(v2.cpu().numpy(), votes)
+
+
+@pytest.mark.gpu
+def test_gpu_filter_floaters_matches_oracle():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import depthdensifier_amd as dd
+
+    d = _scene(6, 6, 64, 80)
+    d["depth"] = np.where(np.isfinite(d["depth"]) & (d["depth"] > 0), d["depth"], 1.0).astype(np.float32)
+    cloud = dd.unproject_views(d["depth"], d["params"], d["cam_from_world"], mask=d["mask"], normal=d["normal"], rgb=d["rgb"],
+                               view_index=True)
+    K = dd.intrinsics_matrix(d["params"])
+    cfg = dd.FilteringConfig(vote_threshold=2, depth_threshold=0.7)
+    out, votes = dd.filter_floaters(cloud, d["depth"], K, d["cam_from_world"], mask=d["mask"], config=cfg)
+    culled = np.where(d["mask"], d["depth"], 0).astype(np.float32)
+    c = cloud.numpy()
+    ep, ec, en, ev = forc.filter_floaters(c["points"].astype(np.float32), c["colors"], c["normals"], culled, K,
+                                          d["cam_from_world"], vote_threshold=2, depth_threshold=0.7)
+    assert np.array_equal(votes.cpu().numpy(), ev)
+    assert 0 < len(ep) < len(c["points"])
+    o = out.numpy()
+    assert np.array_equal(o["points"].astype(np.float32), ep) and np.array_equal(o["colors"], ec)
+    assert np.array_equal(o["normals"], en)
+    # per-view offsets of the filtered cloud follow the kept points
+    counts = np.bincount(o["view_index"], minlength=6)
+    assert np.array_equal(np.diff(o["view_offsets"]), counts)
