@@ -23,10 +23,11 @@ from .densify import (  # noqa: F401
     unproject_views,
 )
 
+from .depth_refiner import DepthRefiner, RefinerConfig  # noqa: F401,E402
 from .filtering import FilteringConfig, filter_cameras, filter_floaters, floater_votes  # noqa: F401,E402
 
 __all__ = [
-    "FilteringConfig", "filter_cameras", "filter_floaters", "floater_votes",
+    "DepthRefiner", "RefinerConfig", "FilteringConfig", "filter_cameras", "filter_floaters", "floater_votes",
     "CloudBuilder", "FusedCloud", "ViewBatch", "camera_blocks", "count_valid", "fuse_batches",
     "intrinsics_matrix", "plan_batch", "BatchPlan", "unproject_views", "DDCoreError", "__version__",
 ]

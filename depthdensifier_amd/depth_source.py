@@ -1,0 +1,69 @@
+"""Where per-view depth / normal / mask come from.
+
+The reference runs MoGe-2 per image (``scripts/test.py:101-106, 161-168``).  ``moge`` and its weights
+are not available offline, so the source is pluggable:
+
+* ``MoGeSource``   -- ``MoGeModel.from_pretrained(checkpoint).infer(image)`` when ``moge`` imports;
+* ``CachedSource`` -- precomputed maps ``<cache_dir>/<image stem>.npz`` with ``depth`` (H,W) f32/f16,
+  ``mask`` (H,W) bool, optional ``normal`` (H,W,3) -- e.g. dumped once on a machine that has MoGe.
+
+Every source returns DEVICE tensors: the maps go from the producer to the densify kernels
+without the reference's ``.cpu().numpy()`` round trip (``scripts/test.py:166-168``).
+"""
+
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+import torch
+
+
+class DepthSource:
+    def infer(self, image_name: str, rgb_u8: np.ndarray, device: torch.device) -> dict:
+        """``{'depth': (H,W) float, 'normal': (H,W,3) float32 | None, 'mask': (H,W) bool}`` on ``device``."""
+        raise NotImplementedError
+
+
+class MoGeSource(DepthSource):
+    def __init__(self, checkpoint: Path, device: torch.device):
+        from moge.model.v2 import MoGeModel          # scripts/test.py:4
+        self.model = MoGeModel.from_pretrained(checkpoint).to(device).eval()     # :104-105
+
+    def infer(self, image_name, rgb_u8, device):
+        x = torch.from_numpy(rgb_u8).to(device).permute(2, 0, 1).unsqueeze(0).float() / 255.0   # :154-155
+        with torch.no_grad():
+            out = self.model.infer(x)                # :161-162
+        sq = lambda t: None if t is None else t.squeeze(0)
+        return {"depth": sq(out["depth"]), "normal": sq(out.get("normal")), "mask": sq(out["mask"]).bool()}
+
+
+class CachedSource(DepthSource):
+    def __init__(self, cache_dir: Path):
+        self.dir = Path(cache_dir)
+        if not self.dir.is_dir():
+            raise FileNotFoundError(f"depth cache directory not found: {self.dir}")
+
+    def infer(self, image_name, rgb_u8, device):
+        f = self.dir / (Path(image_name).stem + ".npz")
+        if not f.exists():
+            raise FileNotFoundError(f"no cached depth for {image_name}: {f}")
+        z = np.load(f)
+        h, w = rgb_u8.shape[:2]
+        if z["depth"].shape != (h, w):
+            raise ValueError(f"{f}: depth is {z['depth'].shape}, image at processing resolution is {(h, w)}")
+        g = lambda k: torch.from_numpy(z[k]).to(device) if k in z.files else None
+        mask = g("mask")
+        return {"depth": g("depth"), "normal": g("normal"),
+                "mask": mask.bool() if mask is not None else torch.ones((h, w), dtype=torch.bool, device=device)}
+
+
+def make_depth_source(checkpoint: Path, cache_dir: Optional[Path], device: torch.device) -> DepthSource:
+    if cache_dir is not None:
+        return CachedSource(cache_dir)
+    try:
+        return MoGeSource(checkpoint, device)
+    except ImportError as e:
+        raise ImportError("MoGe is not installed; pass --config.moge.cache-dir with precomputed depth maps "
+                          "(<stem>.npz: depth, mask, normal)") from e

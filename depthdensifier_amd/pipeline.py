@@ -1,0 +1,173 @@
+"""The densification pipeline of ``scripts/test.py:main`` (``:95-370``) on the MI355X core.
+
+Same configuration tree (``PathsConfig / MoGeConfig / ProcessingConfig / RefinerConfig /
+FilteringConfig / ScriptConfig``, ``scripts/test.py:20-55``), same steps and messages, same
+outputs (a COLMAP binary model with the dense points appended).  What changed is where the work
+happens: depth / normal / mask stay on the GPU from the depth source through the refiner to the
+densify kernels; the per-view NumPy block (``:203-244``) is ``CloudBuilder.append``; the
+multi-view filter (``:269-335``) is ``filter_floaters``; the per-point ``add_point3D`` loop
+(``:355-358``) is one bulk append.
+"""
+
+from __future__ import annotations
+
+import dataclasses
+import time
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .colmap_io import Reconstruction
+from .densify import CloudBuilder, ViewBatch
+from .depth_refiner import DepthRefiner, RefinerConfig
+from .depth_source import make_depth_source
+from .filtering import FilteringConfig, floater_votes
+
+
+@dataclass
+class PathsConfig:
+    """Configuration for input and output paths."""
+    recon_path: Path = Path("data/360_v2/bicycle/sparse/0")
+    image_dir: Path = Path("data/360_v2/bicycle/images")
+    output_model_dir: Path = Path("results/0")
+
+
+@dataclass
+class MoGeConfig:
+    """Configuration for the MoGe model."""
+    checkpoint: Path = Path("models/moge/moge-2-vitl-normal/model.pt")
+    cache_dir: Optional[Path] = None
+    """Directory of precomputed <image stem>.npz maps (depth, mask, normal); used instead of MoGe."""
+
+
+@dataclass
+class ProcessingConfig:
+    """Parameters for processing and densification."""
+    pipeline_downsample_factor: int = 1
+    """Factor to downsample images before processing. Larger is faster."""
+    downsample_density: int = 32
+    """Controls final point cloud density (1=densest)."""
+
+
+@dataclass
+class ScriptConfig:
+    """Main configuration for the densification script."""
+    paths: PathsConfig = field(default_factory=PathsConfig)
+    moge: MoGeConfig = field(default_factory=MoGeConfig)
+    processing: ProcessingConfig = field(default_factory=ProcessingConfig)
+    refiner: RefinerConfig = field(default_factory=RefinerConfig)
+    filtering: FilteringConfig = field(default_factory=FilteringConfig)
+
+
+def _load_rgb(path: Path, factor: int) -> np.ndarray:
+    from PIL import Image as PILImage
+    img = PILImage.open(path).convert("RGB")                                   # scripts/test.py:146
+    w, h = img.size
+    img = img.resize((w // factor, h // factor), PILImage.Resampling.LANCZOS)  # :149-152
+    return np.array(img)
+
+
+def main(config: ScriptConfig) -> dict:
+    """Densify one COLMAP scan; returns a small report (counts, timings)."""
+    t_total = time.time()
+    if not torch.cuda.is_available():
+        raise RuntimeError("the densification core needs an AMD GPU (no CPU fallback)")
+    device = torch.device("cuda", torch.cuda.current_device())
+
+    t0 = time.time()
+    print(f"Loading depth source ({config.moge.cache_dir or config.moge.checkpoint})...")
+    source = make_depth_source(config.moge.checkpoint, config.moge.cache_dir, device)
+    print(f"-> Depth source ready in {time.time() - t0:.2f}s.")
+
+    t0 = time.time()
+    print(f"Loading COLMAP reconstruction from {config.paths.recon_path}...")
+    rec = Reconstruction(config.paths.recon_path)
+    print(f"Loaded model with {rec.num_reg_images()} images and {rec.num_points3D()} sparse points.")
+    print(f"-> COLMAP reconstruction loaded in {time.time() - t0:.2f}s.")
+
+    refiner_cfg = dataclasses.asdict(config.refiner)
+    refiner = DepthRefiner(**refiner_cfg)                                       # :118-119
+    verbose = refiner_cfg["verbose"] > 0
+    f = config.processing.pipeline_downsample_factor
+    s = config.processing.downsample_density
+
+    # view order: registered images by id (pycolmap iterates an unordered map; sorted is deterministic)
+    image_list = [rec.images[i] for i in sorted(rec.images) if rec.images[i].has_pose]     # :130
+    capacity = 0
+    for im in image_list:
+        cam = rec.cameras[im.camera_id]
+        capacity += (-(-(cam.height // f) // s)) * (-(-(cam.width // f) // s))
+    builder = CloudBuilder(capacity, normals=True, colors=True, pixel_index=False, device=device)
+    cached = []                                                                 # :128 cached_refinement_data
+    t_loop = time.time()
+    for image in image_list:
+        ids = image.observed_point3D_ids()                                      # :135
+        if len(ids) == 0:
+            continue                                                            # :136-137
+        pts_world = rec.xyz_of(ids)                                             # :139
+        rgb = _load_rgb(config.paths.image_dir / image.name, f)                 # :145-152
+        new_h, new_w = rgb.shape[:2]
+        maps = source.infer(image.name, rgb, device)                            # :161-168, stays on device
+        camera = rec.cameras[image.camera_id]
+        camera.rescale(new_width=new_w, new_height=new_h)                       # :172-173 (in place, like the reference)
+        E = image.cam_from_world().matrix()[:3, :]                              # :177
+        K = camera.calibration_matrix()                                         # :178
+        if verbose:
+            print(f"\n--- Refining depth for {image.name} (ID: {image.image_id}) ---")
+        normal = maps["normal"]
+        if normal is None:
+            normal = torch.zeros((new_h, new_w, 3), dtype=torch.float32, device=device)
+        res = refiner.refine_depth(depth_map=maps["depth"], normal_map=normal, points3D=pts_world, cam_from_world=E, K=K,
+                                   mask=maps["mask"], return_tensor=True)        # :179-186
+        refined = res["refined_depth"]
+        refined = refined if isinstance(refined, torch.Tensor) else torch.as_tensor(refined, device=device)
+        refined = refined.float()
+        # :194 "refined_depth[~moge_mask] = 0" is the kernels' validity rule (mask AND depth > 0);
+        # :203-240 densify + append
+        batch = ViewBatch(refined, camera.pinhole_params()[None], E[None], mask=maps["mask"], normal=normal, rgb=rgb,
+                          stride=s, view_index_base=len(cached), device=device)
+        builder.append(batch)
+        cached.append(dict(depth=refined, mask=maps["mask"], K=K, E=E))         # :197-201
+    print(f"-> Image processing loop finished in {time.time() - t_loop:.2f}s.")
+
+    report = {"views": len(cached), "dense_points": 0, "removed": 0}
+    if not cached:
+        print("No dense points were generated. Skipping save.")                 # :366-367
+        return report
+    cloud = builder.finish()
+    print(f"number of dense points: {len(cloud)}")                              # :244-245
+    if len(cloud) == 0:
+        print("No dense points were generated. Skipping save.")
+        return report
+
+    print("\n--- Filtering point cloud for geometric consistency ---")          # :270
+    t0 = time.time()
+    votes = None
+    groups: dict = {}
+    for c in cached:                                                            # views of one size share a launch
+        groups.setdefault(tuple(c["depth"].shape), []).append(c)
+    for views in groups.values():
+        votes = floater_votes(cloud.points, cloud.normals, torch.stack([c["depth"] for c in views]),
+                              np.stack([c["K"] for c in views]), np.stack([c["E"] for c in views]),
+                              mask=torch.stack([c["mask"] for c in views]),
+                              depth_threshold=config.filtering.depth_threshold, votes=votes)
+    keep = votes < config.filtering.vote_threshold                              # :330
+    points = cloud.points[keep].cpu().numpy().astype(np.float64)
+    colors = cloud.colors[keep].cpu().numpy()
+    removed = int((~keep).sum().item())
+    print(f"-> Filtering removed {removed} points ({removed / len(cloud) * 100:.2f}%)")
+    print(f"-> Filtering finished in {time.time() - t0:.2f}s.")
+
+    t0 = time.time()
+    print(f"Adding {len(points)} new dense points...")
+    rec.add_points3D(points, colors)                                            # :355-358, bulk
+    config.paths.output_model_dir.mkdir(parents=True, exist_ok=True)
+    rec.write_binary(config.paths.output_model_dir)                             # :363
+    print(f"COLMAP binary model saved to: {config.paths.output_model_dir}")
+    print(f"-> COLMAP model written in {time.time() - t0:.2f}s.")
+    print(f"\nTotal script execution time: {time.time() - t_total:.2f}s")
+    report.update(dense_points=len(points), removed=removed, total_points=rec.num_points3D())
+    return report

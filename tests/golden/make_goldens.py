@@ -11,6 +11,7 @@ of a function imported from the reference tree:
 * ``COLMAPVisualizer.add_rgbd_pointcloud``   (src/depthdensifier/visualizer.py:246-289)
 * ``unproject_points``                       (scripts/test.py:79-90)
 * ``project_points``                         (scripts/test.py:58-76)   -> filter_small.npz
+* ``DepthRefiner.refine_depth``              (src/depthdensifier/depth_refiner.py:207-328, CPU/FP32) -> refiner_small.npz
 
 The densify block of ``scripts/test.py:203-233`` is inline in ``main`` and not
 callable.  Its validity/order/stride semantics are pinned through the package
@@ -260,10 +261,63 @@ def build_filter():
     return g
 
 
+def refiner_case(seed, H=96, W=128, n_pts=900):
+    """Mono depth = distorted true depth; sparse points = true-depth unprojections + noise + outliers."""
+    rng = np.random.default_rng(seed)
+    ys, xs = np.mgrid[0:H, 0:W]
+    true_depth = 3.0 + 1.2 * np.sin(xs / 17.0) + 0.8 * np.cos(ys / 11.0)
+    mono = (0.35 * true_depth ** 1.15 + 0.1).astype(np.float32)        # unknown monotone distortion
+    mask = rng.uniform(size=(H, W)) < 0.9
+    fx, fy, cx, cy = 110.0, 112.0, W / 2.0, H / 2.0
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+    E = random_pose(rng)
+    u = rng.uniform(2, W - 3, n_pts); v = rng.uniform(2, H - 3, n_pts)
+    d = true_depth[v.astype(int), u.astype(int)] * (1 + 0.01 * rng.standard_normal(n_pts))
+    d[: n_pts // 20] *= rng.uniform(1.5, 3.0, n_pts // 20)            # outliers
+    cam = np.stack([(u - cx) / fx * d, (v - cy) / fy * d, d], axis=-1)
+    world = (cam - E[:, 3]) @ E[:, :3]                                 # R^T (p - t)
+    behind = rng.standard_normal((40, 3)) * 0.2 - E[:, :3].T @ E[:, 3] - 3.0 * E[2, :3]
+    return dict(depth=mono, mask=mask, points3D=np.vstack([world, behind]), cam_from_world=E, K=K)
+
+
+def build_refiner():
+    """``DepthRefiner.refine_depth`` (src/depthdensifier/depth_refiner.py:207-328) of the reference on
+    CPU / FP32, deterministic (adaptive_correspondences=False avoids the unseeded randperm)."""
+    import torch
+    from depthdensifier import DepthRefiner as RefRefiner            # the reference's class
+    g = {}
+    variants = {
+        "default": dict(),
+        "nosmooth": dict(skip_smoothing=True),
+        "notrobust": dict(robust=False),
+        "nomask": dict(),
+        "toofew": dict(min_correspondences=100000),
+    }
+    for i, (name, kw) in enumerate(variants.items()):
+        c = refiner_case(500 + i)
+        if name == "nomask":
+            c["mask"] = None
+        for k, v in c.items():
+            if v is not None:
+                g[f"{name}_in_{k}"] = v
+        ref = RefRefiner(adaptive_correspondences=False, use_fp16=False, verbose=0, **kw)
+        assert ref.device.type == "cpu" and ref.dtype == torch.float32
+        depth_in = c["depth"].copy()
+        out = ref.refine_depth(depth_in, None, c["points3D"], c["cam_from_world"][:3], c["K"], c["mask"])
+        g[f"{name}_exp_refined_depth__refine_depth"] = out["refined_depth"]
+        g[f"{name}_exp_num_correspondences__refine_depth"] = np.int64(out["num_correspondences"])
+        g[f"{name}_exp_scale_factor__refine_depth"] = np.float64(out["scale_factor"])
+        g[f"{name}_exp_outliers_removed__refine_depth"] = np.int64(out.get("outliers_removed", -1))
+        g[f"{name}_exp_returns_input_object"] = np.bool_(out["refined_depth"] is depth_in)
+    np.savez_compressed(OUT / "refiner_small.npz", **g)
+    return g
+
+
 if __name__ == "__main__":
     a = build_small()
     b = build_vga()
     build_filter()
-    for f in ("densify_small.npz", "densify_vga.npz", "filter_small.npz"):
+    build_refiner()
+    for f in ("densify_small.npz", "densify_vga.npz", "filter_small.npz", "refiner_small.npz"):
         print(f, (OUT / f).stat().st_size, "bytes")
     print("keys:", len(a), len(b))

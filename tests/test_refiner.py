@@ -1,0 +1,80 @@
+"""DepthRefiner against outputs of the reference's own class (CPU/FP32 goldens)."""
+
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+VARIANTS = {"default": {}, "nosmooth": {"skip_smoothing": True}, "notrobust": {"robust": False}, "nomask": {},
+            "toofew": {"min_correspondences": 100000}}
+
+
+@pytest.fixture(scope="module")
+def g():
+    return dict(np.load(Path(__file__).parent / "golden" / "refiner_small.npz"))
+
+
+def _refiner(**kw):
+    from depthdensifier_amd.depth_refiner import DepthRefiner
+    r = DepthRefiner(adaptive_correspondences=False, use_fp16=False, **kw)
+    return r
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_against_reference_golden_cpu(g, name, monkeypatch):
+    """Same torch ops on the CPU in FP32 -> same result as the reference returned."""
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+    r = _refiner(**VARIANTS[name])
+    assert r.device.type == "cpu" and r.dtype == torch.float32
+    depth = g[f"{name}_in_depth"].copy()
+    mask = g.get(f"{name}_in_mask")
+    out = r.refine_depth(depth, None, g[f"{name}_in_points3D"], g[f"{name}_in_cam_from_world"][:3], g[f"{name}_in_K"], mask)
+    exp = g[f"{name}_exp_refined_depth__refine_depth"]
+    assert out["num_correspondences"] == int(g[f"{name}_exp_num_correspondences__refine_depth"])
+    assert bool(g[f"{name}_exp_returns_input_object"]) == (out["refined_depth"] is depth)   # early exits alias the input
+    if not g[f"{name}_exp_returns_input_object"]:
+        assert out["outliers_removed"] == int(g[f"{name}_exp_outliers_removed__refine_depth"])
+        assert abs(out["scale_factor"] - float(g[f"{name}_exp_scale_factor__refine_depth"])) < 1e-6
+    assert out["refined_depth"].dtype == np.float32
+    assert np.abs(out["refined_depth"] - exp).max() <= 1e-6 * np.abs(exp).max()
+
+
+def test_median_network_equals_torch_median():
+    from depthdensifier_amd.depth_refiner import median3x3
+    torch.manual_seed(0)
+    img = torch.rand(37, 53)
+    img[img < 0.2] = 0
+    pad = torch.nn.functional.pad(img[None, None], (1, 1, 1, 1), mode="replicate")
+    ref = torch.nn.functional.unfold(pad, 3).view(9, -1).median(dim=0).values.view(37, 53)
+    assert torch.equal(median3x3(img), ref)
+
+
+def test_constructor_overrides_and_config():
+    from depthdensifier_amd import DepthRefiner, RefinerConfig
+    import dataclasses
+    cfg = RefinerConfig(min_correspondences=7, verbose=0)
+    r = DepthRefiner(**dataclasses.asdict(cfg))                    # scripts/test.py:118-119 construction
+    assert r.min_correspondences == 7 and r.edge_margin == 10 and r.robust
+    r2 = DepthRefiner(config=cfg, edge_margin=3)
+    assert r2.min_correspondences == 7 and r2.edge_margin == 3
+    with pytest.raises(TypeError):
+        DepthRefiner(bogus=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ("default", "nomask"))
+def test_gpu_fp32_matches_golden_and_stays_on_device(g, name):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    r = _refiner()
+    assert r.device.type == "cuda"
+    mask = g.get(f"{name}_in_mask")
+    out = r.refine_depth(g[f"{name}_in_depth"], None, g[f"{name}_in_points3D"], g[f"{name}_in_cam_from_world"][:3],
+                         g[f"{name}_in_K"], mask, return_tensor=True)
+    t = out["refined_depth"]
+    assert isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32
+    exp = g[f"{name}_exp_refined_depth__refine_depth"]
+    # GPU matmul / grid_sample round differently from the CPU: a correspondence on the IQR edge may flip
+    diff = np.abs(t.cpu().numpy() - exp)
+    assert np.median(diff) <= 1e-5 and np.quantile(diff, 0.999) <= 2e-2 * exp.max()

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Throughput of the floater-vote kernel on a garden-like scene (GPU box)."""
+import argparse, sys, time
+from pathlib import Path
+import numpy as np, torch
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import bench, depthdensifier_amd as dd
+
+ap = argparse.ArgumentParser(); ap.add_argument("--views", type=int, default=32); ap.add_argument("--cpu-views", type=int, default=0)
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+cfg = dict(bench.WORKLOADS["garden185"]); cfg["V"] = a.views
+ids = np.arange(a.views)
+scene = bench.make_scene(cfg, ids, dev)
+H, W = cfg["H"], cfg["W"]
+params = np.tile([0.8 * W, 0.8 * W, W / 2.0, H / 2.0], (a.views, 1))
+E = bench.ring_poses(ids, a.views)
+cloud = dd.unproject_views(scene["depth"], params, E, mask=scene["mask"], normal=scene["normal"], rgb=scene["rgb"])
+K = dd.intrinsics_matrix(params)
+torch.cuda.synchronize()
+for _ in range(2):
+    t0 = time.perf_counter()
+    votes = dd.floater_votes(cloud.points, cloud.normals, scene["depth"], K, E, mask=scene["mask"])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+pairs = len(cloud) * a.views
+print(f"points {len(cloud)/1e6:.1f} M x views {a.views} = {pairs/1e9:.2f} G pairs in {dt*1e3:.1f} ms -> {pairs/dt/1e9:.1f} Gpairs/s; "
+      f"votes>=5: {(votes >= 5).float().mean().item()*100:.2f} %  max {int(votes.max())}")
+if a.cpu_views:
+    from oracle import filter_oracle as forc
+    n = 2_000_000
+    p = cloud.points[:n].cpu().numpy(); nn = cloud.normals[:n].cpu().numpy()
+    cd = torch.where(scene["mask"], scene["depth"], torch.zeros_like(scene["depth"]))[:a.cpu_views].cpu().numpy()
+    t0 = time.perf_counter(); forc.floater_votes(p, nn, cd, K[:a.cpu_views], E[:a.cpu_views]); dt = time.perf_counter() - t0
+    print(f"oracle (NumPy, 1 core): {n*a.cpu_views/dt/1e6:.1f} Mpairs/s")
