@@ -384,3 +384,27 @@ def test_full_size_12mp_f16(dd, orc):
     dn = depth[1].cpu().numpy()
     ref = orc.densify_view_script(dn, params[1], E[1])
     assert_xyz(cloud.points[H * W:].double().cpu().numpy(), ref["points"], scene_radius(E, dn))
+
+
+def test_visualizer_add_rgbd_pointcloud_dropin(dd, golden_small):
+    """The reference's package API (visualizer.py:246-289) through the alias package."""
+    from depthdensifier.visualizer import COLMAPVisualizer
+    import depthdensifier
+    assert depthdensifier.__version__ == "0.1.0" and depthdensifier.DepthRefiner is dd.DepthRefiner
+    i = _inputs(golden_small, "a")
+    viz = COLMAPVisualizer()
+    with pytest.raises(ValueError):
+        viz.add_rgbd_pointcloud(i["depth"][0])
+    d32 = i["depth"][0].astype(np.float32)
+    pts = viz.add_rgbd_pointcloud(d32, i["rgb"][0], i["Kskew"], i["cam_from_world"][0], i["mask"][0], i["normal"][0], name="x")
+    n0 = int(golden_small["a_exp_viz_counts"][0])
+    assert pts.dtype == np.float64 and pts.shape == (n0, 3)
+    assert_xyz(pts, golden_small["a_exp_viz_points__depth_to_pointcloud"][:n0], scene_radius(i["cam_from_world"][:1], d32))
+    pc = viz.point_clouds[0]
+    assert pc.name == "x" and np.array_equal(pc.colors, golden_small["a_exp_viz_colors__depth_to_pointcloud"][:n0])
+    assert np.abs(pc.normals - golden_small["a_exp_viz_normals__transform_normals"][:n0]).max() <= NORMAL_ATOL
+    # 4x4 extrinsics and no mask -> depth > 0 validity, no normals (visualizer.py:276, 325-327)
+    E4 = np.vstack([i["cam_from_world"][0], [0, 0, 0, 1.0]])
+    viz.add_rgbd_pointcloud(d32, None, i["Kskew"], E4, None, i["normal"][0])
+    assert viz.point_clouds[1].normals is None and viz.point_clouds[1].colors is None
+    assert len(viz.point_clouds[1].points) == int(golden_small["a_exp_viznomask_counts"][0])
