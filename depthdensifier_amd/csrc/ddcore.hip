@@ -11,13 +11,14 @@
 //   src/depthdensifier/visualizer.py:291-376  package formulation (mask-only validity, general K,
 //                              rotated + renormalised normals) -> flags of the same kernel.
 //
-// Design: a memory-bound map + stable compaction, no MFMA.  One 256-thread
-// workgroup per tile of visited pixels; tiles take a ticket (so a tile only ever waits on tiles
-// that already run), count their valid pixels with wave ballots, publish the count in an 8-byte
-// {status,value} granule and obtain their global slot by decoupled look-back over predecessor
-// granules (relaxed agent-scope atomics: the granule is the whole payload, so no fence is needed).
-// Surviving pixels are listed in LDS in output order, then one lane per output point computes
-// xyz and copies the attributes, so stores of consecutive lanes hit consecutive output rows.
+// Design: a memory-bound map + stable compaction, no MFMA.  Two passes, no
+// inter-workgroup dependency in either: (1) count the valid pixels of every 4096-pixel tile (one
+// streaming read of depth/mask/conf), scan the counts per view and over views; (2) every tile re-derives
+// its validity bits, ranks its survivors with wave ballots, lists them in LDS in output order and
+// one lane per output point computes xyz and copies the attributes, so that consecutive lanes write
+// consecutive rows of the (N,3) outputs at their final position.  A single-pass variant (ticket +
+// decoupled look-back over 8-byte {status,value} granules, relaxed agent-scope atomics) is kept behind
+// tuning bit 8: it is bit-identical but slower on MI355X because the polling loads cross XCDs.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -73,6 +74,7 @@ struct KArgs {
     unsigned flags;
     int conf_f16;
     int view_base;
+    int sp_static;                // diagnostic: single-pass without tickets (tile = blockIdx.x)
 };
 
 using gu64 = __attribute__((address_space(1))) unsigned long long;
@@ -84,7 +86,7 @@ __device__ __forceinline__ void st_state(unsigned long long *p, unsigned long lo
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// ---- element loads ---------------------------------------------------------------------------
+// ---- element conversion ------------------------------------------------------------------------
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static __device__ __forceinline__ float cvt(float x) { return x; }
@@ -93,109 +95,43 @@ template <> struct Elem<_Float16> {
     static __device__ __forceinline__ float cvt(_Float16 x) { return (float)x; }
 };
 
-// VEC contiguous elements, address aligned to min(16, VEC*sizeof(T)).
-template <typename T, int VEC>
-__device__ __forceinline__ void load_vec(const T *p, float (&out)[VEC]) {
-    constexpr int BYTES = VEC * (int)sizeof(T);
-    if constexpr (BYTES >= 16) {
-        constexpr int PER = 16 / (int)sizeof(T);
-        typedef T vt __attribute__((ext_vector_type(PER)));
-#pragma unroll
-        for (int i = 0; i < VEC / PER; ++i) {
-            vt v = *reinterpret_cast<const vt *>(p + i * PER);
-#pragma unroll
-            for (int k = 0; k < PER; ++k) out[i * PER + k] = Elem<T>::cvt(v[k]);
-        }
-    } else if constexpr (VEC == 1) {
-        out[0] = Elem<T>::cvt(*p);
-    } else {
-        typedef T vt __attribute__((ext_vector_type(VEC)));
-        vt v = *reinterpret_cast<const vt *>(p);
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) out[k] = Elem<T>::cvt(v[k]);
-    }
-}
+// ==================================================================================================
+// Generic path: any downsample_density, any alignment (scripts/test.py:205-206 default stride is 32,
+// i.e. ~1/1000 of the pixels -- this path is about semantics, not bandwidth).  Visited pixel q of a
+// view (row-major over the Hs x Ws strided grid) lives at source pixel (qy*stride, qx*stride); a
+// thread owns G_CHUNKS visited pixels, chunk c at q0 + c*BLOCK + tid (scalar, lane-contiguous loads).
+// ==================================================================================================
+constexpr int G_CHUNKS = 8;
+constexpr int G_TILE = BLOCK * G_CHUNKS;
 
-template <int VEC>
-__device__ __forceinline__ void load_bytes(const uint8_t *p, unsigned (&out)[VEC]) {
-    if constexpr (VEC == 1) {
-        out[0] = *p;
-    } else if constexpr (VEC == 4) {
-        unsigned w = *reinterpret_cast<const unsigned *>(p);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) out[k] = (w >> (8 * k)) & 0xffu;
-    } else {
-        static_assert(VEC == 8, "VEC");
-        uint2 w = *reinterpret_cast<const uint2 *>(p);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) out[k] = (w.x >> (8 * k)) & 0xffu;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) out[4 + k] = (w.y >> (8 * k)) & 0xffu;
-    }
-}
-
-// ---- validity of the chunks a thread owns ------------------------------------------------------
-// Visited pixel q of a view (row-major over the Hs x Ws strided grid) lives at source pixel
-// (qy*stride, qx*stride).  A thread owns CHUNKS groups of VEC consecutive q; group c starts at
-// q0 + (c*BLOCK + tid)*VEC, so every load instruction of a wave is one contiguous run.
-template <typename DepthT, int VEC, int CHUNKS, bool CONTIG>
-__device__ __forceinline__ void load_and_test(const KArgs &a, int v, unsigned q0, int tid,
-                                              float (&dval)[CHUNKS][VEC], unsigned (&vbits)[CHUNKS]) {
+template <typename DepthT>
+__device__ __forceinline__ void generic_load_test(const KArgs &a, int v, unsigned q0, int tid,
+                                                  float (&dval)[G_CHUNKS], unsigned (&vbits)[G_CHUNKS]) {
     const long long vbase = (long long)v * a.hw;
-    const DepthT *depth = reinterpret_cast<const DepthT *>(a.depth) + vbase;
     const bool use_depth = a.flags & DD_VALID_DEPTH_POSITIVE;
     const bool use_mask = a.flags & DD_VALID_MASK;
     const bool use_conf = a.flags & DD_VALID_CONF;
 #pragma unroll
-    for (int c = 0; c < CHUNKS; ++c) {
-        const unsigned qb = q0 + (unsigned)(c * BLOCK + tid) * VEC;
-        unsigned bits = 0;
-        if constexpr (CONTIG) {
-            if (qb < a.P) {   // P % VEC == 0 in this mode: a group is entirely inside or outside
-                load_vec<DepthT, VEC>(depth + qb, dval[c]);
-                bits = (1u << VEC) - 1;
-                if (use_mask) {
-                    unsigned m[VEC];
-                    load_bytes<VEC>(a.mask + vbase + qb, m);
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) if (m[k] == 0) bits &= ~(1u << k);
-                }
-                if (use_conf) {
-                    float cf[VEC];
-                    if (a.conf_f16) load_vec<_Float16, VEC>(reinterpret_cast<const _Float16 *>(a.conf) + vbase + qb, cf);
-                    else load_vec<float, VEC>(reinterpret_cast<const float *>(a.conf) + vbase + qb, cf);
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) if (!(cf[k] > a.conf_thr)) bits &= ~(1u << k);
-                }
-                if (use_depth) {
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) if (!(dval[c][k] > 0.0f)) bits &= ~(1u << k);
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) dval[c][k] = 0.0f;
+    for (int c = 0; c < G_CHUNKS; ++c) {
+        const unsigned q = q0 + (unsigned)(c * BLOCK + tid);
+        dval[c] = 0.0f;
+        vbits[c] = 0;
+        if (q < a.P) {
+            const unsigned qy = q / (unsigned)a.Ws;
+            const unsigned qx = q - qy * (unsigned)a.Ws;
+            const long long off = vbase + (long long)(qy * (unsigned)a.stride) * a.W + qx * (unsigned)a.stride;
+            const float d = Elem<DepthT>::cvt(reinterpret_cast<const DepthT *>(a.depth)[off]);
+            dval[c] = d;
+            bool ok = true;
+            if (use_mask) ok = ok && (a.mask[off] != 0);
+            if (use_conf) {
+                const float cf = a.conf_f16 ? (float)reinterpret_cast<const _Float16 *>(a.conf)[off]
+                                            : reinterpret_cast<const float *>(a.conf)[off];
+                ok = ok && (cf > a.conf_thr);
             }
-        } else {
-            static_assert(CONTIG || VEC == 1, "strided mode is scalar");
-            dval[c][0] = 0.0f;
-            if (qb < a.P) {
-                const unsigned qy = qb / (unsigned)a.Ws;
-                const unsigned qx = qb - qy * (unsigned)a.Ws;
-                const long long off = vbase + (long long)(qy * (unsigned)a.stride) * a.W + qx * (unsigned)a.stride;
-                const float d = Elem<DepthT>::cvt(reinterpret_cast<const DepthT *>(a.depth)[off]);
-                dval[c][0] = d;
-                bool ok = true;
-                if (use_mask) ok = ok && (a.mask[off] != 0);
-                if (use_conf) {
-                    const float cf = a.conf_f16 ? (float)reinterpret_cast<const _Float16 *>(a.conf)[off]
-                                                : reinterpret_cast<const float *>(a.conf)[off];
-                    ok = ok && (cf > a.conf_thr);
-                }
-                if (use_depth) ok = ok && (d > 0.0f);
-                bits = ok ? 1u : 0u;
-            }
+            if (use_depth) ok = ok && (d > 0.0f);
+            vbits[c] = ok ? 1u : 0u;
         }
-        vbits[c] = bits;
     }
 }
 
@@ -250,14 +186,12 @@ __device__ __forceinline__ long long lookback(unsigned long long *state, unsigne
     return excl;
 }
 
-// ---- the hot kernel ------------------------------------------------------------------------------
-template <typename DepthT, int VEC, int CHUNKS, bool CONTIG, bool SINGLE_PASS>
-__global__ __launch_bounds__(BLOCK) void unproject_compact_kernel(const KArgs a) {
-    constexpr int TILE = BLOCK * VEC * CHUNKS;
-    static_assert(TILE <= 65536, "tile-local index is 16 bit");
-    __shared__ float s_d[TILE];
-    __shared__ unsigned short s_q[TILE];
-    __shared__ int s_tot[CHUNKS][WAVES];
+// ---- generic scatter kernel (two-pass by default; SINGLE_PASS = ticket + look-back variant) -------
+template <typename DepthT, bool SINGLE_PASS>
+__global__ __launch_bounds__(BLOCK) void compact_generic(const KArgs a) {
+    __shared__ float s_d[G_TILE];
+    __shared__ unsigned short s_q[G_TILE];
+    __shared__ int s_tot[G_CHUNKS][WAVES];
     __shared__ long long s_excl;
     __shared__ unsigned s_ticket;
 
@@ -276,26 +210,26 @@ __global__ __launch_bounds__(BLOCK) void unproject_compact_kernel(const KArgs a)
     }
     const int v = (int)(t / a.tiles_per_view);
     const unsigned tv = t - (unsigned)v * a.tiles_per_view;
-    const unsigned q0 = tv * (unsigned)TILE;
+    const unsigned q0 = tv * (unsigned)G_TILE;
 
-    float dval[CHUNKS][VEC];
-    unsigned vbits[CHUNKS];
-    load_and_test<DepthT, VEC, CHUNKS, CONTIG>(a, v, q0, tid, dval, vbits);
+    float dval[G_CHUNKS];
+    unsigned vbits[G_CHUNKS];
+    generic_load_test<DepthT>(a, v, q0, tid, dval, vbits);
 
-    int lane_pre[CHUNKS];
+    int lane_pre[G_CHUNKS];
 #pragma unroll
-    for (int c = 0; c < CHUNKS; ++c) {
+    for (int c = 0; c < G_CHUNKS; ++c) {
         int tot;
-        wave_rank<VEC>(vbits[c], lane, lane_pre[c], tot);
+        wave_rank<1>(vbits[c], lane, lane_pre[c], tot);
         if (lane == 0) s_tot[c][wave] = tot;
     }
     __syncthreads();
 
     // tile-local rank of each owned pixel: chunks in order, waves in order inside a chunk
     int n = 0;
-    int base_c[CHUNKS];
+    int base_c[G_CHUNKS];
 #pragma unroll
-    for (int c = 0; c < CHUNKS; ++c) {
+    for (int c = 0; c < G_CHUNKS; ++c) {
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) {
             if (w == wave) base_c[c] = n;
@@ -303,16 +237,11 @@ __global__ __launch_bounds__(BLOCK) void unproject_compact_kernel(const KArgs a)
         }
     }
 #pragma unroll
-    for (int c = 0; c < CHUNKS; ++c) {
-        int r = base_c[c] + lane_pre[c];
-        const unsigned ql = (unsigned)(c * BLOCK + tid) * VEC;
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            if ((vbits[c] >> k) & 1u) {
-                s_q[r] = (unsigned short)(ql + k);
-                s_d[r] = dval[c][k];
-                ++r;
-            }
+    for (int c = 0; c < G_CHUNKS; ++c) {
+        if (vbits[c]) {
+            const int r = base_c[c] + lane_pre[c];
+            s_q[r] = (unsigned short)(c * BLOCK + tid);
+            s_d[r] = dval[c];
         }
     }
 
@@ -407,6 +336,9 @@ __global__ __launch_bounds__(BLOCK) void unproject_compact_kernel(const KArgs a)
 #endif
 #ifndef DD_XCD_SWIZZLE
 #define DD_XCD_SWIZZLE 0
+#endif
+#ifndef DD_REVERSE_SCATTER
+#define DD_REVERSE_SCATTER 1
 #endif
 #ifndef DD_LEAN_WGS
 #define DD_LEAN_WGS 6
@@ -513,22 +445,51 @@ __device__ __forceinline__ void lean_load_test(const KArgs &a, long long vbase, 
     }
 }
 
-// Look-back for tiles of <= 4096 pixels: aggregates fit 13 bits, so their wave sum is taken with
-// bit-sliced ballots (scalar popcounts) and the single inclusive value with a readlane.
+// Look-back for tiles of <= 4096 pixels.  Every lane inspects LB_K granules (window = 64*LB_K tiles per
+// round trip, nearest tiles in lane 0).  Measured on MI355X (185x1080p): LB_K = 1 -> 3.57 ms, 4 -> 5.50 ms,
+// 8 -> 6.09 ms against 3.45 ms for the dependency-free two-pass path on the same GPU: the sc1 polling
+// loads are served across XCDs through the fabric and compete with the data streams, so a wider window
+// costs more than the round trips it saves.  LB_K stays 1 and two-pass stays the default.
+// Aggregates fit 13 bits: their wave sum is taken with bit-sliced ballots (scalar popcounts) and the
+// single inclusive value with a readlane -- no cross-lane data movement.
+#ifndef DD_LB_K
+#define DD_LB_K 1
+#endif
+constexpr int LB_K = DD_LB_K;
+
 __device__ __forceinline__ long long lookback13(unsigned long long *state, unsigned t, unsigned agg,
                                                 long long base, int lane, int *err) {
     long long excl = 0;
-    long long look = (long long)t - 1;
+    long long look = (long long)t - 1;        // nearest predecessor = lane 0, k 0
     unsigned spins = 0;
     for (;;) {
-        const long long idx = look - lane;
-        const unsigned long long s = (idx >= 0) ? ld_state(&state[idx]) : (ST_INCL | (unsigned long long)base);
-        const unsigned st = (unsigned)(s >> 62);
-        const unsigned long long incl_b = __ballot(st == 2u);
-        const unsigned long long empty_b = __ballot(st == 0u);
-        const int first_incl = incl_b ? __builtin_ctzll(incl_b) : 64;
-        const unsigned long long need = (first_incl >= 63) ? ~0ull : ((2ull << first_incl) - 1ull);
-        if (empty_b & need) {
+        unsigned long long s[LB_K];
+#pragma unroll
+        for (int k = 0; k < LB_K; ++k) {
+            const long long idx = look - (long long)(lane * LB_K + k);
+            s[k] = (idx >= 0) ? ld_state(&state[idx]) : (ST_INCL | (unsigned long long)base);
+        }
+        int incl_k = LB_K;                    // first inclusive granule among this lane's (nearest first)
+        bool empty_before = false;            // an unpublished granule in front of it
+        unsigned agg_before = 0;
+        unsigned long long incl_val = 0;
+#pragma unroll
+        for (int k = LB_K - 1; k >= 0; --k) {
+            const unsigned st = (unsigned)(s[k] >> 62);
+            if (st == 2u) { incl_k = k; incl_val = s[k] & VAL_MASK; }
+        }
+#pragma unroll
+        for (int k = 0; k < LB_K; ++k) {
+            if (k < incl_k) {
+                const unsigned st = (unsigned)(s[k] >> 62);
+                empty_before |= (st == 0u);
+                agg_before += (unsigned)s[k];             // aggregates: value bits only (status 1 sits in bit 62)
+            }
+        }
+        const unsigned long long incl_b = __ballot(incl_k < LB_K);
+        const int L = incl_b ? __builtin_ctzll(incl_b) : 64;
+        const unsigned long long need = (L >= 63) ? ~0ull : ((2ull << L) - 1ull);   // lanes 0..L
+        if (__ballot(empty_before) & need) {
             if (++spins > SPIN_LIMIT) {
                 if (lane == 0) atomicExch(err, 1);
                 break;
@@ -536,18 +497,18 @@ __device__ __forceinline__ long long lookback13(unsigned long long *state, unsig
             __builtin_amdgcn_s_sleep(1);
             continue;
         }
-        const unsigned aggv = (lane < first_incl) ? (unsigned)s : 0u;
+        const unsigned mine = (lane <= L) ? agg_before : 0u;       // <= LB_K * 4096
         unsigned sum = 0;
 #pragma unroll
-        for (int b = 0; b < 13; ++b) sum += (unsigned)__popcll(__ballot((aggv >> b) & 1u)) << b;
+        for (int b = 0; b < 16; ++b) sum += (unsigned)__popcll(__ballot((mine >> b) & 1u)) << b;
         excl += sum;
         if (incl_b) {
-            const unsigned lo = __builtin_amdgcn_readlane((unsigned)s, first_incl);
-            const unsigned hi = __builtin_amdgcn_readlane((unsigned)(s >> 32), first_incl);
-            excl += (long long)((((unsigned long long)hi << 32) | lo) & VAL_MASK);
+            const unsigned lo = __builtin_amdgcn_readlane((unsigned)incl_val, L);
+            const unsigned hi = __builtin_amdgcn_readlane((unsigned)(incl_val >> 32), L);
+            excl += (long long)(((unsigned long long)hi << 32) | lo);
             break;
         }
-        look -= 64;
+        look -= 64 * LB_K;
     }
     if (lane == 0) st_state(&state[t], ST_INCL | (unsigned long long)(excl + agg));
     return excl;
@@ -568,16 +529,22 @@ __global__ __launch_bounds__(BLOCK, DD_LEAN_WGS) void compact_lean(const KArgs a
 
     unsigned t;
     if constexpr (SINGLE_PASS) {
-        if (tid == 0) s_ticket = atomicAdd(&a.hdr->ticket, 1u);
-        __syncthreads();
-        t = __builtin_amdgcn_readfirstlane(s_ticket);
-        if (t >= a.num_tiles) return;
+        if (a.sp_static) {
+            t = blockIdx.x;
+        } else {
+            if (tid == 0) s_ticket = atomicAdd(&a.hdr->ticket, 1u);
+            __syncthreads();
+            t = __builtin_amdgcn_readfirstlane(s_ticket);
+            if (t >= a.num_tiles) return;
+        }
     } else {
 #if DD_XCD_SWIZZLE
         {   // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous range of tiles
             const unsigned nt = a.num_tiles, b = blockIdx.x, x = b & 7u, q = nt >> 3, r = nt & 7u;
             t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
         }
+#elif DD_REVERSE_SCATTER
+        t = a.num_tiles - 1u - blockIdx.x;   // pass 1 read tiles 0..T-1: start where its reads are still in the Infinity Cache
 #else
         t = blockIdx.x;
 #endif
@@ -833,21 +800,20 @@ __global__ __launch_bounds__(BLOCK) void scan_views(const KArgs a) {
     if (tid == 0) a.view_offsets[a.V] = s_carry;
 }
 
-// ---- per-view counts (scripts/test.py:210-212 "valid_pixels", without producing points) ----------
-template <typename DepthT, int VEC, int CHUNKS, bool CONTIG>
-__global__ __launch_bounds__(BLOCK) void count_valid_kernel(const KArgs a) {
-    constexpr int TILE = BLOCK * VEC * CHUNKS;
+// ---- generic pass 1 / dd_count_valid (scripts/test.py:210-212 "valid_pixels", no points produced) -
+template <typename DepthT>
+__global__ __launch_bounds__(BLOCK) void count_generic(const KArgs a) {
     __shared__ int s_part[WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned t = blockIdx.x;
     const int v = (int)(t / a.tiles_per_view);
     const unsigned tv = t - (unsigned)v * a.tiles_per_view;
-    float dval[CHUNKS][VEC];
-    unsigned vbits[CHUNKS];
-    load_and_test<DepthT, VEC, CHUNKS, CONTIG>(a, v, tv * (unsigned)TILE, tid, dval, vbits);
+    float dval[G_CHUNKS];
+    unsigned vbits[G_CHUNKS];
+    generic_load_test<DepthT>(a, v, tv * (unsigned)G_TILE, tid, dval, vbits);
     int cnt = 0;
 #pragma unroll
-    for (int c = 0; c < CHUNKS; ++c) cnt += __popc(vbits[c]);
+    for (int c = 0; c < G_CHUNKS; ++c) cnt += (int)vbits[c];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
     if (lane == 0) s_part[wave] = cnt;
@@ -914,7 +880,8 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
     if (b->tuning & TUNE_FORCE_GENERIC) aligned = false;
     p.lean = aligned;
     p.single = (b->tuning & TUNE_SINGLE_PASS) != 0;
-    p.tile = p.lean ? L_TILE : BLOCK * 8;
+    a.sp_static = (b->tuning & 16u) != 0;   // diagnostic only: relies on in-order dispatch
+    p.tile = p.lean ? L_TILE : G_TILE;
     a.tiles_per_view = (a.P + p.tile - 1) / p.tile;
     const unsigned long long nt = (unsigned long long)a.tiles_per_view * (unsigned)a.V;
     if (nt >= (1ull << 31)) return fail(DD_ERR_UNSUPPORTED, "too many tiles in one batch; split the batch");
@@ -971,8 +938,8 @@ void launch_scatter(const Plan &p, const KArgs &a, hipStream_t s) {
         if (p.f16) launch_lean<_Float16, SP>(a, s); else launch_lean<float, SP>(a, s);
     } else {
         const dim3 grid(a.num_tiles), block(BLOCK);
-        if (p.f16) hipLaunchKernelGGL((unproject_compact_kernel<_Float16, 1, 8, false, SP>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((unproject_compact_kernel<float, 1, 8, false, SP>), grid, block, 0, s, a);
+        if (p.f16) hipLaunchKernelGGL((compact_generic<_Float16, SP>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((compact_generic<float, SP>), grid, block, 0, s, a);
     }
 }
 
@@ -985,8 +952,8 @@ void launch_count(const Plan &p, const KArgs &a, hipStream_t s) {
         else { if (hm) hipLaunchKernelGGL((count_lean<float, true>), grid, block, 0, s, a);
                else hipLaunchKernelGGL((count_lean<float, false>), grid, block, 0, s, a); }
     } else {
-        if (p.f16) hipLaunchKernelGGL((count_valid_kernel<_Float16, 1, 8, false>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((count_valid_kernel<float, 1, 8, false>), grid, block, 0, s, a);
+        if (p.f16) hipLaunchKernelGGL((count_generic<_Float16>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((count_generic<float>), grid, block, 0, s, a);
     }
 }
 

@@ -11,7 +11,7 @@ def main(src: str, dst: str, note: str = "") -> None:
     if not stats:
         sys.exit(f"no *_kernel_stats.csv under {src}")
     rows = list(csv.DictReader(stats[0].open()))
-    mine = ("unproject_compact_kernel", "compact_lean", "count_lean", "count_valid_kernel", "scan_view_tiles", "scan_views",
+    mine = ("compact_generic", "compact_lean", "count_lean", "count_generic", "scan_view_tiles", "scan_views",
             "floater_", "dd_")
     ours = [r for r in rows if any(m in r["Name"] for m in mine)]
     rest = [r for r in rows if r not in ours]
