@@ -174,7 +174,14 @@ class ViewBatch:
             self.conf = self.conf.float()
         if (self.conf is None) != (conf_threshold is None):
             raise ValueError("conf and conf_threshold must be given together")
-        self.conf_threshold = 0.0 if conf_threshold is None else float(conf_threshold)
+        # `conf > thr` as NumPy evaluates it (NEP 50): a Python-float threshold is rounded to the map's
+        # dtype before the comparison, so an f16 map is compared against f16(thr)
+        if conf_threshold is None:
+            self.conf_threshold = 0.0
+        elif self.conf.dtype == torch.float16:
+            self.conf_threshold = float(np.float16(conf_threshold))
+        else:
+            self.conf_threshold = float(np.float32(conf_threshold))
         self.normal = _gpu(normal, dev, torch.float32)
         self.rgb = _gpu(rgb, dev)
         if self.rgb is not None and self.rgb.dtype != torch.uint8:

@@ -1,0 +1,63 @@
+"""Randomised parity sweep: HIP path vs oracle over random shapes, strides, dtypes, field subsets,
+semantics and kernel variants (seeded, so failures reproduce)."""
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import assert_cloud, scene_radius  # noqa: E402  (shared helpers)
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed):
+    from synth import make_views
+    rng = np.random.default_rng(10_000 + seed)
+    V = int(rng.integers(1, 5))
+    # mix of vector-aligned shapes (H*W % 8 == 0) and ragged ones
+    if rng.uniform() < 0.5:
+        H, W = int(rng.integers(1, 40)) * 4, int(rng.integers(1, 40)) * 8
+    else:
+        H, W = int(rng.integers(1, 150)), int(rng.integers(1, 150))
+    dtype = np.float16 if rng.uniform() < 0.4 else np.float32
+    d = make_views(seed, V, H, W, rho=float(rng.uniform(0.05, 1.0)), specials=bool(rng.uniform() < 0.7), depth_dtype=dtype)
+    d["params"] = np.stack([[W * rng.uniform(0.5, 1.5), W * rng.uniform(0.5, 1.5), W / 2 + rng.uniform(-5, 5),
+                             H / 2 + rng.uniform(-5, 5)] for _ in range(V)])
+    opts = dict(
+        stride=int(rng.choice([1, 1, 1, 2, 3, 5, 32])),
+        use_mask=bool(rng.uniform() < 0.7), use_conf=bool(rng.uniform() < 0.3),
+        conf_dtype=np.float16 if rng.uniform() < 0.5 else np.float32,
+        use_normal=bool(rng.uniform() < 0.6), use_rgb=bool(rng.uniform() < 0.6),
+        viz=bool(rng.uniform() < 0.25), tuning=int(rng.choice([0, 0, 1, 8, 9])),
+    )
+    return d, opts
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_configuration(seed):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import depthdensifier_amd as dd
+    from oracle import densify_oracle as orc
+
+    d, o = _case(seed)
+    mask = d["mask"] if o["use_mask"] else None
+    normal = d["normal"] if o["use_normal"] else None
+    rgb = d["rgb"] if o["use_rgb"] else None
+    rad = scene_radius(d["cam_from_world"], d["depth"])
+    if o["viz"]:
+        depth32 = d["depth"].astype(np.float32)
+        K = dd.intrinsics_matrix(d["params"])
+        cloud = dd.unproject_views(depth32, K, d["cam_from_world"], mask=mask, normal=normal, rgb=rgb, semantics="viz",
+                                   view_index=True, tuning=o["tuning"])
+        with np.errstate(invalid="ignore", over="ignore"):
+            ref = orc.densify_scene_viz(depth32, K, d["cam_from_world"], mask=mask, normal=normal, rgb=rgb)
+        assert_cloud(cloud, ref, rad, normals="close")
+        return
+    conf = d["conf"].astype(o["conf_dtype"]) if o["use_conf"] else None
+    thr = 0.37 if o["use_conf"] else None
+    cloud = dd.unproject_views(d["depth"], d["params"], d["cam_from_world"], mask=mask, normal=normal, rgb=rgb, conf=conf,
+                               conf_threshold=thr, downsample_density=o["stride"], view_index=True, tuning=o["tuning"])
+    ref = orc.densify_scene_script(d["depth"], d["params"], d["cam_from_world"], mask=mask, normal=normal, rgb=rgb,
+                                   stride=o["stride"], conf=conf, conf_threshold=thr)
+    assert_cloud(cloud, ref, rad)
