@@ -367,10 +367,11 @@ template <> __device__ __forceinline__ float raw_depth<_Float16>(const uint4 &d,
 // Loads + validity bits of the CH groups a lane owns.  Addresses of out-of-range groups are clamped
 // (P % VEC == 0, so a group is entirely in or out) to keep every load unconditional: the compiler
 // then issues them all before the first use.
-template <typename DepthT, bool HAS_MASK>
+template <typename DepthT, bool HAS_MASK, bool NEED_DEPTH>
 __device__ __forceinline__ void lean_load_test(const KArgs &a, long long vbase, unsigned qw, int lane,
                                                uint4 (&d)[L_PXT / (16 / (int)sizeof(DepthT))],
                                                unsigned (&bits)[L_PXT / (16 / (int)sizeof(DepthT))]) {
+    // NEED_DEPTH = false: pass 1 under a mask-only validity rule touches 1 B/px instead of 5
     constexpr int VEC = 16 / (int)sizeof(DepthT), CH = L_PXT / VEC;
     unsigned mk[CH][VEC / 4];
     bool inside[CH];
@@ -380,8 +381,9 @@ __device__ __forceinline__ void lean_load_test(const KArgs &a, long long vbase, 
         inside[ch] = qb < a.P;
         if (!inside[ch]) qb = a.P - VEC;
         const long long e = vbase + qb;
+        if constexpr (!NEED_DEPTH) { d[ch].x = d[ch].y = d[ch].z = d[ch].w = 0u; }
 #if DD_NT_LOAD
-        {
+        if constexpr (NEED_DEPTH) {
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 w = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(reinterpret_cast<const DepthT *>(a.depth) + e));
             d[ch].x = w.x; d[ch].y = w.y; d[ch].z = w.z; d[ch].w = w.w;
@@ -391,7 +393,7 @@ __device__ __forceinline__ void lean_load_test(const KArgs &a, long long vbase, 
             for (int i = 0; i < VEC / 4; ++i) mk[ch][i] = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(a.mask + e + 4 * i));
         }
 #else
-        d[ch] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const DepthT *>(a.depth) + e);
+        if constexpr (NEED_DEPTH) d[ch] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const DepthT *>(a.depth) + e);
         if constexpr (HAS_MASK) {
 #pragma unroll
             for (int i = 0; i < VEC / 4; ++i) mk[ch][i] = *reinterpret_cast<const unsigned *>(a.mask + e + 4 * i);
@@ -418,7 +420,7 @@ __device__ __forceinline__ void lean_load_test(const KArgs &a, long long vbase, 
             }
         }
     }
-    const bool use_depth = a.flags & DD_VALID_DEPTH_POSITIVE;
+    const bool use_depth = NEED_DEPTH && (a.flags & DD_VALID_DEPTH_POSITIVE);
 #pragma unroll
     for (int ch = 0; ch < CH; ++ch) {
         unsigned b = inside[ch] ? ((1u << VEC) - 1u) : 0u;
@@ -557,7 +559,7 @@ __global__ __launch_bounds__(BLOCK, DD_LEAN_WGS) void compact_lean(const KArgs a
 
     uint4 d[CH];
     unsigned bits[CH];
-    lean_load_test<DepthT, HAS_MASK>(a, vbase, qw, lane, d, bits);
+    lean_load_test<DepthT, HAS_MASK, true>(a, vbase, qw, lane, d, bits);
 
     int lane_pre[CH], tot[CH], m = 0;
 #pragma unroll
@@ -713,7 +715,7 @@ __global__ __launch_bounds__(BLOCK, DD_LEAN_WGS) void compact_lean(const KArgs a
 }
 
 // ---- pass 1 of the two-pass mode (and dd_count_valid on aligned maps) ----------------------------
-template <typename DepthT, bool HAS_MASK>
+template <typename DepthT, bool HAS_MASK, bool NEED_DEPTH>
 __global__ __launch_bounds__(BLOCK) void count_lean(const KArgs a) {
     constexpr int VEC = 16 / (int)sizeof(DepthT), CH = L_PXT / VEC;
     __shared__ unsigned s_tot[WAVES];
@@ -724,7 +726,7 @@ __global__ __launch_bounds__(BLOCK) void count_lean(const KArgs a) {
     const unsigned tv = t - v * a.tiles_per_view;
     uint4 d[CH];
     unsigned bits[CH];
-    lean_load_test<DepthT, HAS_MASK>(a, (long long)v * a.hw, tv * (unsigned)L_TILE + (unsigned)wave * L_WSPAN, lane, d, bits);
+    lean_load_test<DepthT, HAS_MASK, NEED_DEPTH>(a, (long long)v * a.hw, tv * (unsigned)L_TILE + (unsigned)wave * L_WSPAN, lane, d, bits);
     unsigned cnt = 0;
 #pragma unroll
     for (int ch = 0; ch < CH; ++ch) cnt += __popc(bits[ch]);
@@ -947,10 +949,17 @@ void launch_count(const Plan &p, const KArgs &a, hipStream_t s) {
     const dim3 grid(a.num_tiles), block(BLOCK);
     const bool hm = a.flags & DD_VALID_MASK;
     if (p.lean) {
-        if (p.f16) { if (hm) hipLaunchKernelGGL((count_lean<_Float16, true>), grid, block, 0, s, a);
-                     else hipLaunchKernelGGL((count_lean<_Float16, false>), grid, block, 0, s, a); }
-        else { if (hm) hipLaunchKernelGGL((count_lean<float, true>), grid, block, 0, s, a);
-               else hipLaunchKernelGGL((count_lean<float, false>), grid, block, 0, s, a); }
+        const bool nd = (a.flags & DD_VALID_DEPTH_POSITIVE) != 0;   // mask(/conf)-only rules never read depth in pass 1
+        if (hm && !nd) {
+            if (p.f16) hipLaunchKernelGGL((count_lean<_Float16, true, false>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((count_lean<float, true, false>), grid, block, 0, s, a);
+        } else if (p.f16) {
+            if (hm) hipLaunchKernelGGL((count_lean<_Float16, true, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((count_lean<_Float16, false, true>), grid, block, 0, s, a);
+        } else {
+            if (hm) hipLaunchKernelGGL((count_lean<float, true, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((count_lean<float, false, true>), grid, block, 0, s, a);
+        }
     } else {
         if (p.f16) hipLaunchKernelGGL((count_generic<_Float16>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((count_generic<float>), grid, block, 0, s, a);

@@ -149,7 +149,7 @@ class ViewBatch:
                  conf_threshold: Optional[float] = None, normal: Optional[ArrayLike] = None,
                  rgb: Optional[ArrayLike] = None, stride: int = 1, semantics: str = "script",
                  rotate_normals: Optional[bool] = None, view_index_base: int = 0, device=None,
-                 tuning: int = 0):
+                 tuning: int = 0, depth_positive_on_mask: bool = False):
         if semantics not in SEMANTICS:
             raise ValueError(f"semantics must be one of {SEMANTICS}")
         dev = _require_gpu(device)
@@ -204,8 +204,13 @@ class ViewBatch:
 
         flags = 0
         if semantics == "script":
-            # scripts/test.py:194 + :210 -- mask folded into depth, then depth > 0
-            flags |= _lib.DD_VALID_DEPTH_POSITIVE
+            # scripts/test.py:194 + :210 -- mask folded into depth, then depth > 0.
+            # depth_positive_on_mask: the caller guarantees depth > 0 wherever the mask is set (true for
+            # DepthRefiner output with skip_smoothing, floored at 1e-3 on the mask, depth_refiner.py:176;
+            # NOT with the 3x3 median, which can zero an isolated masked pixel); the rule then reduces
+            # to the mask and pass 1 reads 1 B/px instead of 5.
+            if self.mask is None or not depth_positive_on_mask:
+                flags |= _lib.DD_VALID_DEPTH_POSITIVE
             if self.mask is not None:
                 flags |= _lib.DD_VALID_MASK
             rot_default = False                      # scripts/test.py:220 camera-frame normals

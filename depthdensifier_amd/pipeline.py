@@ -123,12 +123,15 @@ def main(config: ScriptConfig) -> dict:
         res = refiner.refine_depth(depth_map=maps["depth"], normal_map=normal, points3D=pts_world, cam_from_world=E, K=K,
                                    mask=maps["mask"], return_tensor=True)        # :179-186
         refined = res["refined_depth"]
+        # depth > 0 on the whole mask is guaranteed only for an un-smoothed refinement: early exits hand back
+        # the raw map (depth_refiner.py:259-299) and the 3x3 median can zero an isolated masked pixel (:194-203)
+        was_refined = "outliers_removed" in res and refiner.skip_smoothing
         refined = refined if isinstance(refined, torch.Tensor) else torch.as_tensor(refined, device=device)
         refined = refined.float()
         # :194 "refined_depth[~moge_mask] = 0" is the kernels' validity rule (mask AND depth > 0);
         # :203-240 densify + append
         batch = ViewBatch(refined, camera.pinhole_params()[None], E[None], mask=maps["mask"], normal=normal, rgb=rgb,
-                          stride=s, view_index_base=len(cached), device=device)
+                          stride=s, view_index_base=len(cached), device=device, depth_positive_on_mask=was_refined)
         builder.append(batch)
         cached.append(dict(depth=refined, mask=maps["mask"], K=K, E=E))         # :197-201
     print(f"-> Image processing loop finished in {time.time() - t_loop:.2f}s.")

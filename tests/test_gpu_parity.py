@@ -408,3 +408,14 @@ def test_visualizer_add_rgbd_pointcloud_dropin(dd, golden_small):
     viz.add_rgbd_pointcloud(d32, None, i["Kskew"], E4, None, i["normal"][0])
     assert viz.point_clouds[1].normals is None and viz.point_clouds[1].colors is None
     assert len(viz.point_clouds[1].points) == int(golden_small["a_exp_viznomask_counts"][0])
+
+
+def test_mask_only_pass1_and_positive_depth_hint(dd, orc):
+    """Pass 1 without depth loads (mask-only validity): viz semantics and the refiner-output hint give the
+    same cloud as the full rule when depth > 0 on the mask."""
+    d = _rand_case(51, 3, 128, 192, specials=False)          # depth in [0.5, 5): positive everywhere
+    ref = orc.densify_scene_script(d["depth"], d["params"], d["cam_from_world"], mask=d["mask"], rgb=d["rgb"])
+    hinted = dd.fuse_batches([dd.ViewBatch(d["depth"], d["params"], d["cam_from_world"], mask=d["mask"], rgb=d["rgb"],
+                                           depth_positive_on_mask=True)], colors=True, view_index=True)
+    assert hinted.numpy()["view_offsets"].tolist() == ref.view_offsets.tolist()
+    assert_cloud(hinted, ref, scene_radius(d["cam_from_world"], d["depth"]))
