@@ -21,7 +21,7 @@ import torch  # noqa: F401  (load order, see above)
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("DDCORE_LIB", _HERE / "libddcore.so"))
 
-DD_ABI_VERSION = 3
+DD_ABI_VERSION = 4
 DD_OK = 0
 DD_F32, DD_F16 = 0, 1
 DD_VALID_DEPTH_POSITIVE = 0x1
@@ -40,6 +40,8 @@ EXPORTS = (
     "dd_unproject_compact",
     "dd_floater_votes",
     "dd_filter_last_error",
+    "dd_refine_apply",
+    "dd_refine_last_error",
 )
 
 
@@ -125,6 +127,11 @@ def _load() -> C.CDLL:
     lib.dd_floater_votes.argtypes = [C.POINTER(DDFilterViews), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]
     lib.dd_filter_last_error.restype = C.c_char_p
     lib.dd_filter_last_error.argtypes = []
+    lib.dd_refine_apply.restype = C.c_int
+    lib.dd_refine_apply.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                    C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.dd_refine_last_error.restype = C.c_char_p
+    lib.dd_refine_last_error.argtypes = []
     got = lib.dd_abi_version()
     if got != DD_ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI version {got}, binding expects {DD_ABI_VERSION}; rebuild the library")

@@ -128,8 +128,28 @@ class DepthRefiner:
         out = y0 + t * (y1 - y0)
         return torch.maximum(out, torch.tensor(1e-3, device=self.device, dtype=self.dtype))
 
+    def _apply_curve_hip(self, depth: torch.Tensor, mask: Optional[torch.Tensor], x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        """The same per-pixel work as ``_apply_curve`` in one hand-written kernel (``dd_refine_apply``,
+        ``csrc/ddrefine.hip``): the view is read once and written once.  Always float32 arithmetic."""
+        from ._lib import DD_F16, DD_F32, DDCoreError, lib
+        order = torch.argsort(x.float())
+        kx, ky = x.float()[order].contiguous(), y.float()[order].contiguous()
+        d = depth if depth.dtype in (torch.float16, torch.float32) else depth.float()
+        d = d.contiguous()
+        m = None if mask is None else mask.contiguous().view(torch.uint8)
+        out = torch.empty(d.shape, dtype=torch.float32, device=d.device)
+        rc = lib.dd_refine_apply(d.data_ptr(), DD_F16 if d.dtype == torch.float16 else DD_F32,
+                                 None if m is None else m.data_ptr(), d.shape[0], d.shape[1], kx.data_ptr(), ky.data_ptr(),
+                                 kx.numel(), 1 if self.skip_smoothing else 0, out.data_ptr(),
+                                 torch.cuda.current_stream(d.device).cuda_stream)
+        if rc < 0:
+            raise DDCoreError(rc, lib.dd_refine_last_error().decode())
+        return out
+
     def _apply_curve(self, depth: torch.Tensor, mask: torch.Tensor, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         """``depth_refiner.py:180-205``: curve on masked pixels, 3x3 median, zeros outside the mask."""
+        if depth.is_cuda and len(x) >= 2 and int(mask.sum().item()) >= 4:       # (:143-145, 153-154 keep the tensor path)
+            return self._apply_curve_hip(depth, mask, x, y)
         out = torch.zeros_like(depth)
         if mask.any():
             out[mask] = self._lut_interpolate(depth[mask], x, y)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 3
+#define DD_ABI_VERSION 4
 
 enum {
     DD_OK = 0,
@@ -173,6 +173,18 @@ typedef struct DDFilterViews {
 int dd_floater_votes(const DDFilterViews *views, const float *xyz, const float *normal, int64_t n,
                      int32_t *votes_dev, int32_t accumulate, void *stream);
 const char *dd_filter_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * the per-pixel half of DepthRefiner as one kernel --
+ * src/depthdensifier/depth_refiner.py:180-205 (_apply_transformation) with :141-178
+ * (_pchip_interpolate_optimized): refined = mask ? median3x3( mask ? LUT(depth) : 0 ) : 0, where LUT is
+ * the piecewise-linear curve through the sorted knots (knots_x ascending, >= 2 of them), clamped at the
+ * end knots and floored at 1e-3.  mask == NULL means depth > 0 (:241).  float32 arithmetic.
+ * ------------------------------------------------------------------------------------------- */
+int dd_refine_apply(const void *depth, int32_t depth_dtype, const uint8_t *mask, int32_t height, int32_t width,
+                    const float *knots_x, const float *knots_y, int32_t n_knots, int32_t skip_smoothing,
+                    float *refined_out, void *stream);
+const char *dd_refine_last_error(void);
 
 #ifdef __cplusplus
 }

@@ -78,3 +78,33 @@ def test_gpu_fp32_matches_golden_and_stays_on_device(g, name):
     # GPU matmul / grid_sample round differently from the CPU: a correspondence on the IQR edge may flip
     diff = np.abs(t.cpu().numpy() - exp)
     assert np.median(diff) <= 1e-5 and np.quantile(diff, 0.999) <= 2e-2 * exp.max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("skip", (False, True))
+@pytest.mark.parametrize("shape", [(96, 128), (37, 53), (1, 1), (33, 65)])
+@pytest.mark.parametrize("with_mask", (True, False))
+def test_hip_apply_kernel_equals_tensor_path(shape, skip, with_mask):
+    """dd_refine_apply (csrc/ddrefine.hip) vs the tensor formulation evaluated on the CPU: bit-exact."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from depthdensifier_amd.depth_refiner import DepthRefiner
+    g = torch.Generator().manual_seed(shape[0] * 1000 + shape[1])
+    H, W = shape
+    depth = torch.rand((H, W), generator=g) * 4 + 0.2
+    depth[torch.rand((H, W), generator=g) < 0.1] = 0.0
+    mask = (torch.rand((H, W), generator=g) < 0.8) if with_mask else None
+    x = torch.rand(300, generator=g) * 3 + 0.5            # knots cover only part of the depth range (clamping)
+    x[5] = x[6]                                           # duplicate knot: dx == 0 branch
+    y = 2.0 * x + 0.3 * torch.rand(300, generator=g)
+    y[5] = y[6]                                           # (equal y too: argsort may order equal keys either way)
+    r = DepthRefiner(use_fp16=False, skip_smoothing=skip)
+    m_gpu = None if mask is None else mask.cuda()
+    got = r._apply_curve_hip(depth.cuda(), m_gpu, x.cuda(), y.cuda()).cpu()
+    cpu = DepthRefiner.__new__(DepthRefiner)
+    cpu.__dict__.update(r.__dict__); cpu.device = torch.device("cpu"); cpu.dtype = torch.float32
+    m_cpu = mask if mask is not None else depth > 0
+    if int(m_cpu.sum()) < 4:
+        pytest.skip("fewer than 4 masked pixels: the tensor path takes its own branch")
+    want = cpu._apply_curve(depth.clone(), m_cpu, x, y)
+    assert torch.equal(got, want)
