@@ -58,6 +58,7 @@ struct KArgs {
     long long capacity;
     long long *view_offsets;
     const long long *cursor;
+    long long *cursor_out;        // two-pass: scan_views stores the row after the batch here (may be NULL)
     WsHeader *hdr;
     unsigned long long *tile_state;
     unsigned long long *counts;   // per-view counts (dd_count_valid)
@@ -799,7 +800,52 @@ __global__ __launch_bounds__(BLOCK) void scan_views(const KArgs a) {
         if (tid == BLOCK - 1) s_carry = pre + incl;
         __syncthreads();
     }
-    if (tid == 0) a.view_offsets[a.V] = s_carry;
+    if (tid == 0) {
+        a.view_offsets[a.V] = s_carry;
+        if (a.cursor_out) *a.cursor_out = s_carry;      // read at the top, written last, by the only workgroup
+    }
+}
+
+// Small batches (a single view streamed per call): both scans in ONE workgroup, one launch less.
+__global__ __launch_bounds__(BLOCK) void scan_small(const KArgs a) {
+    __shared__ unsigned s_w[WAVES];
+    __shared__ unsigned s_carry;
+    __shared__ long long s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_base = *a.cursor;
+    for (int v = 0; v < a.V; ++v) {
+        const unsigned *cnt = a.tile_cnt + (size_t)v * a.tiles_per_view;
+        unsigned *off = a.tile_off + (size_t)v * a.tiles_per_view;
+        if (tid == 0) s_carry = 0;
+        __syncthreads();
+        for (unsigned b = 0; b < a.tiles_per_view; b += BLOCK) {
+            const unsigned i = b + tid;
+            const unsigned x = i < a.tiles_per_view ? cnt[i] : 0u;
+            unsigned incl = x;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned y = __shfl_up(incl, o);
+                if (lane >= o) incl += y;
+            }
+            if (lane == 63) s_w[wave] = incl;
+            __syncthreads();
+            unsigned pre = s_carry;
+            for (int w = 0; w < wave; ++w) pre += s_w[w];
+            if (i < a.tiles_per_view) off[i] = pre + incl - x;
+            __syncthreads();
+            if (tid == BLOCK - 1) s_carry = pre + incl;
+            __syncthreads();
+        }
+        if (tid == 0) {
+            a.view_offsets[v] = s_base;
+            s_base += (long long)s_carry;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        a.view_offsets[a.V] = s_base;
+        if (a.cursor_out) *a.cursor_out = s_base;
+    }
 }
 
 // ---- generic pass 1 / dd_count_valid (scripts/test.py:210-212 "valid_pixels", no points produced) -
@@ -974,10 +1020,14 @@ int check_launch(const char *what) {
 
 // pass 1: tile counts -> per-view tile offsets + view totals -> absolute view offsets
 int enqueue_plan(const Plan &p, const KArgs &a, hipStream_t s) {
-    if (hipMemsetAsync(a.hdr, 0, sizeof(WsHeader), s) != hipSuccess) return fail(DD_ERR_LAUNCH, "hipMemsetAsync(workspace) failed");
     launch_count(p, a, s);
-    hipLaunchKernelGGL(scan_view_tiles, dim3(a.V), dim3(BLOCK), 0, s, a);
-    hipLaunchKernelGGL(scan_views, dim3(1), dim3(BLOCK), 0, s, a);
+    const unsigned long long serial_steps = (unsigned long long)a.V * ((a.tiles_per_view + BLOCK - 1) / BLOCK);
+    if (serial_steps <= 16) {
+        hipLaunchKernelGGL(scan_small, dim3(1), dim3(BLOCK), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(scan_view_tiles, dim3(a.V), dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL(scan_views, dim3(1), dim3(BLOCK), 0, s, a);
+    }
     return check_launch("dd_plan");
 }
 
@@ -1051,15 +1101,16 @@ int dd_unproject_compact(const DDViewBatch *batch, const DDCloudOut *out, int64_
         if (hipMemsetAsync(workspace, 0, (size_t)(sizeof(WsHeader) + (size_t)a.num_tiles * 8), s) != hipSuccess)
             return fail(DD_ERR_LAUNCH, "hipMemsetAsync(workspace) failed");
         launch_scatter<true>(p, a, s);
-    } else {
-        if ((rc = enqueue_plan(p, a, s)) != DD_OK) return rc;
-        launch_scatter<false>(p, a, s);
+        if ((rc = check_launch("dd_unproject_compact")) != DD_OK) return rc;
+        // cursor <- row after the batch (kept out of the kernel: its tiles read the old cursor)
+        if (hipMemcpyAsync(cursor_dev, view_offsets_dev + a.V, sizeof(int64_t), hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return fail(DD_ERR_LAUNCH, "hipMemcpyAsync(cursor) failed");
+        return DD_OK;
     }
-    if ((rc = check_launch("dd_unproject_compact")) != DD_OK) return rc;
-    // cursor <- row after the batch (kept out of the kernels: they read the old cursor)
-    if (hipMemcpyAsync(cursor_dev, view_offsets_dev + a.V, sizeof(int64_t), hipMemcpyDeviceToDevice, s) != hipSuccess)
-        return fail(DD_ERR_LAUNCH, "hipMemcpyAsync(cursor) failed");
-    return DD_OK;
+    a.cursor_out = reinterpret_cast<long long *>(cursor_dev);   // the scan kernel advances the cursor itself
+    if ((rc = enqueue_plan(p, a, s)) != DD_OK) return rc;
+    launch_scatter<false>(p, a, s);
+    return check_launch("dd_unproject_compact");
 }
 
 }  // extern "C"

@@ -242,6 +242,23 @@ class ViewBatch:
         return self.num_views * self.visited_per_view
 
     def c_struct(self) -> DDViewBatch:
+        """The C view of this batch (cached: the tensors it points to are owned by ``self``)."""
+        key = (self.view_index_base, self.tuning, self.flags, self.conf_threshold)
+        cached = getattr(self, "_cstruct", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        cs = self._make_c_struct()
+        self._cstruct = (key, cs)
+        self._ws_bytes = None
+        return cs
+
+    def workspace_bytes(self) -> int:
+        cs = self.c_struct()
+        if getattr(self, "_ws_bytes", None) is None:
+            self._ws_bytes = check(lib.dd_workspace_bytes(C.byref(cs)))
+        return self._ws_bytes
+
+    def _make_c_struct(self) -> DDViewBatch:
         V, H, W = self.depth.shape
         ptr = lambda t: None if t is None else t.data_ptr()
         return DDViewBatch(
@@ -288,11 +305,11 @@ def plan_batch(batch: ViewBatch, cursor: Optional[torch.Tensor] = None,
     if cursor is None:
         cursor = torch.zeros(1, dtype=torch.int64, device=batch.device)
     cb = batch.c_struct()
-    nbytes = check(lib.dd_workspace_bytes(C.byref(cb)))
+    nbytes = batch.workspace_bytes()
     if reuse is not None and reuse.workspace.numel() >= nbytes and reuse.view_offsets.numel() == batch.num_views + 1:
         ws, offsets = reuse.workspace, reuse.view_offsets        # steady-state: no allocation per step
     else:
-        ws = torch.empty(max(nbytes, 1024), dtype=torch.uint8, device=batch.device)
+        ws = torch.zeros(max(nbytes, 1024), dtype=torch.uint8, device=batch.device)
         offsets = torch.empty(batch.num_views + 1, dtype=torch.int64, device=batch.device)
     check(lib.dd_plan(C.byref(cb), cursor.data_ptr(), offsets.data_ptr(), ws.data_ptr(), ws.numel(), _stream(batch.device)))
     return BatchPlan(offsets, ws)
@@ -332,9 +349,19 @@ class CloudBuilder:
         self._offsets.clear()
         self._workspaces.clear()
 
+    def _offsets_slice(self, n: int) -> torch.Tensor:
+        """(n,) int64 device slice from a pooled tensor (one allocation per ~4096 offsets, not per append)."""
+        pool, used = getattr(self, "_off_pool", (None, 0))
+        if pool is None or used + n > pool.numel():
+            pool, used = torch.empty(max(4096, n), dtype=torch.int64, device=self.device), 0
+        self._off_pool = (pool, used + n)
+        return pool[used:used + n]
+
     def _workspace(self, nbytes: int) -> torch.Tensor:
         if self._ws_cache is None or self._ws_cache.numel() < nbytes:
-            self._ws_cache = torch.empty(max(nbytes, 1024), dtype=torch.uint8, device=self.device)
+            # zero-filled once: the two-pass kernels never touch the header's error word, the single-pass
+            # variant re-zeroes it on every call
+            self._ws_cache = torch.zeros(max(nbytes, 1024), dtype=torch.uint8, device=self.device)
         return self._ws_cache
 
     def append(self, batch: ViewBatch) -> torch.Tensor:
@@ -345,10 +372,9 @@ class CloudBuilder:
         if self.rgb is not None and batch.rgb is None:
             raise ValueError("this cloud carries colours but the batch has no rgb image")
         cb = batch.c_struct()
-        nbytes = check(lib.dd_workspace_bytes(C.byref(cb)))
-        ws = self._workspace(nbytes)
+        ws = self._workspace(batch.workspace_bytes())
         out = self._out_struct()
-        offsets = torch.empty(batch.num_views + 1, dtype=torch.int64, device=self.device)
+        offsets = self._offsets_slice(batch.num_views + 1)
         check(lib.dd_unproject_compact(C.byref(cb), C.byref(out), offsets.data_ptr(), self.cursor.data_ptr(),
                                        ws.data_ptr(), ws.numel(), _stream(self.device)))
         self._offsets.append(offsets)
@@ -356,9 +382,11 @@ class CloudBuilder:
         return offsets
 
     def _out_struct(self) -> DDCloudOut:
-        ptr = lambda t: None if t is None else t.data_ptr()
-        return DDCloudOut(xyz=ptr(self.xyz), normal=ptr(self.normal), rgb=ptr(self.rgb),
-                          pixel_index=ptr(self.pix), view_index=ptr(self.view), capacity=self.capacity)
+        if getattr(self, "_out_cached", None) is None:
+            ptr = lambda t: None if t is None else t.data_ptr()
+            self._out_cached = DDCloudOut(xyz=ptr(self.xyz), normal=ptr(self.normal), rgb=ptr(self.rgb),
+                                          pixel_index=ptr(self.pix), view_index=ptr(self.view), capacity=self.capacity)
+        return self._out_cached
 
     def scatter(self, batch: ViewBatch, plan: "BatchPlan") -> torch.Tensor:
         """Pass 2 only (``dd_scatter``) for a batch planned with :func:`plan_batch` against this
