@@ -148,6 +148,31 @@ def cpu_baseline(cfg: dict, scene: dict, params: np.ndarray, E: np.ndarray, budg
     }
 
 
+def _timed_gather(D, dd, dist, cloud, cfg, args, step, fence, total_views, n_total, H, W, device) -> dict:
+    rec = 12 + (12 if cfg["normal"] else 0) + (3 if cfg["rgb"] else 0) + (4 if args.pixel_index else 0)
+    free, _ = torch.cuda.mem_get_info(device)
+    if n_total * rec > 0.8 * free:
+        return {"skipped": f"replicated cloud of {n_total * rec / 1e9:.1f} GB does not fit the free HBM ({free / 1e9:.1f} GB)"}
+    sharded = D.fuse_sharded(cloud, total_views)
+    bufs = {"points": torch.empty((n_total, 3), dtype=torch.float32, device=device)}
+    if cfg["rgb"]:
+        bufs["colors"] = torch.empty((n_total, 3), dtype=torch.uint8, device=device)
+    if cfg["normal"]:
+        bufs["normals"] = torch.empty((n_total, 3), dtype=torch.float32, device=device)
+    D.gather_cloud(sharded, out=bufs)
+    fence()
+    g0 = time.perf_counter()
+    for _ in range(args.gather_steps):
+        step(False)
+        D.gather_cloud(sharded, out=bufs)
+    fence()
+    gt = torch.tensor([(time.perf_counter() - g0) / args.gather_steps], dtype=torch.float64, device=device)
+    dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+    return {"value": round(total_views * H * W / float(gt.item()) / 1e6, 1), "unit": "Mpixels/s",
+            "ms_per_step": round(float(gt.item()) * 1e3, 3), "cloud_bytes": n_total * rec,
+            "note": "densify + replicated all-gatherv of xyz/rgb/normal to every rank"}
+
+
 # ------------------------------------------------------------------------------ main
 
 def main() -> None:
@@ -273,29 +298,14 @@ def main() -> None:
     if single_pass:
         plan_ms = 0.0
 
-    # replicated fuse (the north-star all-gatherv of the per-GPU clouds), timed separately
+    # replicated fuse (the north-star all-gatherv of the per-GPU clouds), timed separately.  Guarded: a
+    # failure here (e.g. not enough HBM for the replicated cloud) must not take the main line down.
     gathered = None
     if use_dist and args.gather_steps > 0:
-        sharded = D.fuse_sharded(cloud, total_views)
-        rows = n_total
-        bufs = {"points": torch.empty((rows, 3), dtype=torch.float32, device=device)}
-        if cfg["rgb"]:
-            bufs["colors"] = torch.empty((rows, 3), dtype=torch.uint8, device=device)
-        if cfg["normal"]:
-            bufs["normals"] = torch.empty((rows, 3), dtype=torch.float32, device=device)
-        D.gather_cloud(sharded, out=bufs)
-        fence()
-        g0 = time.perf_counter()
-        for _ in range(args.gather_steps):
-            step(False)
-            D.gather_cloud(sharded, out=bufs)
-        fence()
-        gt = torch.tensor([(time.perf_counter() - g0) / args.gather_steps], dtype=torch.float64, device=device)
-        dist.all_reduce(gt, op=dist.ReduceOp.MAX)
-        rec = 12 + (12 if cfg["normal"] else 0) + (3 if cfg["rgb"] else 0) + (4 if args.pixel_index else 0)
-        gathered = {"value": round(total_views * H * W / float(gt.item()) / 1e6, 1), "unit": "Mpixels/s",
-                    "ms_per_step": round(float(gt.item()) * 1e3, 3), "cloud_bytes": n_total * rec,
-                    "note": "densify + replicated all-gatherv of xyz/rgb/normal to every rank"}
+        try:
+            gathered = _timed_gather(D, dd, dist, cloud, cfg, args, step, fence, total_views, n_total, H, W, device)
+        except Exception as e:      # noqa: BLE001  (reported, not fatal)
+            gathered = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         props = torch.cuda.get_device_properties(device)
