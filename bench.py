@@ -86,10 +86,13 @@ def make_scene(cfg: dict, view_ids: np.ndarray, device) -> dict:
                  + 0.5 * torch.sin(f[2] * 6.283 * (xs + ys) + ph[2]) + 0.25 * torch.sin(f[3] * 12.566 * xs + ph[3]))
         depth[i] = (4.5 + 2.0 * field).clamp(1.0, 8.0).to(ddt)
         if mask is not None:
-            coarse = torch.rand((1, 1, 18, 32), generator=g, device=device)
-            blob = torch.nn.functional.interpolate(coarse, size=(H, W), mode="bicubic", align_corners=False)[0, 0]
-            thr = torch.quantile(blob.flatten()[:: max(1, (H * W) // 200000)], 1.0 - cfg["rho"])
-            mask[i] = blob > thr
+            if cfg.get("mask_kind") == "bernoulli":
+                mask[i] = torch.rand((H, W), generator=g, device=device) < cfg["rho"]
+            else:
+                coarse = torch.rand((1, 1, 18, 32), generator=g, device=device)
+                blob = torch.nn.functional.interpolate(coarse, size=(H, W), mode="bicubic", align_corners=False)[0, 0]
+                thr = torch.quantile(blob.flatten()[:: max(1, (H * W) // 200000)], 1.0 - cfg["rho"])
+                mask[i] = blob > thr
         if normal is not None:
             n = torch.randn((H, W, 3), generator=g, device=device)
             normal[i] = torch.nn.functional.normalize(n, dim=-1)
@@ -185,6 +188,8 @@ def main() -> None:
     ap.add_argument("--pixel-index", action="store_true", help="also emit the int32 pixel index per point")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--gather-steps", type=int, default=2, help="N>1: timed replicated all-gatherv passes (0 = skip)")
+    ap.add_argument("--mask-kind", default="blob", choices=("blob", "bernoulli"),
+                    help="blob: smooth regions (default); bernoulli: independent per-pixel cull, worst case for compaction")
     ap.add_argument("--tuning", type=int, default=0)
     ap.add_argument("--fused-call", action="store_true", help="one dd_unproject_compact call per step instead of dd_plan + dd_scatter")
     args = ap.parse_args()
@@ -217,6 +222,7 @@ def main() -> None:
     from depthdensifier_amd import distributed as D
 
     cfg = dict(WORKLOADS[args.workload])
+    cfg["mask_kind"] = args.mask_kind
     strong = args.workload == "scene2000"
     if args.views:
         cfg["V"] = args.views
@@ -331,7 +337,7 @@ def main() -> None:
             "device": f"{torch.cuda.get_device_name(device)} pci {getattr(props, 'pci_bus_id', '?'):02x}:{getattr(props, 'pci_device_id', 0):02x}",
             "mpoints_per_s": round(n_total / (elapsed / args.steps) / 1e6, 1),
             "config": {"workload": args.workload, "note": cfg["note"], "views_total": total_views, "views_per_gpu": V,
-                       "height": H, "width": W, "downsample_density": 1, "valid_fraction": round(n_local / (V * H * W), 4),
+                       "height": H, "width": W, "downsample_density": 1, "valid_fraction": round(n_local / (V * H * W), 4), "mask_kind": args.mask_kind,
                        "inputs": "+".join(k for k in ("depth", "mask", "conf", "normal", "rgb") if scene[k] is not None),
                        "outputs": "xyz f32" + (" + normal f32" if cfg["normal"] else "") + (" + rgb u8" if cfg["rgb"] else "")
                                   + (" + pixel_index i32" if args.pixel_index else ""),

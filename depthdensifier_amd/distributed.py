@@ -50,6 +50,10 @@ def exchange_counts(local_counts: torch.Tensor, num_views: int, group=None) -> t
     sizes = shard_sizes(num_views, world)
     if local_counts.numel() != sizes[rank]:
         raise ValueError(f"rank {rank} holds {local_counts.numel()} views, shard has {sizes[rank]}")
+    if min(sizes) == max(sizes) and sizes[0] > 0:          # equal shards (weak scaling): no padding, no concat
+        recv = torch.empty(world * sizes[0], dtype=torch.int64, device=local_counts.device)
+        dist.all_gather_into_tensor(recv, local_counts.contiguous(), group=group)
+        return recv
     width = max(max(sizes), 1)
     send = torch.zeros(width, dtype=torch.int64, device=local_counts.device)
     send[: sizes[rank]] = local_counts
