@@ -188,6 +188,7 @@ def main() -> None:
     ap.add_argument("--pixel-index", action="store_true", help="also emit the int32 pixel index per point")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--gather-steps", type=int, default=2, help="N>1: timed replicated all-gatherv passes (0 = skip)")
+    ap.add_argument("--gather-timeout", type=float, default=240.0, help="watchdog for the all-gatherv leg, seconds")
     ap.add_argument("--mask-kind", default="blob", choices=("blob", "bernoulli"),
                     help="blob: smooth regions (default); bernoulli: independent per-pixel cull, worst case for compaction")
     ap.add_argument("--tuning", type=int, default=0)
@@ -304,15 +305,6 @@ def main() -> None:
     if single_pass:
         plan_ms = 0.0
 
-    # replicated fuse (the north-star all-gatherv of the per-GPU clouds), timed separately.  Guarded: a
-    # failure here (e.g. not enough HBM for the replicated cloud) must not take the main line down.
-    gathered = None
-    if use_dist and args.gather_steps > 0:
-        try:
-            gathered = _timed_gather(D, dd, dist, cloud, cfg, args, step, fence, total_views, n_total, H, W, device)
-        except Exception as e:      # noqa: BLE001  (reported, not fatal)
-            gathered = {"error": f"{type(e).__name__}: {e}"[:300]}
-
     if rank == 0:
         props = torch.cuda.get_device_properties(device)
         ms_per_step = elapsed / args.steps * 1e3
@@ -352,10 +344,34 @@ def main() -> None:
                          "pass1_note": "count_lean + 2 scan kernels re-read depth+mask; not credited in algorithmic bytes",
                          "whole_step_frac": round(alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
         }
-        if gathered:
-            line["gathered"] = gathered
-        if args.cpu_seconds > 0:
+        if args.cpu_seconds > 0 and world == 1:      # reported at N=1 only, on rank 0
             line["cpu_baseline"] = cpu_baseline(cfg, scene, params, E, args.cpu_seconds)
+    else:
+        line = None
+
+    # replicated fuse (the north-star all-gatherv of the per-GPU clouds), timed separately AFTER the main
+    # result exists.  Doubly guarded: an exception is reported in the line; a collective that does not
+    # finish within the watchdog's limit makes every rank print/exit with the main result intact.
+    if use_dist and args.gather_steps > 0:
+        import threading
+
+        def bail():
+            if rank == 0:
+                line["gathered"] = {"error": f"all-gatherv leg did not finish within {args.gather_timeout:.0f} s"}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(args.gather_timeout, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            gathered = _timed_gather(D, dd, dist, cloud, cfg, args, step, fence, total_views, n_total, H, W, device)
+        except Exception as e:      # noqa: BLE001  (reported, not fatal)
+            gathered = {"error": f"{type(e).__name__}: {e}"[:300]}
+        dog.cancel()
+        if rank == 0:
+            line["gathered"] = gathered
+    if rank == 0:
         print(json.dumps(line), flush=True)
 
     if use_dist:

@@ -11,9 +11,10 @@ only exchange the path needs is the fuse itself:
   step the fused cloud exists *distributed*: rank r holds global slots
   ``[rank_offsets[r], rank_offsets[r+1])`` ("sharded" fuse, no data-path collective);
 * ``allgatherv_rows`` -- the all-gatherv of the per-GPU compacted clouds (replicated fuse).
-  RCCL has no gatherv primitive; each rank's slice is broadcast straight into its final rows
-  of the pre-allocated global buffer (no staging copy, no padding), all R broadcasts issued
-  asynchronously so an xGMI fully-connected node can drive every link at once.
+  RCCL has no gatherv primitive and xGMI is point-to-point (one link per peer): every rank posts
+  ONE grouped batch of sends (its slice to each peer) and receives (each peer's slice straight into
+  its final rows of the pre-allocated global buffer) -- no staging copy, no padding, every link
+  driven at once.
 
 Works on any ``torch.distributed`` backend: ``nccl`` (= RCCL on ROCm) on GPUs, ``gloo`` in the
 CPU tests.
@@ -21,6 +22,7 @@ CPU tests.
 
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
@@ -86,17 +88,26 @@ def allgatherv_rows(local: torch.Tensor, rows_per_rank: Sequence[int], out: Opti
         out = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     elif out.shape[0] != total or out.shape[1:] != local.shape[1:] or out.dtype != local.dtype:
         raise ValueError("out has the wrong shape or dtype")
-    start = 0
-    work = []
+    starts = [0]
     for r in range(world):
-        piece = out[start:start + rows[r]]
-        start += rows[r]
-        if rows[r] == 0:
-            continue
-        if r == rank:
-            piece.copy_(local)
-        src = r if group is None else dist.get_global_rank(group, r)
-        work.append(dist.broadcast(piece, src=src, group=group, async_op=True))
+        starts.append(starts[-1] + rows[r])
+    pieces = [out[starts[r]:starts[r + 1]] for r in range(world)]
+    glob = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
+    if rows[rank]:
+        pieces[rank].copy_(local)
+    if world == 1:
+        return out
+    if os.environ.get("DD_ALLGATHERV", "p2p") == "broadcast":
+        work = [dist.broadcast(pieces[r], src=glob(r), group=group, async_op=True) for r in range(world) if rows[r]]
+    else:
+        ops = []
+        for k in range(1, world):                      # peer order staggered per rank: no hot receiver
+            dst, src = (rank + k) % world, (rank - k) % world
+            if rows[rank]:
+                ops.append(dist.P2POp(dist.isend, local, glob(dst), group))
+            if rows[src]:
+                ops.append(dist.P2POp(dist.irecv, pieces[src], glob(src), group))
+        work = dist.batch_isend_irecv(ops) if ops else []
     for w in work:
         w.wait()
     return out
