@@ -419,3 +419,32 @@ def test_mask_only_pass1_and_positive_depth_hint(dd, orc):
                                            depth_positive_on_mask=True)], colors=True, view_index=True)
     assert hinted.numpy()["view_offsets"].tolist() == ref.view_offsets.tolist()
     assert_cloud(hinted, ref, scene_radius(d["cam_from_world"], d["depth"]))
+
+
+def test_offsets_beyond_32_bits(dd, orc):
+    """480 views x 1080p: 995 M pixels, ~800 M points -> xyz element offsets > 2^31 and byte offsets > 4 GiB
+    (BASELINE config 3 territory).  Counts, per-view sortedness and the LAST views against the oracle."""
+    import torch
+    V, H, W = 480, 1080, 1920
+    g = torch.Generator(device="cuda").manual_seed(2024)
+    depth = torch.empty((V, H, W), device="cuda")
+    mask = torch.empty((V, H, W), dtype=torch.bool, device="cuda")
+    for v in range(V):                      # per-view generation keeps the temporaries small
+        depth[v].uniform_(0.5, 8.0, generator=g)
+        mask[v] = torch.rand((H, W), device="cuda", generator=g) < 0.8
+    rgb = torch.empty((V, H, W, 3), dtype=torch.uint8, device="cuda")
+    for v in range(0, V, 20):
+        rgb[v:v + 20] = torch.randint(0, 256, (min(20, V - v), H, W, 3), device="cuda", generator=g, dtype=torch.uint8)
+    params = np.tile([0.8 * W, 0.8 * W, W / 2, H / 2], (V, 1))
+    E = _ring_poses(V)
+    cloud = dd.unproject_views(depth, params, E, mask=mask, rgb=rgb, view_index=True)
+    offs = cloud.view_offsets.cpu().numpy()
+    assert offs[-1] == len(cloud) and len(cloud) * 3 > 2 ** 31 and len(cloud) * 12 > 2 ** 32
+    assert np.array_equal(np.diff(offs), mask.sum(dim=(1, 2)).cpu().numpy())
+    for v in (V - 1, V - 2, 200):
+        sl = slice(int(offs[v]), int(offs[v + 1]))
+        ref = orc.densify_view_script(depth[v].cpu().numpy(), params[v], E[v], mask=mask[v].cpu().numpy(), rgb=rgb[v].cpu().numpy())
+        assert np.array_equal(cloud.pixel_index[sl].cpu().numpy().astype(np.int64), ref["pixel_index"])
+        assert torch.all(cloud.view_index[sl] == v)
+        assert np.array_equal(cloud.colors[sl].cpu().numpy(), ref["colors"])
+        assert_xyz(cloud.points[sl].double().cpu().numpy(), ref["points"], scene_radius(E, np.array([8.0])))
