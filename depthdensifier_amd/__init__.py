@@ -24,10 +24,10 @@ from .densify import (  # noqa: F401
 )
 
 from .depth_refiner import DepthRefiner, RefinerConfig  # noqa: F401,E402
-from .filtering import FilteringConfig, filter_cameras, filter_floaters, floater_votes  # noqa: F401,E402
+from .filtering import FilteringConfig, compact_cloud, filter_cameras, filter_floaters, floater_votes  # noqa: F401,E402
 
 __all__ = [
-    "DepthRefiner", "RefinerConfig", "FilteringConfig", "filter_cameras", "filter_floaters", "floater_votes",
+    "DepthRefiner", "RefinerConfig", "FilteringConfig", "compact_cloud", "filter_cameras", "filter_floaters", "floater_votes",
     "CloudBuilder", "FusedCloud", "ViewBatch", "camera_blocks", "count_valid", "fuse_batches",
     "intrinsics_matrix", "plan_batch", "BatchPlan", "unproject_views", "DDCoreError", "__version__",
 ]

@@ -21,7 +21,7 @@ import torch  # noqa: F401  (load order, see above)
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("DDCORE_LIB", _HERE / "libddcore.so"))
 
-DD_ABI_VERSION = 4
+DD_ABI_VERSION = 5
 DD_OK = 0
 DD_F32, DD_F16 = 0, 1
 DD_VALID_DEPTH_POSITIVE = 0x1
@@ -40,6 +40,8 @@ EXPORTS = (
     "dd_unproject_compact",
     "dd_floater_votes",
     "dd_filter_last_error",
+    "dd_compact_workspace_bytes",
+    "dd_compact_cloud",
     "dd_refine_apply",
     "dd_refine_last_error",
 )
@@ -127,6 +129,11 @@ def _load() -> C.CDLL:
     lib.dd_floater_votes.argtypes = [C.POINTER(DDFilterViews), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]
     lib.dd_filter_last_error.restype = C.c_char_p
     lib.dd_filter_last_error.argtypes = []
+    lib.dd_compact_workspace_bytes.restype = C.c_int64
+    lib.dd_compact_workspace_bytes.argtypes = [C.c_int64]
+    lib.dd_compact_cloud.restype = C.c_int
+    lib.dd_compact_cloud.argtypes = [C.POINTER(DDCloudOut), C.c_int64, C.c_void_p, C.c_int32, C.POINTER(DDCloudOut), C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
     lib.dd_refine_apply.restype = C.c_int
     lib.dd_refine_apply.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                     C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]

@@ -73,6 +73,160 @@ __global__ __launch_bounds__(256) void floater_votes_kernel(const FArgs a) {
     a.votes[i] = votes;
 }
 
+// ==================================================================================================
+// Stable compaction of the fused cloud by the vote test (scripts/test.py:330-332:
+// `keep = votes < vote_threshold; points = points[keep]; colors = colors[keep]`), every per-point field.
+// Two passes, no inter-workgroup dependency: (1) kept rows per 4096-row tile, (2) two small scans,
+// (3) one lane per INPUT row: each wave owns 1024 consecutive rows, ranks its kept rows with ballots
+// and copies them to their final position (reads perfectly coalesced, writes contiguous up to the
+// gaps the dropped rows leave).  New view offsets = number of kept rows before each old offset.
+// ==================================================================================================
+constexpr int C_BLOCK = 256, C_WAVES = 4, C_PER_LANE = 16, C_WSPAN = 64 * C_PER_LANE, C_TILE = C_WAVES * C_WSPAN;
+constexpr int C_GROUP = 1024;       // tiles per first-level scan group
+
+typedef float cf3 __attribute__((ext_vector_type(3)));
+typedef unsigned cu1u __attribute__((aligned(1)));
+
+struct CArgs {
+    const int32_t *votes;
+    const float *xyz, *normal;
+    const uint8_t *rgb;
+    const int32_t *pix, *view;
+    float *o_xyz, *o_normal;
+    uint8_t *o_rgb;
+    int32_t *o_pix, *o_view;
+    long long n;
+    int thr;
+    unsigned num_tiles, num_groups;
+    unsigned *tile_cnt, *tile_off;       // kept rows per tile; offset of the tile inside its group
+    long long *group_tot, *group_off;    // kept rows per group; absolute offset of the group
+    long long *kept;                     // (1) total kept rows
+    const long long *old_offsets;        // (V+1) or NULL
+    long long *new_offsets;
+    int V;
+};
+
+__global__ __launch_bounds__(C_BLOCK) void compact_count(const CArgs a) {
+    __shared__ unsigned s_w[C_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long base = (long long)blockIdx.x * C_TILE + wave * C_WSPAN;
+    unsigned cnt = 0;
+#pragma unroll
+    for (int i = 0; i < C_PER_LANE; ++i) {
+        const long long r = base + i * 64 + lane;
+        const bool keep = r < a.n && a.votes[r] < a.thr;
+        cnt += (unsigned)__popcll(__ballot(keep));
+    }
+    if (lane == 0) s_w[wave] = cnt;
+    __syncthreads();
+    if (tid == 0) a.tile_cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// exclusive scan of up to C_GROUP tile counts per workgroup (one group each) + the group's total
+__global__ __launch_bounds__(C_BLOCK) void compact_scan_groups(const CArgs a) {
+    __shared__ unsigned s_w[C_WAVES];
+    __shared__ unsigned s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned g0 = blockIdx.x * C_GROUP;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (unsigned b = 0; b < C_GROUP; b += C_BLOCK) {
+        const unsigned i = g0 + b + tid;
+        const unsigned x = i < a.num_tiles ? a.tile_cnt[i] : 0u;
+        unsigned incl = x;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        unsigned pre = s_carry;
+        for (int w = 0; w < wave; ++w) pre += s_w[w];
+        if (i < a.num_tiles) a.tile_off[i] = pre + incl - x;
+        __syncthreads();
+        if (tid == C_BLOCK - 1) s_carry = pre + incl;
+        __syncthreads();
+    }
+    if (tid == 0) a.group_tot[blockIdx.x] = (long long)s_carry;
+}
+
+// exclusive scan of the group totals (one workgroup), total kept rows, and the new view offsets
+__global__ __launch_bounds__(C_BLOCK) void compact_scan_top(const CArgs a) {
+    __shared__ long long s_w[C_WAVES];
+    __shared__ long long s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (unsigned b = 0; b < a.num_groups; b += C_BLOCK) {
+        const unsigned i = b + tid;
+        const long long x = i < a.num_groups ? a.group_tot[i] : 0ll;
+        long long incl = x;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const long long y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        long long pre = s_carry;
+        for (int w = 0; w < wave; ++w) pre += s_w[w];
+        if (i < a.num_groups) a.group_off[i] = pre + incl - x;
+        __syncthreads();
+        if (tid == C_BLOCK - 1) s_carry = pre + incl;
+        __syncthreads();
+    }
+    if (tid == 0) *a.kept = s_carry;
+}
+
+// new_offsets[v] = kept rows in [0, old_offsets[v])
+__global__ __launch_bounds__(C_BLOCK) void compact_view_offsets(const CArgs a) {
+    const int v = blockIdx.x * C_BLOCK + threadIdx.x;
+    if (v > a.V) return;
+    const long long row = a.old_offsets[v];
+    const long long t = row / C_TILE;
+    long long kept;
+    if (t >= (long long)a.num_tiles) {
+        kept = *a.kept;
+    } else {
+        kept = a.group_off[t / C_GROUP] + a.tile_off[t];
+        for (long long r = t * C_TILE; r < row; ++r) kept += a.votes[r] < a.thr ? 1 : 0;
+    }
+    a.new_offsets[v] = kept;
+}
+
+__global__ __launch_bounds__(C_BLOCK) void compact_scatter(const CArgs a) {
+    __shared__ unsigned s_w[C_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned t = blockIdx.x;
+    const long long base = (long long)t * C_TILE + wave * C_WSPAN;
+    unsigned long long bal[C_PER_LANE];
+    unsigned cnt = 0;
+#pragma unroll
+    for (int i = 0; i < C_PER_LANE; ++i) {
+        const long long r = base + i * 64 + lane;
+        bal[i] = __ballot(r < a.n && a.votes[r] < a.thr);
+        cnt += (unsigned)__popcll(bal[i]);
+    }
+    if (lane == 0) s_w[wave] = cnt;
+    __syncthreads();
+    long long dst = a.group_off[t / C_GROUP] + a.tile_off[t];
+    for (int w = 0; w < wave; ++w) dst += s_w[w];
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int i = 0; i < C_PER_LANE; ++i) {
+        const long long r = base + i * 64 + lane;
+        if ((bal[i] >> lane) & 1ull) {
+            const long long o = dst + __popcll(bal[i] & lt);
+            *reinterpret_cast<cf3 *>(a.o_xyz + o * 3) = *reinterpret_cast<const cf3 *>(a.xyz + r * 3);
+            if (a.o_normal) *reinterpret_cast<cf3 *>(a.o_normal + o * 3) = *reinterpret_cast<const cf3 *>(a.normal + r * 3);
+            if (a.o_rgb) {
+                const unsigned c = r ? (*reinterpret_cast<const cu1u *>(a.rgb + r * 3 - 1) >> 8)
+                                     : (*reinterpret_cast<const cu1u *>(a.rgb) & 0xffffffu);
+                uint8_t *d = a.o_rgb + o * 3;
+                d[0] = (uint8_t)c; d[1] = (uint8_t)(c >> 8); d[2] = (uint8_t)(c >> 16);
+            }
+            if (a.o_pix) a.o_pix[o] = a.pix[r];
+            if (a.o_view) a.o_view[o] = a.view[r];
+        }
+        dst += __popcll(bal[i]);
+    }
+}
+
 thread_local char g_ferr[192] = "";
 
 }  // namespace
@@ -99,6 +253,60 @@ int dd_floater_votes(const DDFilterViews *views, const float *xyz, const float *
     if (blocks > 0x7fffffffll) return fail("too many points for one launch; split the call");
     hipLaunchKernelGGL(floater_votes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     if (hipGetLastError() != hipSuccess) { snprintf(g_ferr, sizeof(g_ferr), "floater_votes launch failed"); return DD_ERR_LAUNCH; }
+    return DD_OK;
+}
+
+int64_t dd_compact_workspace_bytes(int64_t n) {
+    if (n < 0) return DD_ERR_INVALID_ARG;
+    const int64_t tiles = (n + C_TILE - 1) / C_TILE, groups = (tiles + C_GROUP - 1) / C_GROUP;
+    return 16 + tiles * 8 + groups * 16;
+}
+
+int dd_compact_cloud(const DDCloudOut *in, int64_t n, const int32_t *votes_dev, int32_t vote_threshold,
+                     const DDCloudOut *out, int64_t *kept_dev, const int64_t *old_view_offsets_dev,
+                     int64_t *new_view_offsets_dev, int32_t num_views, void *workspace, int64_t workspace_bytes,
+                     void *stream) {
+    auto fail = [](const char *m) { snprintf(g_ferr, sizeof(g_ferr), "%s", m); return DD_ERR_INVALID_ARG; };
+    if (!in || !out || !in->xyz || !out->xyz) return fail("in / out / xyz is NULL");
+    if (n < 0 || !kept_dev) return fail("n is negative or kept_dev is NULL");
+    if (n > 0 && !votes_dev) return fail("votes_dev is NULL");
+    if ((out->normal && !in->normal) || (out->rgb && !in->rgb) || (out->pixel_index && !in->pixel_index) ||
+        (out->view_index && !in->view_index)) return fail("an output field has no input field");
+    if (out->capacity < n) return fail("out->capacity must be >= n (the kept count is not known on the host)");
+    if ((old_view_offsets_dev == nullptr) != (new_view_offsets_dev == nullptr)) return fail("old/new view offsets must be given together");
+    const int64_t need = dd_compact_workspace_bytes(n);
+    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace % 16)) {
+        snprintf(g_ferr, sizeof(g_ferr), "workspace is NULL, mis-aligned or smaller than dd_compact_workspace_bytes()");
+        return DD_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t tiles = (n + C_TILE - 1) / C_TILE, groups = (tiles + C_GROUP - 1) / C_GROUP;
+    if (tiles > 0x7fffffffll) return fail("too many rows for one call");
+    CArgs a;
+    a.votes = votes_dev; a.xyz = in->xyz; a.normal = in->normal; a.rgb = in->rgb; a.pix = in->pixel_index; a.view = in->view_index;
+    a.o_xyz = out->xyz; a.o_normal = out->normal; a.o_rgb = out->rgb; a.o_pix = out->pixel_index; a.o_view = out->view_index;
+    a.n = n; a.thr = vote_threshold; a.num_tiles = (unsigned)tiles; a.num_groups = (unsigned)groups;
+    char *w = reinterpret_cast<char *>(workspace) + 16;
+    a.tile_cnt = reinterpret_cast<unsigned *>(w);
+    a.tile_off = a.tile_cnt + tiles;
+    a.group_tot = reinterpret_cast<long long *>(w + tiles * 8);
+    a.group_off = a.group_tot + groups;
+    a.kept = reinterpret_cast<long long *>(kept_dev);
+    a.old_offsets = reinterpret_cast<const long long *>(old_view_offsets_dev);
+    a.new_offsets = reinterpret_cast<long long *>(new_view_offsets_dev);
+    a.V = num_views;
+    if (n == 0) {
+        if (hipMemsetAsync(kept_dev, 0, 8, s) != hipSuccess) return DD_ERR_LAUNCH;
+        if (new_view_offsets_dev && hipMemsetAsync(new_view_offsets_dev, 0, 8 * (size_t)(num_views + 1), s) != hipSuccess) return DD_ERR_LAUNCH;
+        return DD_OK;
+    }
+    hipLaunchKernelGGL(compact_count, dim3((unsigned)tiles), dim3(C_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(compact_scan_groups, dim3((unsigned)groups), dim3(C_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(compact_scan_top, dim3(1), dim3(C_BLOCK), 0, s, a);
+    if (new_view_offsets_dev)
+        hipLaunchKernelGGL(compact_view_offsets, dim3((unsigned)((num_views + 1 + C_BLOCK - 1) / C_BLOCK)), dim3(C_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(compact_scatter, dim3((unsigned)tiles), dim3(C_BLOCK), 0, s, a);
+    if (hipGetLastError() != hipSuccess) { snprintf(g_ferr, sizeof(g_ferr), "compact_cloud launch failed"); return DD_ERR_LAUNCH; }
     return DD_OK;
 }
 

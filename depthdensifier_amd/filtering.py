@@ -16,7 +16,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from ._lib import DDFilterViews, DDCoreError, lib
+from ._lib import DDCloudOut, DDFilterViews, DDCoreError, lib
 from .densify import ArrayLike, FusedCloud, _gpu, _require_gpu, _stream, intrinsics_matrix
 
 
@@ -90,6 +90,36 @@ def floater_votes(points: torch.Tensor, normals: torch.Tensor, depth: ArrayLike,
     return votes
 
 
+def compact_cloud(cloud: FusedCloud, votes: torch.Tensor, vote_threshold: int) -> FusedCloud:
+    """``keep = votes < vote_threshold`` applied to every per-point field, stable, on the GPU
+    (``dd_compact_cloud``; ``scripts/test.py:330-332``).  One host read for the kept count."""
+    dev = cloud.points.device
+    n = len(cloud)
+    if n == 0:                      # nothing to compact (empty tensors have no device pointer)
+        return cloud
+    ptr = lambda t: None if t is None else t.data_ptr()
+    mk = lambda t: None if t is None else torch.empty_like(t)
+    o_xyz, o_rgb, o_nrm, o_pix, o_view = (mk(t) for t in (cloud.points, cloud.colors, cloud.normals, cloud.pixel_index,
+                                                           cloud.view_index))
+    src = DDCloudOut(xyz=ptr(cloud.points.contiguous()), normal=ptr(cloud.normals), rgb=ptr(cloud.colors),
+                     pixel_index=ptr(cloud.pixel_index), view_index=ptr(cloud.view_index), capacity=n)
+    dst = DDCloudOut(xyz=ptr(o_xyz), normal=ptr(o_nrm), rgb=ptr(o_rgb), pixel_index=ptr(o_pix), view_index=ptr(o_view),
+                     capacity=n)
+    kept = torch.zeros(1, dtype=torch.int64, device=dev)
+    old = cloud.view_offsets.contiguous()
+    new = torch.empty_like(old)
+    nb = int(lib.dd_compact_workspace_bytes(n))
+    ws = torch.empty(max(nb, 64), dtype=torch.uint8, device=dev)
+    rc = lib.dd_compact_cloud(C.byref(src), n, votes.data_ptr(), int(vote_threshold), C.byref(dst), kept.data_ptr(),
+                              old.data_ptr(), new.data_ptr(), old.numel() - 1, ws.data_ptr(), ws.numel(), _stream(dev))
+    if rc < 0:
+        raise DDCoreError(rc, lib.dd_filter_last_error().decode())
+    k = int(kept.item())
+    cut = lambda t: None if t is None else t[:k]
+    return FusedCloud(points=o_xyz[:k], colors=cut(o_rgb), normals=cut(o_nrm), pixel_index=cut(o_pix), view_index=cut(o_view),
+                      view_offsets=new, name=cloud.name)
+
+
 def filter_floaters(cloud: FusedCloud, depth: ArrayLike, intrinsics: ArrayLike, cam_from_world: ArrayLike,
                     mask: Optional[ArrayLike] = None, config: Optional[FilteringConfig] = None):
     """``scripts/test.py:269-335``: returns ``(filtered_cloud, votes)``.  The reference filters points and
@@ -99,11 +129,4 @@ def filter_floaters(cloud: FusedCloud, depth: ArrayLike, intrinsics: ArrayLike, 
     if cloud.normals is None:
         raise ValueError("the floater filter needs per-point normals (scripts/test.py:291)")
     votes = floater_votes(cloud.points, cloud.normals, depth, intrinsics, cam_from_world, mask, cfg.depth_threshold)
-    keep = votes < cfg.vote_threshold                                   # :330
-    csum = torch.zeros(len(cloud) + 1, dtype=torch.int64, device=keep.device)
-    torch.cumsum(keep, 0, out=csum[1:])
-    pick = lambda t: None if t is None else t[keep]
-    out = FusedCloud(points=cloud.points[keep], colors=pick(cloud.colors), normals=pick(cloud.normals),
-                     pixel_index=pick(cloud.pixel_index), view_index=pick(cloud.view_index),
-                     view_offsets=csum[cloud.view_offsets], name=cloud.name)
-    return out, votes
+    return compact_cloud(cloud, votes, cfg.vote_threshold), votes          # :330-332

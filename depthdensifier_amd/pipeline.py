@@ -24,7 +24,7 @@ from .colmap_io import Reconstruction
 from .densify import CloudBuilder, ViewBatch
 from .depth_refiner import DepthRefiner, RefinerConfig
 from .depth_source import make_depth_source
-from .filtering import FilteringConfig, floater_votes
+from .filtering import FilteringConfig, compact_cloud, floater_votes
 
 
 @dataclass
@@ -157,10 +157,10 @@ def main(config: ScriptConfig) -> dict:
                               np.stack([c["K"] for c in views]), np.stack([c["E"] for c in views]),
                               mask=torch.stack([c["mask"] for c in views]),
                               depth_threshold=config.filtering.depth_threshold, votes=votes)
-    keep = votes < config.filtering.vote_threshold                              # :330
-    points = cloud.points[keep].cpu().numpy().astype(np.float64)
-    colors = cloud.colors[keep].cpu().numpy()
-    removed = int((~keep).sum().item())
+    kept = compact_cloud(cloud, votes, config.filtering.vote_threshold)        # :330-332
+    points = kept.points.cpu().numpy().astype(np.float64)
+    colors = kept.colors.cpu().numpy()
+    removed = len(cloud) - len(kept)
     print(f"-> Filtering removed {removed} points ({removed / len(cloud) * 100:.2f}%)")
     print(f"-> Filtering finished in {time.time() - t0:.2f}s.")
 

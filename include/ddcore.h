@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 4
+#define DD_ABI_VERSION 5
 
 enum {
     DD_OK = 0,
@@ -173,6 +173,17 @@ typedef struct DDFilterViews {
 int dd_floater_votes(const DDFilterViews *views, const float *xyz, const float *normal, int64_t n,
                      int32_t *votes_dev, int32_t accumulate, void *stream);
 const char *dd_filter_last_error(void);
+
+/* Stable compaction of every per-point field by the vote test of scripts/test.py:330-332
+ * (keep = votes < vote_threshold).  in / out: the field pointers of DDCloudOut (out->capacity >= n; NULL
+ * output fields are skipped); kept_dev: (1) int64 out; old/new_view_offsets_dev: (V+1) int64 each or both
+ * NULL -- the new offsets are the kept rows before each old offset.  workspace:
+ * dd_compact_workspace_bytes(n) bytes, 16-B aligned. */
+int64_t dd_compact_workspace_bytes(int64_t n);
+int dd_compact_cloud(const DDCloudOut *in, int64_t n, const int32_t *votes_dev, int32_t vote_threshold,
+                     const DDCloudOut *out, int64_t *kept_dev, const int64_t *old_view_offsets_dev,
+                     int64_t *new_view_offsets_dev, int32_t num_views, void *workspace, int64_t workspace_bytes,
+                     void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * the per-pixel half of DepthRefiner as one kernel --

@@ -112,3 +112,36 @@ def test_gpu_filter_floaters_matches_oracle():
     # per-view offsets of the filtered cloud follow the kept points
     counts = np.bincount(o["view_index"], minlength=6)
     assert np.array_equal(np.diff(o["view_offsets"]), counts)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", (0, 1, 63, 4095, 4096, 4097, 300_001))
+@pytest.mark.parametrize("fields", ("all", "xyz_rgb", "xyz"))
+def test_gpu_compact_cloud(n, fields):
+    """dd_compact_cloud vs boolean indexing: stable order, every field, view offsets."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import depthdensifier_amd as dd
+    g = torch.Generator(device="cuda").manual_seed(n + 7)
+    pts = torch.randn((n, 3), device="cuda", generator=g)
+    rgb = torch.randint(0, 256, (n, 3), device="cuda", generator=g, dtype=torch.uint8) if fields != "xyz" else None
+    nrm = torch.randn((n, 3), device="cuda", generator=g) if fields == "all" else None
+    pix = torch.arange(n, device="cuda", dtype=torch.int32) if fields == "all" else None
+    counts = torch.tensor([n // 3, 0, n - n // 3 - n // 5, n // 5], dtype=torch.int64)
+    offs = torch.cat([torch.zeros(1, dtype=torch.int64), counts.cumsum(0)]).cuda()
+    view = torch.repeat_interleave(torch.arange(4, dtype=torch.int32), counts).cuda() if fields == "all" else None
+    cloud = dd.FusedCloud(points=pts, colors=rgb, normals=nrm, pixel_index=pix, view_index=view, view_offsets=offs)
+    votes = torch.randint(0, 8, (n,), device="cuda", generator=g, dtype=torch.int32)
+    out = dd.compact_cloud(cloud, votes, 5)
+    keep = votes < 5
+    assert len(out) == int(keep.sum())
+    assert torch.equal(out.points, pts[keep])
+    if rgb is not None:
+        assert torch.equal(out.colors, rgb[keep])
+    if fields == "all":
+        assert torch.equal(out.normals, nrm[keep]) and torch.equal(out.pixel_index, pix[keep]) and torch.equal(out.view_index, view[keep])
+        assert torch.equal(out.view_offsets.cpu(), torch.cat([torch.zeros(1, dtype=torch.int64),
+                                                               torch.bincount(view[keep].long(), minlength=4).cumsum(0).cpu()]))
+    # keep everything / drop everything
+    assert len(dd.compact_cloud(cloud, votes, 100)) == n and len(dd.compact_cloud(cloud, votes, 0)) == 0
