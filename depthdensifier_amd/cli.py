@@ -81,5 +81,5 @@ def cli(main, argv: Optional[Sequence[str]] = None) -> Any:
     except ImportError:
         pass
     hints = typing.get_type_hints(main)
-    (name, cls), = [(k, v) for k, v in hints.items() if k != "return"]
+    cls = next(v for k, v in hints.items() if k != "return" and dataclasses.is_dataclass(v))   # the config parameter
     return main(parse(cls, sys.argv[1:] if argv is None else argv, description=main.__doc__))
