@@ -452,13 +452,21 @@ __device__ __forceinline__ void lean_load_test(const KArgs &a, long long vbase, 
 // round trip, nearest tiles in lane 0).  Measured on MI355X (185x1080p): LB_K = 1 -> 3.57 ms, 4 -> 5.50 ms,
 // 8 -> 6.09 ms against 3.45 ms for the dependency-free two-pass path on the same GPU: the sc1 polling
 // loads are served across XCDs through the fabric and compete with the data streams, so a wider window
-// costs more than the round trips it saves.  LB_K stays 1 and two-pass stays the default.
+// costs more than the round trips it saves.  Narrower is better still: 16 polling lanes (one or two
+// 128-B lines per poll) -> 3.02 ms.  LB_K stays 1, LB_LANES 16, and two-pass stays the default.
 // Aggregates fit 13 bits: their wave sum is taken with bit-sliced ballots (scalar popcounts) and the
 // single inclusive value with a readlane -- no cross-lane data movement.
 #ifndef DD_LB_K
 #define DD_LB_K 1
 #endif
 constexpr int LB_K = DD_LB_K;
+#ifndef DD_LB_LANES
+#define DD_LB_LANES 16
+#endif
+#ifndef DD_LB_SLEEP
+#define DD_LB_SLEEP 1
+#endif
+constexpr int LB_LANES = DD_LB_LANES;   // lanes that actually poll (window = LB_LANES * LB_K tiles)
 
 __device__ __forceinline__ long long lookback13(unsigned long long *state, unsigned t, unsigned agg,
                                                 long long base, int lane, int *err) {
@@ -470,7 +478,8 @@ __device__ __forceinline__ long long lookback13(unsigned long long *state, unsig
 #pragma unroll
         for (int k = 0; k < LB_K; ++k) {
             const long long idx = look - (long long)(lane * LB_K + k);
-            s[k] = (idx >= 0) ? ld_state(&state[idx]) : (ST_INCL | (unsigned long long)base);
+            if (lane < LB_LANES) s[k] = (idx >= 0) ? ld_state(&state[idx]) : (ST_INCL | (unsigned long long)base);
+            else s[k] = ST_AGG;          // lanes outside the window contribute nothing and never block
         }
         int incl_k = LB_K;                    // first inclusive granule among this lane's (nearest first)
         bool empty_before = false;            // an unpublished granule in front of it
@@ -497,7 +506,7 @@ __device__ __forceinline__ long long lookback13(unsigned long long *state, unsig
                 if (lane == 0) atomicExch(err, 1);
                 break;
             }
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(DD_LB_SLEEP);
             continue;
         }
         const unsigned mine = (lane <= L) ? agg_before : 0u;       // <= LB_K * 4096
@@ -511,7 +520,7 @@ __device__ __forceinline__ long long lookback13(unsigned long long *state, unsig
             excl += (long long)(((unsigned long long)hi << 32) | lo);
             break;
         }
-        look -= 64 * LB_K;
+        look -= LB_LANES * LB_K;
     }
     if (lane == 0) st_state(&state[t], ST_INCL | (unsigned long long)(excl + agg));
     return excl;
@@ -596,22 +605,7 @@ __global__ __launch_bounds__(BLOCK, DD_LEAN_WGS) void compact_lean(const KArgs a
             cum += tot[ch];
         }
     }
-    if constexpr (SINGLE_PASS) {
-        if (wave == 0) {
-            const long long e = lookback13(a.tile_state, t, n, *a.cursor, lane, &a.hdr->error);
-            if (lane == 0) {
-                s_excl = e;
-                if (tv == 0) a.view_offsets[v] = e;
-                if (t == a.num_tiles - 1) a.view_offsets[a.V] = e + n;
-            }
-        }
-    }
-    __syncthreads();   // #2
-    long long excl;
-    if constexpr (SINGLE_PASS) excl = s_excl;
-    else excl = a.view_offsets[v] + (long long)a.tile_off[t];
-    if (n == 0) return;
-
+    long long excl = 0;     // first output row of the tile; known after the look-back / from pass 1
     // ---- one lane per output point; gathers of group i+1 in flight while group i is stored ----
     // Gathers are unconditional and branch-free (lanes past the end re-read point 0) so that the
     // loop is straight-line code and the compiler can keep counted vmcnt waits.
@@ -703,7 +697,30 @@ __global__ __launch_bounds__(BLOCK, DD_LEAN_WGS) void compact_lean(const KArgs a
 
     constexpr int NI = L_TILE / BLOCK;       // 16 point slots per lane at most
     Pt pa, pb;
-    prep(0, pa);
+    if constexpr (SINGLE_PASS) {
+        // Wave 0 looks back while the other waves already issue their first gathers (the list is complete
+        // after this barrier; neither the list nor the gathers need the tile's first row).
+        __syncthreads();
+        if (wave == 0) {
+            const long long e = lookback13(a.tile_state, t, n, *a.cursor, lane, &a.hdr->error);
+            if (lane == 0) {
+                s_excl = e;
+                if (tv == 0) a.view_offsets[v] = e;
+                if (t == a.num_tiles - 1) a.view_offsets[a.V] = e + n;
+            }
+        } else if (n != 0) {
+            prep(0, pa);
+        }
+        __syncthreads();
+        excl = s_excl;
+        if (n == 0) return;
+        if (wave == 0) prep(0, pa);
+    } else {
+        __syncthreads();
+        excl = a.view_offsets[v] + (long long)a.tile_off[t];
+        if (n == 0) return;
+        prep(0, pa);
+    }
 #pragma unroll
     for (int i = 0; i < NI; i += 2) {
         prep(i + 1, pb);
