@@ -191,6 +191,8 @@ def main() -> None:
     ap.add_argument("--gather-timeout", type=float, default=240.0, help="watchdog for the all-gatherv leg, seconds")
     ap.add_argument("--mask-kind", default="blob", choices=("blob", "bernoulli"),
                     help="blob: smooth regions (default); bernoulli: independent per-pixel cull, worst case for compaction")
+    ap.add_argument("--colmap-path", type=Path, default=ROOT / "data" / "360_v2" / "garden" / "sparse" / "0",
+                    help="COLMAP model whose poses/intrinsics replace the synthetic ring (used only if it exists)")
     ap.add_argument("--tuning", type=int, default=0)
     ap.add_argument("--fused-call", action="store_true", help="one dd_unproject_compact call per step instead of dd_plan + dd_scatter")
     args = ap.parse_args()
@@ -242,6 +244,19 @@ def main() -> None:
     scene = make_scene(cfg, view_ids, device)
     params = np.tile([0.8 * W, 0.8 * W, W / 2.0, H / 2.0], (V, 1))
     E = ring_poses(view_ids, total_views)
+    poses_from = "synthetic ring"
+    if args.workload == "garden185" and (args.colmap_path / "images.bin").exists():
+        # real registered poses / intrinsics when the dataset is on disk; maps stay synthetic
+        from depthdensifier_amd.colmap_io import Reconstruction
+        rec = Reconstruction(args.colmap_path)
+        imgs = [rec.images[i] for i in sorted(rec.images)]
+        if len(imgs) >= hi:
+            for j, vid in enumerate(view_ids):
+                im = imgs[int(vid)]
+                cam = rec.cameras[im.camera_id]
+                E[j] = im.cam_from_world().matrix()
+                params[j] = cam.pinhole_params() * [W / cam.width, H / cam.height, W / cam.width, H / cam.height]
+            poses_from = str(args.colmap_path)
     batch = dd.ViewBatch(scene["depth"], params, E, mask=scene["mask"], normal=scene["normal"], rgb=scene["rgb"],
                          conf=scene["conf"], conf_threshold=cfg.get("conf"),
                          view_index_base=int(lo), device=device, tuning=args.tuning)
@@ -330,6 +345,7 @@ def main() -> None:
             "mpoints_per_s": round(n_total / (elapsed / args.steps) / 1e6, 1),
             "config": {"workload": args.workload, "note": cfg["note"], "views_total": total_views, "views_per_gpu": V,
                        "height": H, "width": W, "downsample_density": 1, "valid_fraction": round(n_local / (V * H * W), 4), "mask_kind": args.mask_kind,
+                       "poses": poses_from,
                        "inputs": "+".join(k for k in ("depth", "mask", "conf", "normal", "rgb") if scene[k] is not None),
                        "outputs": "xyz f32" + (" + normal f32" if cfg["normal"] else "") + (" + rgb u8" if cfg["rgb"] else "")
                                   + (" + pixel_index i32" if args.pixel_index else ""),

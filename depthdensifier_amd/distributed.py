@@ -41,6 +41,23 @@ def shard_sizes(num_views: int, world_size: int) -> list[int]:
     return [b - a for a, b in (shard_views(num_views, world_size, r) for r in range(world_size))]
 
 
+def shard_views_balanced(costs: Sequence[float], world_size: int) -> list[tuple[int, int]]:
+    """Contiguous split of views with unequal cost (e.g. pixel counts of mixed-resolution scenes, SURVEY.md
+    8e / BASELINE config 4): cut points at the cumulative-cost quantiles, so rank order is still view
+    order and no rank gets more than its fair share plus one view."""
+    total = float(sum(costs))
+    bounds, acc, v = [0], 0.0, 0
+    n = len(costs)
+    for r in range(1, world_size):
+        target = total * r / world_size
+        while v < n and acc + costs[v] / 2.0 <= target:
+            acc += costs[v]
+            v += 1
+        bounds.append(v)
+    bounds.append(n)
+    return [(bounds[r], bounds[r + 1]) for r in range(world_size)]
+
+
 def exchange_counts(local_counts: torch.Tensor, num_views: int, group=None) -> torch.Tensor:
     """All-gather the per-view counts of every rank; returns (num_views,) int64 on the input's device.
 

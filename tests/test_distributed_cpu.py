@@ -48,3 +48,16 @@ def test_shard_views_partition():
     assert shard_views(2000, 8, 3) == (750, 1000)
     with pytest.raises(ValueError):
         shard_views(10, 2, 2)
+
+
+def test_balanced_contiguous_split():
+    from depthdensifier_amd.distributed import shard_views_balanced
+    costs = [1920 * 1080] * 100 + [4032 * 3024] * 20 + [640 * 480] * 300        # mixed resolutions, in view order
+    for R in (1, 2, 3, 8):
+        spans = shard_views_balanced(costs, R)
+        assert spans[0][0] == 0 and spans[-1][1] == len(costs)
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        loads = [sum(costs[a:b]) for a, b in spans]
+        assert max(loads) <= sum(costs) / R + max(costs)
+    assert shard_views_balanced([1.0] * 8, 4) == [(0, 2), (2, 4), (4, 6), (6, 8)]
+    assert shard_views_balanced([], 2) == [(0, 0), (0, 0)]
