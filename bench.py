@@ -194,7 +194,7 @@ def main() -> None:
     ap.add_argument("--colmap-path", type=Path, default=ROOT / "data" / "360_v2" / "garden" / "sparse" / "0",
                     help="COLMAP model whose poses/intrinsics replace the synthetic ring (used only if it exists)")
     ap.add_argument("--tuning", type=int, default=0)
-    ap.add_argument("--fused-call", action="store_true", help="one dd_unproject_compact call per step instead of dd_plan + dd_scatter")
+    ap.add_argument("--two-pass", action="store_true", help="dd_plan + dd_scatter per step instead of the fused single-pass call")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -266,11 +266,12 @@ def main() -> None:
 
     ev = []
     state = {"plan": None}
-    single_pass = bool(args.tuning & 8) or args.fused_call
+    single_pass = not args.two_pass
 
     def step(record: bool):
-        """One pass of the hot path: pass 1 (count + scans -> exact rows), pass 2 (the dominant
-        unproject + compact + scatter kernel).  Events bracket each pass on the launch stream."""
+        """One pass of the hot path.  Default: the fused call dd_unproject_compact (one kernel reads the
+        inputs once: cull + unproject + transform + look-back scan + compaction + write).  --two-pass:
+        dd_plan (count + scans) then dd_scatter.  Events bracket the kernels on the launch stream."""
         builder.reset()
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if record else None
         if record:
@@ -329,7 +330,7 @@ def main() -> None:
         traffic = None
         tfile = ROOT / "profiles" / "traffic.json"
         if tfile.exists():
-            rec = json.loads(tfile.read_text()).get(args.workload)
+            rec = json.loads(tfile.read_text()).get(args.workload + ("" if single_pass else ":two-pass"))
             if rec:     # PMC bytes were collected on the full workload; a launch over fewer views moves proportionally fewer
                 traffic = int(rec["hbm_bytes_per_launch"] * V / rec["views"])
         line = {
@@ -351,13 +352,15 @@ def main() -> None:
                                   + (" + pixel_index i32" if args.pixel_index else ""),
                        "fuse": "single GPU: one global scan, points written at final slots" if world == 1 else
                                "sharded: contiguous view shards + RCCL all-gather of per-view counts (global offsets)"},
-            "roofline": {"bound": "hbm", "kernel": "compact_lean (dd_scatter: cull+unproject+transform+compact+write)",
+            "roofline": {"bound": "hbm",
+                         "kernel": "compact_lean<single-pass> (dd_unproject_compact: cull+unproject+transform+scan+compact+write)"
+                                   if single_pass else "compact_lean (dd_scatter: cull+unproject+transform+compact+write)",
                          "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg,
                          "kernel_ms": round(kernel_ms, 4), "timer": "HIP events on the launch stream, mean over timed steps",
                          "pass1_ms": round(plan_ms, 4),
-                         "pass1_note": "count_lean + 2 scan kernels re-read depth+mask; not credited in algorithmic bytes",
+                         "pass1_note": "two-pass mode only: count_lean + scan kernels re-read depth+mask (not credited)",
                          "whole_step_frac": round(alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
         }
         if args.cpu_seconds > 0 and world == 1:      # reported at N=1 only, on rank 0

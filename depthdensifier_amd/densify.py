@@ -435,8 +435,8 @@ def unproject_views(depth: ArrayLike, intrinsics: ArrayLike, cam_from_world: Arr
     ``downsample_density`` is ``ProcessingConfig.downsample_density`` (``scripts/test.py:37``; the
     reference default is 32, the benchmarks use 1).  ``capacity``: ``None`` runs pass 1
     (``dd_plan``), reads the exact count, allocates exactly and runs pass 2 (``dd_scatter``);
-    ``"max"`` allocates for every visited pixel and enqueues both passes without a host round
-    trip; an int is taken as given.
+    ``"max"`` allocates for every visited pixel and runs the fused single-pass call
+    (``dd_unproject_compact``) without a host round trip; an int is taken as given.
     """
     batch = ViewBatch(depth, intrinsics, cam_from_world, mask=mask, conf=conf, conf_threshold=conf_threshold,
                       normal=normal, rgb=rgb, stride=downsample_density, semantics=semantics,
@@ -449,7 +449,7 @@ def unproject_views(depth: ArrayLike, intrinsics: ArrayLike, cam_from_world: Arr
         builder = CloudBuilder(int(plan.num_points.item()), **fields)
         builder.scatter(batch, plan)
         return builder.finish()
-    if capacity is None:
+    if capacity is None:          # single-pass kernel requested explicitly: size the cloud with a count first
         cap = int(count_valid(batch).sum().item())
     elif capacity == "max":
         cap = batch.max_points

@@ -80,7 +80,8 @@ typedef struct DDViewBatch {
     float conf_threshold;
     uint32_t flags;
     int32_t view_index_base;  /* added to the per-point view index (global view id of view 0) */
-    uint32_t tuning;          /* 0 = default; 1 = force the scalar kernels; 8 = single-pass look-back variant */
+    uint32_t tuning;          /* 0 = default; 1 = force the scalar kernels; 4 / 8 = dd_unproject_compact as
+                                 plan + scatter / as the single-pass look-back kernel (default on aligned maps) */
 } DDViewBatch;
 
 /*
@@ -133,15 +134,16 @@ int dd_scatter(const DDViewBatch *batch, const DDCloudOut *out, const int64_t *v
                void *workspace, int64_t workspace_bytes, void *stream);
 
 /*
- * The whole hot path for one batch, appended to the cloud: dd_plan + dd_scatter + cursor update,
- * all enqueued on `stream` without a host round trip, so chaining calls fuses any number of
- * batches (scripts/test.py:238-240 list append + :264-266 concatenate).
+ * The whole hot path for one batch, appended to the cloud, enqueued on `stream` without a host
+ * round trip, so chaining calls fuses any number of batches (scripts/test.py:238-240 list append +
+ * :264-266 concatenate).  On aligned stride-1 maps this is ONE pass over the inputs (ticket +
+ * decoupled look-back inside the kernel); otherwise dd_plan + dd_scatter.  Same rows either way.
  *
  *  cursor_dev       (1) int64, device, in/out: advanced by the batch's number of points.
  *  view_offsets_dev (V+1) int64, device, out.
- *  workspace        as above.  With tuning bit 8 (single-pass look-back variant)
- *                   ((int32_t*)workspace)[1] != 0 after the stream has drained means the
- *                   in-kernel scan gave up (should never happen).
+ *  workspace        as above.  ((int32_t*)workspace)[1] != 0 after the stream has drained means the
+ *                   in-kernel look-back gave up after ~2 s of polling (should never happen; rows
+ *                   are then invalid -- redo the batch with tuning = 4).
  */
 int dd_unproject_compact(const DDViewBatch *batch, const DDCloudOut *out,
                          int64_t *view_offsets_dev, int64_t *cursor_dev,

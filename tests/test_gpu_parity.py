@@ -75,8 +75,9 @@ def _inputs(g, c):
 
 # ------------------------------------------------------------------ reference goldens
 
-# tuning words: 0 = default (lean two-pass kernels on aligned maps), 1 = generic scalar kernels,
-# 8 = single-pass look-back variant of the lean kernel, 9 = single-pass generic kernel
+# tuning words: 0 = default, 1 = generic scalar kernels, 4 = force plan + scatter in the fused call,
+# 8 = single-pass look-back kernel (the fused call's default on aligned maps), 9 = single-pass generic kernel.
+# With capacity=None the host layer uses dd_plan + dd_scatter unless bit 8 asks for the single-pass kernel.
 TUNINGS = (0, 1, 8, 9)
 
 
@@ -352,7 +353,7 @@ def test_full_size_1080p_properties_and_oracle_sample(dd, orc):
     dsel = depth[v].reshape(-1).cpu().numpy()[pix[offs[v]:offs[v + 1]]]
     assert np.abs(cam[:, 2] - dsel).max() < 1e-4 * 12
     # idempotence: a second run is bit-identical; so are the single-pass and the scalar kernels
-    for tuning in (0, 8, 1):
+    for tuning in (0, 4, 8, 1):     # fused call: single-pass (default), forced two-pass, explicit single-pass, scalar
         again = dd.unproject_views(depth, params, E, mask=mask, normal=normal, rgb=rgb, view_index=True,
                                    capacity="max", tuning=tuning)
         assert torch.equal(again.points, cloud.points) and torch.equal(again.colors, cloud.colors)
