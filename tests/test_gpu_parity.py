@@ -449,3 +449,8 @@ def test_offsets_beyond_32_bits(dd, orc):
         assert torch.all(cloud.view_index[sl] == v)
         assert np.array_equal(cloud.colors[sl].cpu().numpy(), ref["colors"])
         assert_xyz(cloud.points[sl].double().cpu().numpy(), ref["points"], scene_radius(E, np.array([8.0])))
+    # the fused single-pass call (ticket + look-back over ~81 000 tiles) gives the same rows, bit for bit
+    fused = dd.unproject_views(depth, params, E, mask=mask, rgb=rgb, view_index=True, capacity=len(cloud) + 12345)
+    assert torch.equal(fused.view_offsets, cloud.view_offsets) and torch.equal(fused.points, cloud.points)
+    assert torch.equal(fused.colors, cloud.colors) and torch.equal(fused.pixel_index, cloud.pixel_index)
+    assert torch.equal(fused.view_index, cloud.view_index)
