@@ -454,3 +454,23 @@ def test_offsets_beyond_32_bits(dd, orc):
     assert torch.equal(fused.view_offsets, cloud.view_offsets) and torch.equal(fused.points, cloud.points)
     assert torch.equal(fused.colors, cloud.colors) and torch.equal(fused.pixel_index, cloud.pixel_index)
     assert torch.equal(fused.view_index, cloud.view_index)
+
+
+def test_c_abi_client_without_python(tmp_path):
+    """A C++/HIP program linking libddcore.so (no torch, no Python in the loop) drives dd_plan + dd_scatter and
+    the fused call and checks them against its own float64 loop (tests/c_client/abi_client.cpp)."""
+    import shutil, subprocess
+    from pathlib import Path
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "abi_client"
+    lib_dir = root / "depthdensifier_amd"
+    build = subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", f"-I{root / 'include'}",
+                            str(root / "tests" / "c_client" / "abi_client.cpp"), f"-L{lib_dir}", "-lddcore",
+                            f"-Wl,-rpath,{lib_dir}", "-o", str(exe)], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and "C ABI OK" in run.stdout, run.stdout + run.stderr
