@@ -182,7 +182,7 @@ def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="garden185", choices=sorted(WORKLOADS))
     ap.add_argument("--views", type=int, default=0, help="override views per GPU (garden185) / total views (scene2000)")
     ap.add_argument("--pixel-index", action="store_true", help="also emit the int32 pixel index per point")
@@ -316,6 +316,8 @@ def main() -> None:
     cloud = builder.finish()
     assert len(cloud) == n_local
     n_total = int(goffs[-1].item())
+    if os.environ.get("DD_BENCH_TRACE_STEPS") and rank == 0:      # per-step kernel times (diagnostic)
+        print("steps_ms", [round(e[0].elapsed_time(e[2]), 3) for e in ev], file=sys.stderr)
     plan_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     kernel_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) if not single_pass else plan_ms
     if single_pass:
