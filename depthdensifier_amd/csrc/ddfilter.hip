@@ -19,6 +19,13 @@
 
 #include "ddcore.h"
 
+#ifndef DD_VOTES_FAST
+#define DD_VOTES_FAST 1      // filtered predicates (identical decisions, fewer f64 divisions); 0 = always exact
+#endif
+#ifndef DD_VOTES_STAGE
+#define DD_VOTES_STAGE 0     // diagnostic builds stop after stage 1 (depth sign), 2 (bounds), 3 (grazing)
+#endif
+
 namespace {
 
 struct FArgs {
@@ -48,20 +55,67 @@ __global__ __launch_bounds__(256) void floater_votes_kernel(const FArgs a) {
         // scripts/test.py:63-68  camera-frame point and depth
         const double zc = c[8] * x + c[9] * y + c[10] * z + c[11];
         if (!(zc > 0.0)) continue;                           // :301 depths > 0
+#if DD_VOTES_STAGE == 1
+        ++votes; continue;
+#endif
         const double xc = c[0] * x + c[1] * y + c[2] * z + c[3];
         const double yc = c[4] * x + c[5] * y + c[6] * z + c[7];
-        // :71-75  normalise by (depth + 1e-8), apply K
+        // :71-75  normalise by (depth + 1e-8), apply K.  Filtered predicate: the decisions below depend on u, w
+        // only through comparisons with integers (image bounds, truncation to a pixel), so a cheaper
+        // evaluation (one reciprocal instead of three divisions; error ~1e-15 relative) decides whenever
+        // it is farther than 1e-9 from every integer; inside that band the exact formulation is used.
         const double den = zc + 1e-8;
-        const double xn = xc / den, yn = yc / den, zn = zc / den;
-        const double u = c[12] * xn + c[13] * yn + c[14] * zn;
-        const double w = c[15] * xn + c[16] * yn + c[17] * zn;
+        double u, w;
+#if DD_VOTES_FAST
+        {
+            const double rden = 1.0 / den;
+            const double xf = xc * rden, yf = yc * rden, zf = zc * rden;
+            u = c[12] * xf + c[13] * yf + c[14] * zf;
+            w = c[15] * xf + c[16] * yf + c[17] * zf;
+            const double gu = 1e-9 * (fabs(u) + 1.0), gw = 1e-9 * (fabs(w) + 1.0);
+            const bool safe = fabs(u - rint(u)) > gu && fabs(w - rint(w)) > gw && fabs(u) < 1e12 && fabs(w) < 1e12;
+            if (!safe) {
+                const double xn = xc / den, yn = yc / den, zn = zc / den;
+                u = c[12] * xn + c[13] * yn + c[14] * zn;
+                w = c[15] * xn + c[16] * yn + c[17] * zn;
+            }
+        }
+#else
+        {
+            const double xn = xc / den, yn = yc / den, zn = zc / den;
+            u = c[12] * xn + c[13] * yn + c[14] * zn;
+            w = c[15] * xn + c[16] * yn + c[17] * zn;
+        }
+#endif
         if (!(u >= 0.0 && u < wlim && w >= 0.0 && w < hlim)) continue;      // :300-302
-        // :284-295  grazing-angle test against the direction camera centre -> point
+#if DD_VOTES_STAGE == 2
+        ++votes; continue;
+#endif
+        // :284-295  grazing-angle test against the direction camera centre -> point.  Same idea: with
+        // d = p - centre, facing = -(n . d)/|d| > g  <=>  -(n . d) > g |d|; decided without the three
+        // divisions unless the two sides are within 1e-9 of each other.
         double dx = x - c[18], dy = y - c[19], dz = z - c[20];
         const double len = sqrt(dx * dx + dy * dy + dz * dz);
+#if DD_VOTES_FAST
+        {
+            const double t = -(nx * dx + ny * dy + nz * dz), rhs = a.grazing_cos * len;
+            const double guard = 1e-9 * (fabs(t) + fabs(rhs));
+            if (fabs(t - rhs) > guard && fabs(t) < 1e300) {
+                if (!(t > rhs)) continue;
+            } else {
+                dx /= len; dy /= len; dz /= len;
+                const double facing = nx * -dx + ny * -dy + nz * -dz;
+                if (!(facing > a.grazing_cos)) continue;
+            }
+        }
+#else
         dx /= len; dy /= len; dz /= len;
         const double facing = nx * -dx + ny * -dy + nz * -dz;
         if (!(facing > a.grazing_cos)) continue;
+#endif
+#if DD_VOTES_STAGE == 3
+        ++votes; continue;
+#endif
         // :308-312  truncating lookup of the view's (mask-zeroed) refined depth
         const long long pix = (long long)v * a.hw + (long long)(int)w * a.W + (int)u;
         float seen = a.depth[pix];

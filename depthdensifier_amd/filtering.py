@@ -73,6 +73,11 @@ def floater_votes(points: torch.Tensor, normals: torch.Tensor, depth: ArrayLike,
         m = m.view(torch.uint8) if m.dtype == torch.bool else (m > 0).view(torch.uint8)
         if m.shape != d.shape:
             raise ValueError("mask and depth shapes differ")
+    if m is not None:
+        # scripts/test.py:194 once, instead of a second gather per (point, view) pair: the cached map IS the
+        # mask-zeroed depth in the reference (:197-201)
+        d = torch.where(m.bool(), d, torch.zeros((), dtype=d.dtype, device=dev))
+        m = None
     cams = torch.from_numpy(filter_cameras(intrinsics, cam_from_world)).to(dev)
     if cams.shape[0] != d.shape[0]:
         raise ValueError(f"{cams.shape[0]} cameras for {d.shape[0]} depth maps")

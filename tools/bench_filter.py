@@ -27,6 +27,7 @@ for _ in range(2):
 pairs = len(cloud) * a.views
 print(f"points {len(cloud)/1e6:.1f} M x views {a.views} = {pairs/1e9:.2f} G pairs in {dt*1e3:.1f} ms -> {pairs/dt/1e9:.1f} Gpairs/s; "
       f"votes>=5: {(votes >= 5).float().mean().item()*100:.2f} %  max {int(votes.max())}")
+print("votes checksum", int(votes.long().sum()), int((votes.long() * (torch.arange(len(votes), device=votes.device) % 1000003)).sum()))
 if a.cpu_views:
     from oracle import filter_oracle as forc
     n = 2_000_000
