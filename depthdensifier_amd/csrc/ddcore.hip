@@ -80,7 +80,6 @@ struct KArgs {
     int sp_static;                // diagnostic: single-pass without tickets (tile = blockIdx.x)
 };
 
-using gu64 = __attribute__((address_space(1))) unsigned long long;
 
 __device__ __forceinline__ unsigned long long ld_state(unsigned long long *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

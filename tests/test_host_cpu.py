@@ -114,3 +114,17 @@ def test_no_gpu_means_loud_failure():
 def test_product_never_imports_oracle():
     for f in (ROOT / "depthdensifier_amd").rglob("*.py"):
         assert "oracle" not in f.read_text(), f
+
+
+def test_bench_byte_model_matches_survey_examples():
+    """config 3 (f32 depth + u8 mask + f32x3 normal + u8x3 rgb, rho 0.8) = 17 B read + 21.6 B
+    written per pixel; config 5 (f16 depth in, f32 xyz out, dense) = 2 + 12 B per pixel."""
+    import bench
+    P = 1920 * 1080
+    b3 = bench.algorithmic_bytes(bench.WORKLOADS["scene2000"], 1, int(0.8 * P), False) - 72
+    assert abs(b3 / P - 38.6) < 1e-6
+    P5 = 4032 * 3024
+    b5 = bench.algorithmic_bytes(bench.WORKLOADS["roofline12mp"], 1, P5, False) - 72
+    assert b5 / P5 == 14.0
+    b4 = bench.algorithmic_bytes(bench.WORKLOADS["mip360conf"], 1, int(0.425 * P), True) - 72
+    assert abs(b4 / P - (9 + 0.425 * (15 + 31))) < 1e-6
