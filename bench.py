@@ -207,6 +207,8 @@ def main() -> None:
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if os.environ.get("DD_BENCH_SHARE_GPU") == "1":      # rehearsal: every rank on cuda:0 (1-GPU box), gloo collectives
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -219,7 +221,10 @@ def main() -> None:
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=device)     # "nccl" is RCCL on ROCm
+        if os.environ.get("DD_BENCH_SHARE_GPU") == "1":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)     # "nccl" is RCCL on ROCm
 
     import depthdensifier_amd as dd
     from depthdensifier_amd import distributed as D
@@ -373,7 +378,7 @@ def main() -> None:
     # replicated fuse (the north-star all-gatherv of the per-GPU clouds), timed separately AFTER the main
     # result exists.  Doubly guarded: an exception is reported in the line; a collective that does not
     # finish within the watchdog's limit makes every rank print/exit with the main result intact.
-    if use_dist and args.gather_steps > 0:
+    if use_dist and args.gather_steps > 0 and os.environ.get("DD_BENCH_SHARE_GPU") != "1":
         import threading
 
         def bail():
