@@ -211,7 +211,7 @@ class Reconstruction:
         self._tracks: list = []                 # per original point: (T,2) int32 array
         self._idx: Optional[dict] = None
         if path is not None:
-            self.read_binary(path)
+            self.read(path)
 
     # -- queries ------------------------------------------------------------------------
     @property
@@ -237,6 +237,48 @@ class Reconstruction:
         return self.point_xyz[order[pos]]
 
     # -- reading ------------------------------------------------------------------------
+    def read(self, path: Union[str, Path]) -> None:
+        """Binary model if ``cameras.bin`` exists, else the text model (like ``pycolmap.Reconstruction(path)``)."""
+        path = Path(path)
+        if (path / "cameras.bin").exists():
+            self.read_binary(path)
+        elif (path / "cameras.txt").exists():
+            self.read_text(path)
+        else:
+            raise FileNotFoundError(f"{path}: neither cameras.bin nor cameras.txt found")
+
+    def read_text(self, path: Union[str, Path]) -> None:
+        """COLMAP text model: ``cameras.txt`` (ID MODEL W H PARAMS...), ``images.txt`` (two lines per image:
+        ID QW QX QY QZ TX TY TZ CAMERA_ID NAME / X Y POINT3D_ID ...), ``points3D.txt`` (ID X Y Z R G B ERROR TRACK...)."""
+        path = Path(path)
+        rows = lambda f: [ln for ln in (path / f).read_text().splitlines() if ln.strip() and not ln.startswith("#")]
+        self.cameras = {}
+        for ln in rows("cameras.txt"):
+            t = ln.split()
+            if t[1] not in _MODEL_IDS:
+                raise ValueError(f"cameras.txt: unknown camera model {t[1]}")
+            self.cameras[int(t[0])] = Camera(int(t[0]), _MODEL_IDS[t[1]], int(t[2]), int(t[3]), np.array(t[4:], dtype=np.float64))
+        self.images = {}
+        lines = [ln for ln in (path / "images.txt").read_text().splitlines() if not ln.startswith("#")]
+        lines = lines[next((i for i, ln in enumerate(lines) if ln.strip()), len(lines)):]
+        for i in range(0, len(lines) - 1, 2):
+            head = lines[i].split()
+            if len(head) < 10:
+                continue
+            obs = np.array(lines[i + 1].split(), dtype=np.float64).reshape(-1, 3) if lines[i + 1].strip() else np.zeros((0, 3))
+            self.images[int(head[0])] = Image(int(head[0]), np.array(head[1:5], dtype=np.float64), np.array(head[5:8], dtype=np.float64),
+                                              int(head[8]), " ".join(head[9:]), obs[:, :2].copy(), obs[:, 2].astype(np.int64))
+        ids, xyz, rgb, err, tracks = [], [], [], [], []
+        for ln in rows("points3D.txt"):
+            t = ln.split()
+            ids.append(int(t[0])); xyz.append([float(v) for v in t[1:4]]); rgb.append([int(v) for v in t[4:7]]); err.append(float(t[7]))
+            tracks.append(np.array(t[8:], dtype=np.int32).reshape(-1, 2))
+        self.point_ids = np.array(ids, dtype=np.uint64)
+        self.point_xyz = np.array(xyz, dtype=np.float64).reshape(-1, 3)
+        self.point_rgb = np.array(rgb, dtype=np.uint8).reshape(-1, 3)
+        self.point_error = np.array(err, dtype=np.float64)
+        self._tracks, self._idx = tracks, None
+
     def read_binary(self, path: Union[str, Path]) -> None:
         path = Path(path)
         self._read_cameras(path / "cameras.bin")
@@ -353,10 +395,10 @@ class Reconstruction:
 
 
 def load_colmap_model(model_path: Union[str, Path]) -> Reconstruction:
-    """``src/depthdensifier/utils.py:10-51``: a directory holding the three ``.bin`` files."""
+    """``src/depthdensifier/utils.py:10-51``: a model directory (binary or text files)."""
     p = Path(model_path)
     if not p.is_dir():
-        raise ValueError(f"{p}: expected a COLMAP model directory (cameras.bin, images.bin, points3D.bin)")
+        raise ValueError(f"{p}: expected a COLMAP model directory (cameras/images/points3D .bin or .txt)")
     return Reconstruction(p)
 
 

@@ -136,3 +136,34 @@ def test_pipeline_end_to_end_on_gpu(tmp_path):
     assert (votes >= 2).sum() > 20                                       # the injected floaters are caught
     assert len(dense) == len(ep)
     assert np.array_equal(dense.astype(np.float32), ep) and np.array_equal(out.point_rgb[n_sparse:], ec)
+
+
+def test_colmap_text_model(tmp_path):
+    """The text flavour of a COLMAP model reads to the same reconstruction as its binary twin."""
+    from depthdensifier_amd.colmap_io import CAMERA_MODELS, Reconstruction, load_colmap_model
+    from scan_factory import make_scan
+    scan, _, _ = make_scan(tmp_path, "s", V=2)
+    b = Reconstruction(scan / "sparse" / "0")
+    t = tmp_path / "txt"; t.mkdir()
+    with open(t / "cameras.txt", "w") as f:
+        f.write("# Camera list\n")
+        for c in b.cameras.values():
+            f.write(f"{c.camera_id} {CAMERA_MODELS[c.model_id][0]} {c.width} {c.height} " + " ".join(repr(float(p)) for p in c.params) + "\n")
+    with open(t / "images.txt", "w") as f:
+        f.write("# Image list with two lines of data per image\n")
+        for im in b.images.values():
+            f.write(f"{im.image_id} " + " ".join(repr(float(v)) for v in [*im.qvec, *im.tvec]) + f" {im.camera_id} {im.name}\n")
+            f.write(" ".join(f"{repr(float(x))} {repr(float(y))} {int(p)}" for (x, y), p in zip(im.xys, im.point3D_ids)) + "\n")
+    with open(t / "points3D.txt", "w") as f:
+        for i, pid in enumerate(b.point_ids):
+            f.write(f"{int(pid)} " + " ".join(repr(float(v)) for v in b.point_xyz[i]) + " " + " ".join(str(int(v)) for v in b.point_rgb[i])
+                    + f" {repr(float(b.point_error[i]))}\n")
+    r = load_colmap_model(t)
+    assert np.array_equal(r.point_ids, b.point_ids) and np.array_equal(r.point_xyz, b.point_xyz) and np.array_equal(r.point_rgb, b.point_rgb)
+    assert set(r.images) == set(b.images)
+    for k in b.images:
+        assert r.images[k].name == b.images[k].name and np.array_equal(r.images[k].qvec, b.images[k].qvec)
+        assert np.array_equal(r.images[k].point3D_ids, b.images[k].point3D_ids) and np.array_equal(r.images[k].xys, b.images[k].xys)
+    assert np.array_equal(r.cameras[1].params, b.cameras[1].params) and r.cameras[1].model_name == "PINHOLE"
+    with pytest.raises(FileNotFoundError):
+        Reconstruction(tmp_path)
