@@ -433,10 +433,10 @@ def unproject_views(depth: ArrayLike, intrinsics: ArrayLike, cam_from_world: Arr
     """Densify + fuse a stack of views: ``scripts/test.py:203-244`` per view and ``:262-266``.
 
     ``downsample_density`` is ``ProcessingConfig.downsample_density`` (``scripts/test.py:37``; the
-    reference default is 32, the benchmarks use 1).  ``capacity``: ``None`` runs pass 1
-    (``dd_plan``), reads the exact count, allocates exactly and runs pass 2 (``dd_scatter``);
-    ``"max"`` allocates for every visited pixel and runs the fused single-pass call
-    (``dd_unproject_compact``) without a host round trip; an int is taken as given.
+    reference default is 32, the benchmarks use 1).  ``capacity``: ``None`` counts the valid pixels
+    (``dd_count_valid``, one streaming read of depth/mask), allocates exactly and runs the fused
+    call ``dd_unproject_compact``; ``"max"`` allocates for every visited pixel and skips the count
+    (no host round trip); an int is taken as given.  ``tuning=4`` uses ``dd_plan`` + ``dd_scatter``.
     """
     batch = ViewBatch(depth, intrinsics, cam_from_world, mask=mask, conf=conf, conf_threshold=conf_threshold,
                       normal=normal, rgb=rgb, stride=downsample_density, semantics=semantics,
@@ -444,12 +444,12 @@ def unproject_views(depth: ArrayLike, intrinsics: ArrayLike, cam_from_world: Arr
     with_normals = batch.normal is not None and (semantics == "script" or batch.mask is not None)
     fields = dict(normals=with_normals, colors=batch.rgb is not None, pixel_index=pixel_index,
                   view_index=view_index, device=batch.device)
-    if capacity is None and not (tuning & 8):
+    if capacity is None and (tuning & 4):        # forced two-pass: the plan's offsets feed the scatter directly
         plan = plan_batch(batch)
         builder = CloudBuilder(int(plan.num_points.item()), **fields)
         builder.scatter(batch, plan)
         return builder.finish()
-    if capacity is None:          # single-pass kernel requested explicitly: size the cloud with a count first
+    if capacity is None:          # exact allocation: one counting pass, then the fused single-pass call
         cap = int(count_valid(batch).sum().item())
     elif capacity == "max":
         cap = batch.max_points

@@ -27,7 +27,7 @@ def _case(seed):
         use_mask=bool(rng.uniform() < 0.7), use_conf=bool(rng.uniform() < 0.3),
         conf_dtype=np.float16 if rng.uniform() < 0.5 else np.float32,
         use_normal=bool(rng.uniform() < 0.6), use_rgb=bool(rng.uniform() < 0.6),
-        viz=bool(rng.uniform() < 0.25), tuning=int(rng.choice([0, 0, 1, 8, 9])),
+        viz=bool(rng.uniform() < 0.25), tuning=int(rng.choice([0, 0, 1, 4, 5, 9])),
     )
     return d, opts
 
