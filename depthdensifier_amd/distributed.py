@@ -176,3 +176,30 @@ def gather_cloud(sharded: ShardedCloud, group=None, out: Optional[dict] = None):
     return FusedCloud(points=g("points", loc.points), colors=g("colors", loc.colors), normals=g("normals", loc.normals),
                       pixel_index=g("pixel_index", loc.pixel_index), view_index=g("view_index", view_index),
                       view_offsets=sharded.view_offsets, name=loc.name)
+
+
+def allgather_views(local: torch.Tensor, num_views_total: int, group=None) -> torch.Tensor:
+    """Every rank's per-view stack (depth / mask / camera blocks ..., views along dim 0, sharded with
+    ``shard_views``) gathered into the full ``(num_views_total, ...)`` stack on every rank."""
+    world = dist.get_world_size(group)
+    return allgatherv_rows(local.contiguous(), shard_sizes(num_views_total, world), group=group)
+
+
+def filter_floaters_sharded(local_cloud, local_depth: torch.Tensor, local_intrinsics, local_cam_from_world,
+                            num_views_total: int, local_mask: Optional[torch.Tensor] = None, config=None, group=None):
+    """The multi-view filter on a sharded cloud: the depth maps and cameras of ALL views are
+    all-gathered (2000 x 1080p = 16.6 GB, small next to 288 GB of HBM), then every rank votes on and compacts
+    its own slice of the points -- the O(N*V) work splits by points, no point ever moves."""
+    import numpy as np
+    from .densify import intrinsics_matrix
+    from .filtering import filter_floaters
+
+    dev = local_depth.device
+    depth = allgather_views(local_depth, num_views_total, group)
+    mask = None if local_mask is None else allgather_views(local_mask.view(torch.uint8) if local_mask.dtype == torch.bool
+                                                           else local_mask, num_views_total, group)
+    K = torch.from_numpy(intrinsics_matrix(local_intrinsics)).to(dev)
+    E = torch.as_tensor(np.asarray(local_cam_from_world, dtype=np.float64)).to(dev)
+    K_all = allgather_views(K, num_views_total, group).cpu().numpy()
+    E_all = allgather_views(E, num_views_total, group).cpu().numpy()
+    return filter_floaters(local_cloud, depth, K_all, E_all, mask=mask, config=config)

@@ -66,6 +66,11 @@ def main():
     assert np.array_equal(fused.normals.numpy(), full.normals)
     assert np.array_equal(fused.pixel_index.numpy(), full.pixel_index.astype(np.int32))
     assert np.array_equal(fused.view_index.numpy(), full.view_index.astype(np.int32))
+    # per-view stacks (what the sharded filter all-gathers): every rank ends with all views, in view order
+    depth_all = D.allgather_views(torch.from_numpy(d["depth"][lo:hi].astype(np.float32)), V)
+    assert np.array_equal(depth_all.numpy(), d["depth"].astype(np.float32), equal_nan=True)
+    E_all = D.allgather_views(torch.from_numpy(d["cam_from_world"][lo:hi]), V)
+    assert np.array_equal(E_all.numpy(), d["cam_from_world"])
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {a.rank}/{a.world}: ok, {len(local)} local of {len(full.points)} points")
