@@ -178,6 +178,44 @@ def _timed_gather(D, dd, dist, cloud, cfg, args, step, fence, total_views, n_tot
 
 # ------------------------------------------------------------------------------ main
 
+_GUARD_SRC = r"""
+import signal, sys
+for s in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+    signal.signal(s, signal.SIG_IGN)
+data = sys.stdin.buffer.read()                      # returns when rank 0 closes the pipe -- or dies
+if data and not data.endswith(b"\0DONE"):
+    sys.stdout.buffer.write(data.split(b"\0")[0]); sys.stdout.buffer.flush()
+"""
+
+
+def _claim_stdout():
+    """stdout is reserved for the ONE result line: whatever a library prints to fd 1 (RCCL's version banner
+    on the GPU boxes, for one) is sent to stderr; the returned file is the real stdout."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
+
+
+def _spawn_line_guard(real_out):
+    """A GPU-less child that holds rank 0's finished main result while the (separately timed) all-gatherv
+    leg runs and prints it only if rank 0 dies without printing -- so stdout carries exactly one JSON
+    line whatever RCCL does.  Own session + ignored SIGTERM: it outlives torchrun's clean-up of a failed job."""
+    import subprocess
+    return subprocess.Popen([sys.executable, "-c", _GUARD_SRC], stdin=subprocess.PIPE, stdout=real_out, start_new_session=True)
+
+
+def _release_line_guard(guard) -> None:
+    if guard is None:
+        return
+    try:
+        guard.stdin.write(b"\0DONE")
+        guard.stdin.close()
+        guard.wait(timeout=10)
+    except Exception:      # noqa: BLE001
+        pass
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,6 +243,10 @@ def main() -> None:
             sys.exit("bench.py --gpus N>1 must be launched with: python -m torch.distributed.run --nnodes=1 "
                      "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         args.gpus = world
+    real_out = _claim_stdout()
+    guard = None
+    if rank == 0 and args.gather_steps > 0 and (world > 1 or os.environ.get("DD_BENCH_FORCE_DIST") == "1"):
+        guard = _spawn_line_guard(real_out)      # before anything touches the GPU
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
     if os.environ.get("DD_BENCH_SHARE_GPU") == "1":      # rehearsal: every rank on cuda:0 (1-GPU box), gloo collectives
@@ -384,8 +426,16 @@ def main() -> None:
         def bail():
             if rank == 0:
                 line["gathered"] = {"error": f"all-gatherv leg did not finish within {args.gather_timeout:.0f} s"}
-                print(json.dumps(line), flush=True)
+                print(json.dumps(line), file=real_out, flush=True)
+                _release_line_guard(guard)
             os._exit(0)
+
+        if guard is not None:       # from here on a hard crash of rank 0 still leaves the main result on stdout
+            held = dict(line, gathered={"error": "rank 0 died inside the all-gatherv leg (main result printed by the guard process)"})
+            guard.stdin.write((json.dumps(held) + "\n").encode())
+            guard.stdin.flush()
+        if os.environ.get("DD_BENCH_TEST_ABORT") == "1":      # test hook for the guard
+            os.abort()
 
         dog = threading.Timer(args.gather_timeout, bail)
         dog.daemon = True
@@ -398,7 +448,8 @@ def main() -> None:
         if rank == 0:
             line["gathered"] = gathered
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=real_out, flush=True)
+        _release_line_guard(guard)
 
     if use_dist:
         dist.barrier()
