@@ -21,7 +21,12 @@ import torch
 
 
 class DepthSource:
-    def infer(self, image_name: str, rgb_u8: np.ndarray, device: torch.device) -> dict:
+    def prepare(self, image_name: str, rgb_u8: np.ndarray):
+        """Optional host-side stage (file reads, decoding) that the pipeline may run ahead on an I/O thread;
+        whatever it returns is handed to ``infer`` as ``prepared``.  Must not touch the GPU."""
+        return None
+
+    def infer(self, image_name: str, rgb_u8: np.ndarray, device: torch.device, prepared=None) -> dict:
         """``{'depth': (H,W) float, 'normal': (H,W,3) float32 | None, 'mask': (H,W) bool}`` on ``device``."""
         raise NotImplementedError
 
@@ -31,7 +36,7 @@ class MoGeSource(DepthSource):
         from moge.model.v2 import MoGeModel          # scripts/test.py:4
         self.model = MoGeModel.from_pretrained(checkpoint).to(device).eval()     # :104-105
 
-    def infer(self, image_name, rgb_u8, device):
+    def infer(self, image_name, rgb_u8, device, prepared=None):
         x = torch.from_numpy(rgb_u8).to(device).permute(2, 0, 1).unsqueeze(0).float() / 255.0   # :154-155
         with torch.no_grad():
             out = self.model.infer(x)                # :161-162
@@ -45,15 +50,21 @@ class CachedSource(DepthSource):
         if not self.dir.is_dir():
             raise FileNotFoundError(f"depth cache directory not found: {self.dir}")
 
-    def infer(self, image_name, rgb_u8, device):
+    def prepare(self, image_name, rgb_u8):
         f = self.dir / (Path(image_name).stem + ".npz")
         if not f.exists():
             raise FileNotFoundError(f"no cached depth for {image_name}: {f}")
-        z = np.load(f)
+        with np.load(f) as z:
+            maps = {k: z[k] for k in ("depth", "mask", "normal") if k in z.files}
         h, w = rgb_u8.shape[:2]
-        if z["depth"].shape != (h, w):
-            raise ValueError(f"{f}: depth is {z['depth'].shape}, image at processing resolution is {(h, w)}")
-        g = lambda k: torch.from_numpy(z[k]).to(device) if k in z.files else None
+        if maps["depth"].shape != (h, w):
+            raise ValueError(f"{f}: depth is {maps['depth'].shape}, image at processing resolution is {(h, w)}")
+        return maps
+
+    def infer(self, image_name, rgb_u8, device, prepared=None):
+        maps = prepared if prepared is not None else self.prepare(image_name, rgb_u8)
+        h, w = rgb_u8.shape[:2]
+        g = lambda k: torch.from_numpy(maps[k]).to(device) if k in maps else None
         mask = g("mask")
         return {"depth": g("depth"), "normal": g("normal"),
                 "mask": mask.bool() if mask is not None else torch.ones((h, w), dtype=torch.bool, device=device)}

@@ -13,6 +13,8 @@ from __future__ import annotations
 
 import dataclasses
 import time
+from collections import deque
+from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
 from pathlib import Path
 from typing import Optional
@@ -50,6 +52,8 @@ class ProcessingConfig:
     """Factor to downsample images before processing. Larger is faster."""
     downsample_density: int = 32
     """Controls final point cloud density (1=densest)."""
+    io_threads: int = 4
+    """Host threads that decode images / read cached maps ahead of the GPU (0 = inline, like the reference)."""
 
 
 @dataclass
@@ -102,15 +106,32 @@ def main(config: ScriptConfig) -> dict:
         capacity += (-(-(cam.height // f) // s)) * (-(-(cam.width // f) // s))
     builder = CloudBuilder(capacity, normals=True, colors=True, pixel_index=False, device=device)
     cached = []                                                                 # :128 cached_refinement_data
+    stage = {"image_decode": 0.0, "depth_source": 0.0, "refine": 0.0, "densify": 0.0}     # host seconds per stage
+    clock = time.perf_counter
+    todo = [im for im in image_list if len(im.observed_point3D_ids()) > 0]      # :135-137
+
+    def fetch(im):                                                              # host-only: safe on an I/O thread
+        rgb = _load_rgb(config.paths.image_dir / im.name, f)                    # :145-152
+        return rgb, source.prepare(im.name, rgb)
+
+    # decode / cache reads run `depth` views ahead of the GPU on a small pool; order of consumption is unchanged
+    pool = ThreadPoolExecutor(max_workers=config.processing.io_threads) if config.processing.io_threads > 0 else None
+    ahead = 2 * config.processing.io_threads
+    pending: deque = deque(pool.submit(fetch, im) for im in todo[:ahead]) if pool else deque()
     t_loop = time.time()
-    for image in image_list:
-        ids = image.observed_point3D_ids()                                      # :135
-        if len(ids) == 0:
-            continue                                                            # :136-137
-        pts_world = rec.xyz_of(ids)                                             # :139
-        rgb = _load_rgb(config.paths.image_dir / image.name, f)                 # :145-152
+    for k, image in enumerate(todo):
+        pts_world = rec.xyz_of(image.observed_point3D_ids())                    # :139
+        t1 = clock()
+        if pool:
+            rgb, prepared = pending.popleft().result()
+            if k + ahead < len(todo):
+                pending.append(pool.submit(fetch, todo[k + ahead]))
+        else:
+            rgb, prepared = fetch(image)
         new_h, new_w = rgb.shape[:2]
-        maps = source.infer(image.name, rgb, device)                            # :161-168, stays on device
+        t2 = clock()
+        maps = source.infer(image.name, rgb, device, prepared=prepared)         # :161-168, stays on device
+        t3 = clock()
         camera = rec.cameras[image.camera_id]
         camera.rescale(new_width=new_w, new_height=new_h)                       # :172-173 (in place, like the reference)
         E = image.cam_from_world().matrix()[:3, :]                              # :177
@@ -123,6 +144,7 @@ def main(config: ScriptConfig) -> dict:
         res = refiner.refine_depth(depth_map=maps["depth"], normal_map=normal, points3D=pts_world, cam_from_world=E, K=K,
                                    mask=maps["mask"], return_tensor=True)        # :179-186
         refined = res["refined_depth"]
+        t4 = clock()
         # depth > 0 on the whole mask is guaranteed only for an un-smoothed refinement: early exits hand back
         # the raw map (depth_refiner.py:259-299) and the 3x3 median can zero an isolated masked pixel (:194-203)
         was_refined = "outliers_removed" in res and refiner.skip_smoothing
@@ -134,9 +156,14 @@ def main(config: ScriptConfig) -> dict:
                           stride=s, view_index_base=len(cached), device=device, depth_positive_on_mask=was_refined)
         builder.append(batch)
         cached.append(dict(depth=refined, mask=maps["mask"], K=K, E=E))         # :197-201
+        t5 = clock()
+        stage["image_decode"] += t2 - t1; stage["depth_source"] += t3 - t2
+        stage["refine"] += t4 - t3; stage["densify"] += t5 - t4                  # refine syncs (scale_factor), densify only enqueues
+    if pool:
+        pool.shutdown(wait=False, cancel_futures=True)
     print(f"-> Image processing loop finished in {time.time() - t_loop:.2f}s.")
 
-    report = {"views": len(cached), "dense_points": 0, "removed": 0}
+    report = {"views": len(cached), "dense_points": 0, "removed": 0, "timings": stage}
     if not cached:
         print("No dense points were generated. Skipping save.")                 # :366-367
         return report
@@ -163,6 +190,7 @@ def main(config: ScriptConfig) -> dict:
     removed = len(cloud) - len(kept)
     print(f"-> Filtering removed {removed} points ({removed / len(cloud) * 100:.2f}%)")
     print(f"-> Filtering finished in {time.time() - t0:.2f}s.")
+    stage["filter"] = time.time() - t0
 
     t0 = time.time()
     print(f"Adding {len(points)} new dense points...")
@@ -171,6 +199,8 @@ def main(config: ScriptConfig) -> dict:
     rec.write_binary(config.paths.output_model_dir)                             # :363
     print(f"COLMAP binary model saved to: {config.paths.output_model_dir}")
     print(f"-> COLMAP model written in {time.time() - t0:.2f}s.")
+    stage["write_model"] = time.time() - t0
+    stage["total"] = time.time() - t_total
     print(f"\nTotal script execution time: {time.time() - t_total:.2f}s")
     report.update(dense_points=len(points), removed=removed, total_points=rec.num_points3D())
     return report

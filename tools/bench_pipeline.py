@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""End-to-end `pipeline.main` on a synthetic 1080p COLMAP scan (cached depth maps): stage breakdown.
+The scan is generated into a temp dir by tests/scan_factory.py (not timed)."""
+import contextlib, io, json, sys, tempfile, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+import torch
+from scan_factory import make_scan
+from depthdensifier_amd import pipeline as P
+V = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+with tempfile.TemporaryDirectory() as tmp:
+    t0 = time.time()
+    scan, _cache, _truth = make_scan(Path(tmp), "scan", V=V, H=1080, W=1920, seed=1)
+    print(f"scan of {V} views generated in {time.time() - t0:.1f}s", flush=True)
+    for stride, nio in ((32, 0), (32, 4), (4, 4), (1, 0), (1, 4), (1, 8)):
+        cfg = P.ScriptConfig()
+        cfg.paths = P.PathsConfig(recon_path=scan / "sparse" / "0", image_dir=scan / "images", output_model_dir=Path(tmp) / f"out_s{stride}")
+        cfg.moge.cache_dir = scan / "moge_cache"
+        cfg.processing.downsample_density = stride
+        cfg.processing.pipeline_downsample_factor = 1
+        cfg.processing.io_threads = nio
+        cfg.refiner.verbose = 0
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            rep = P.main(cfg)
+        torch.cuda.synchronize()
+        t = {k: round(v, 3) for k, v in rep["timings"].items()}
+        print(json.dumps({"stride": stride, "io_threads": nio, "views": rep["views"], "dense_points": rep["dense_points"], "removed": rep["removed"], "seconds": t}), flush=True)
