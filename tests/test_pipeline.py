@@ -137,6 +137,15 @@ def test_pipeline_end_to_end_on_gpu(tmp_path):
     assert len(dense) == len(ep)
     assert np.array_equal(dense.astype(np.float32), ep) and np.array_equal(out.point_rgb[n_sparse:], ec)
 
+    # reading ahead on I/O threads (the default) changes nothing: the inline loop writes the same model
+    cfg2 = run_batch.BatchConfig(tmp_path / "scans", tmp_path / "out_inline")
+    cfg2.config = cfg.config
+    cfg2.config.processing.io_threads = 0
+    run_batch.main(cfg2)
+    for name in ("cameras.bin", "images.bin", "points3D.bin"):
+        assert (tmp_path / "out_inline" / "plane" / "sparse" / "0" / name).read_bytes() == \
+               (tmp_path / "out" / "plane" / "sparse" / "0" / name).read_bytes(), name
+
 
 def test_colmap_text_model(tmp_path):
     """The text flavour of a COLMAP model reads to the same reconstruction as its binary twin."""
