@@ -6,10 +6,17 @@ Conventions kept from the reference: a scan is a sub-directory holding ``images/
 ``<output_dir>/<scan>/sparse/0``; an exception inside one scan is reported and recorded as
 ``FAILED`` without stopping the batch; a duration table closes the run; the embedded
 ``ScriptConfig`` is shared by all scans and only its ``paths`` are replaced per scan.
+
+Multi-GPU (BASELINE config 4, "all scenes back-to-back on 8 GPUs"): launched with
+``python -m torch.distributed.run --nproc-per-node N scripts/run_batch.py ...`` every rank owns one
+GPU (``LOCAL_RANK``) and a subset of the scans -- scans are independent, so there is no data-path
+collective; the scans are dealt longest-first (by image count) to the least loaded rank, the same
+on every rank, and the per-rank outcomes are merged over a gloo group so that rank 0 prints one table.
 """
 
 from __future__ import annotations
 
+import os
 import time
 from dataclasses import dataclass, field
 from pathlib import Path
@@ -59,19 +66,52 @@ def format_report(rows: List[Tuple[str, Outcome]], total_s: float, width: int = 
     return "\n".join(lines)
 
 
+def assign_scans(jobs: List[ScanJob], world_size: int) -> List[int]:
+    """Owner rank of every job: longest scan first (image count; incomplete folders cost nothing) to the
+    least loaded rank, ties to the lower rank / earlier name -- a pure function of the folder listing."""
+    def cost(job: ScanJob) -> int:
+        return sum(1 for f in job.images.iterdir() if f.is_file()) if job.complete else 0
+
+    costs = [cost(j) for j in jobs]
+    load = [0] * world_size
+    owner = [0] * len(jobs)
+    for k in sorted(range(len(jobs)), key=lambda k: (-costs[k], jobs[k].name)):
+        r = min(range(world_size), key=lambda r: (load[r], r))
+        owner[k] = r
+        load[r] += max(costs[k], 1)
+    return owner
+
+
+def _launch_env() -> Tuple[int, int, int]:
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    return rank, int(os.environ.get("LOCAL_RANK", str(rank))), world
+
+
 def main(batch_config: BatchConfig, run_scan: Optional[Callable[[ScriptConfig], object]] = None) -> List[Tuple[str, Outcome]]:
     """Run the densification on all valid scan folders found in the root directory."""
     run_scan = run_scan or densify_scan
     started = time.time()
+    rank, local_rank, world = _launch_env()
     root = batch_config.root_dir.resolve()
     if not root.is_dir():
         print(f"Error: Root directory not found at {root}")
         return []
     jobs = list(discover_scans(root, batch_config.output_dir))
     print(f"Found {len(jobs)} potential scan folders in {root}.")
+    owner = assign_scans(jobs, world)
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+        created_group = not dist.is_initialized()
+        if created_group:                            # control plane only (the merged report): gloo
+            dist.init_process_group("gloo")
+        print(f"[rank {rank}/{world}] owns {sum(1 for o in owner if o == rank)} of {len(jobs)} scan folders")
     outcomes: List[Tuple[str, Outcome]] = []
     shared = batch_config.config                     # one config object for the whole batch
-    for job in jobs:
+    for job in (j for j, o in zip(jobs, owner) if o == rank):
         print("\n" + "=" * 80 + f"\nProcessing scan: {job.name}\n" + "=" * 80)
         if not job.complete:
             print(f"Skipping '{job.name}': Missing 'sparse/0' or 'images' directory.")
@@ -86,5 +126,14 @@ def main(batch_config: BatchConfig, run_scan: Optional[Callable[[ScriptConfig], 
         else:
             outcomes.append((job.name, time.time() - tick))
             print(f"\nSuccessfully finished processing scan: {job.name}")
+    if world > 1:
+        gathered: List[Optional[List[Tuple[str, Outcome]]]] = [None] * world
+        dist.all_gather_object(gathered, outcomes)
+        by_name = {name: val for part in gathered for name, val in (part or [])}
+        outcomes = [(j.name, by_name[j.name]) for j in jobs if j.name in by_name]      # folder order, as on one GPU
+        if created_group:
+            dist.destroy_process_group()
+        if rank != 0:
+            return outcomes
     print(format_report(outcomes, time.time() - started))
     return outcomes

@@ -61,3 +61,61 @@ def test_balanced_contiguous_split():
         assert max(loads) <= sum(costs) / R + max(costs)
     assert shard_views_balanced([1.0] * 8, 4) == [(0, 2), (2, 4), (4, 6), (6, 8)]
     assert shard_views_balanced([], 2) == [(0, 0), (0, 0)]
+
+
+def test_batch_assignment_is_balanced_and_deterministic(tmp_path):
+    from depthdensifier_amd.batch import assign_scans, discover_scans
+    sizes = {"a": 9, "b": 1, "c": 5, "d": 4, "e": 0, "f": 3}
+    for name, n in sizes.items():
+        (tmp_path / name / "images").mkdir(parents=True)
+        if name != "e":
+            (tmp_path / name / "sparse" / "0").mkdir(parents=True)       # "e" is incomplete
+        for k in range(n):
+            (tmp_path / name / "images" / f"{k}.png").write_bytes(b"")
+    jobs = list(discover_scans(tmp_path, tmp_path / "out"))
+    owner = assign_scans(jobs, 2)
+    assert owner == assign_scans(jobs, 2) and set(owner) == {0, 1}
+    load = [sum(sizes[j.name] for j, o in zip(jobs, owner) if o == r and j.complete) for r in range(2)]
+    assert abs(load[0] - load[1]) <= 2, load                             # 9+1+.. vs 5+4+3: longest-first deals evenly
+    assert assign_scans(jobs, 1) == [0] * len(jobs)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_sharded_batch(tmp_path, world):
+    """Every complete scan runs exactly once, on the rank the assignment names; every rank ends with the same
+    merged report in folder order; a failing scan is FAILED without stopping its rank."""
+    import json
+    root, out = tmp_path / "scans", tmp_path / "out"
+    out.mkdir()
+    names = ["alpha", "beta", "broken", "delta", "empty", "gamma"]
+    for i, name in enumerate(names):
+        (root / name / "images").mkdir(parents=True)
+        if name != "empty":
+            (root / name / "sparse" / "0").mkdir(parents=True)
+        for k in range(i + 1):
+            (root / name / "images" / f"{k}.png").write_bytes(b"")
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, str(ROOT / "tests" / "batch_worker.py"), str(r), str(world), str(port), str(root), str(out)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=180)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o.decode())
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o}"
+    from depthdensifier_amd.batch import assign_scans, discover_scans
+    jobs = list(discover_scans(root, out))
+    owner = dict(zip((j.name for j in jobs), assign_scans(jobs, world)))
+    for name in ("alpha", "beta", "delta", "gamma"):
+        assert int((out / f"{name}.ran_on").read_text()) == owner[name]
+    assert not (out / "empty.ran_on").exists() and not (out / "broken.ran_on").exists()
+    reports = [json.loads((out / f"report.rank{r}.json").read_text()) for r in range(world)]
+    assert all(rep == reports[0] for rep in reports)
+    assert [n for n, _ in reports[0]] == ["alpha", "beta", "broken", "delta", "gamma"]
+    assert dict(map(tuple, reports[0]))["broken"] == "FAILED"
+    assert "Batch Processing Time Report" in outs[0] and all("Batch Processing Time Report" not in o for o in outs[1:])
