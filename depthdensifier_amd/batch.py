@@ -5,7 +5,8 @@ Conventions kept from the reference: a scan is a sub-directory holding ``images/
 ``sparse/0/``; incomplete folders are skipped with a message; the output model goes to
 ``<output_dir>/<scan>/sparse/0``; an exception inside one scan is reported and recorded as
 ``FAILED`` without stopping the batch; a duration table closes the run; the embedded
-``ScriptConfig`` is shared by all scans and only its ``paths`` are replaced per scan.
+``ScriptConfig`` is shared by all scans and only its ``paths`` are replaced per scan (plus
+``moge.cache_dir`` when it contains the placeholder ``{scan}``, e.g. ``/data/{scan}/moge_cache``).
 
 Multi-GPU (BASELINE config 4, "all scenes back-to-back on 8 GPUs"): launched with
 ``python -m torch.distributed.run --nproc-per-node N scripts/run_batch.py ...`` every rank owns one
@@ -111,12 +112,15 @@ def main(batch_config: BatchConfig, run_scan: Optional[Callable[[ScriptConfig], 
         print(f"[rank {rank}/{world}] owns {sum(1 for o in owner if o == rank)} of {len(jobs)} scan folders")
     outcomes: List[Tuple[str, Outcome]] = []
     shared = batch_config.config                     # one config object for the whole batch
+    cache_template = shared.moge.cache_dir           # may hold "{scan}": cached maps live per scan folder
     for job in (j for j, o in zip(jobs, owner) if o == rank):
         print("\n" + "=" * 80 + f"\nProcessing scan: {job.name}\n" + "=" * 80)
         if not job.complete:
             print(f"Skipping '{job.name}': Missing 'sparse/0' or 'images' directory.")
             continue
         shared.paths = PathsConfig(recon_path=job.recon, image_dir=job.images, output_model_dir=job.output_model)
+        if cache_template is not None and "{scan}" in str(cache_template):
+            shared.moge.cache_dir = Path(str(cache_template).format(scan=job.name))
         tick = time.time()
         try:
             run_scan(shared)

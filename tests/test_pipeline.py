@@ -147,6 +147,23 @@ def test_pipeline_end_to_end_on_gpu(tmp_path):
                (tmp_path / "out" / "plane" / "sparse" / "0" / name).read_bytes(), name
 
 
+def test_batch_cache_dir_placeholder(tmp_path):
+    """``moge.cache_dir`` with ``{scan}`` is resolved per scan folder; a plain path is shared as given."""
+    import run_batch
+    for name in ("a", "b"):
+        (tmp_path / "scans" / name / "images").mkdir(parents=True)
+        (tmp_path / "scans" / name / "sparse" / "0").mkdir(parents=True)
+    seen = []
+    cfg = run_batch.BatchConfig(tmp_path / "scans", tmp_path / "out")
+    cfg.config.moge.cache_dir = tmp_path / "scans" / "{scan}" / "moge_cache"
+    run_batch.main(cfg, run_scan=lambda c: seen.append((c.paths.recon_path.parent.parent.name, c.moge.cache_dir)))
+    assert seen == [("a", tmp_path / "scans" / "a" / "moge_cache"), ("b", tmp_path / "scans" / "b" / "moge_cache")]
+    seen.clear()
+    cfg.config.moge.cache_dir = tmp_path / "shared"
+    run_batch.main(cfg, run_scan=lambda c: seen.append(c.moge.cache_dir))
+    assert seen == [tmp_path / "shared"] * 2
+
+
 def test_colmap_text_model(tmp_path):
     """The text flavour of a COLMAP model reads to the same reconstruction as its binary twin."""
     from depthdensifier_amd.colmap_io import CAMERA_MODELS, Reconstruction, load_colmap_model
