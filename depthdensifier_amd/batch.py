@@ -109,6 +109,7 @@ def main(batch_config: BatchConfig, run_scan: Optional[Callable[[ScriptConfig], 
         created_group = not dist.is_initialized()
         if created_group:                            # control plane only (the merged report): gloo
             dist.init_process_group("gloo")
+        batch_config.config.processing.shard_views = False      # whole scans per rank, not views
         print(f"[rank {rank}/{world}] owns {sum(1 for o in owner if o == rank)} of {len(jobs)} scan folders")
     outcomes: List[Tuple[str, Outcome]] = []
     shared = batch_config.config                     # one config object for the whole batch

@@ -12,6 +12,7 @@ multi-view filter (``:269-335``) is ``filter_floaters``; the per-point ``add_poi
 from __future__ import annotations
 
 import dataclasses
+import os
 import time
 from collections import deque
 from concurrent.futures import ThreadPoolExecutor
@@ -54,6 +55,9 @@ class ProcessingConfig:
     """Controls final point cloud density (1=densest)."""
     io_threads: int = 4
     """Host threads that decode images / read cached maps ahead of the GPU (0 = inline, like the reference)."""
+    shard_views: bool = True
+    """Under torchrun (one process per GPU): shard this scan's views over the ranks.  The batch driver turns it
+    off because it shards by scan."""
 
 
 @dataclass
@@ -74,25 +78,117 @@ def _load_rgb(path: Path, factor: int) -> np.ndarray:
     return np.array(img)
 
 
+class _Ranks:
+    """The ranks one scan's views are sharded over: a torchrun launch (``WORLD_SIZE`` > 1) with
+    ``processing.shard_views`` on -- one process per GPU, RCCL (``DD_DIST_BACKEND=gloo`` for rehearsals)."""
+
+    def __init__(self, enabled: bool):
+        self.rank, self.world, self.created = 0, 1, False
+        if enabled and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            import torch.distributed as dist
+            self.rank, self.world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", self.rank)) % torch.cuda.device_count())
+            if not dist.is_initialized():
+                backend = os.environ.get("DD_DIST_BACKEND", "nccl")
+                extra = {"device_id": torch.device("cuda", torch.cuda.current_device())} if backend == "nccl" else {}
+                dist.init_process_group(backend, **extra)
+                self.created = True
+
+    def total(self, value: int, device) -> int:
+        """Sum of ``value`` over the ranks."""
+        if self.world == 1:
+            return int(value)
+        import torch.distributed as dist
+        t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+        dist.all_reduce(t)
+        return int(t.item())
+
+    def close(self) -> None:
+        if self.created:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def _votes_single(cloud, cached, depth_threshold):
+    """Votes of every point against every view held by this process; views of one size share a launch."""
+    votes = None
+    groups: dict = {}
+    for c in cached:
+        groups.setdefault(tuple(c["depth"].shape), []).append(c)
+    for views in groups.values():
+        votes = floater_votes(cloud.points, cloud.normals, torch.stack([c["depth"] for c in views]),
+                              np.stack([c["K"] for c in views]), np.stack([c["E"] for c in views]),
+                              mask=torch.stack([c["mask"] for c in views]), depth_threshold=depth_threshold, votes=votes)
+    return votes
+
+
+def _votes_sharded(cloud, cached, depth_threshold, ranks: _Ranks, num_views: int, device):
+    """The filter on a view-sharded scan: depth maps / masks / cameras of ALL views are all-gathered size group by
+    size group (a 185-view 1080p scan is 1.9 GB), then every rank votes on its own points -- the O(N*V) work
+    splits by points and no point moves.  Same votes as one GPU: they are counts over the same set of views."""
+    import torch.distributed as dist
+    from . import distributed as D
+
+    local_shapes = [tuple(c["depth"].shape) for c in cached]
+    parts: list = [None] * ranks.world
+    dist.all_gather_object(parts, local_shapes)                   # control plane: a few tuples per rank
+    bounds = [D.shard_views(num_views, ranks.world, r) for r in range(ranks.world)]
+    all_shapes = [shp for part in parts for shp in part]
+    votes = torch.zeros(len(cloud), dtype=torch.int32, device=device)
+    for shp in dict.fromkeys(all_shapes):                         # distinct sizes, first-seen order (same on all ranks)
+        rows = [sum(1 for k in range(lo, hi) if all_shapes[k] == shp) for lo, hi in bounds]
+        mine = [c for c in cached if tuple(c["depth"].shape) == shp]
+
+        def stacked(make, tail, dtype):
+            if mine:
+                return torch.stack([make(c) for c in mine]).contiguous()
+            return torch.empty((0,) + tail, dtype=dtype, device=device)
+
+        depth = D.allgatherv_rows(stacked(lambda c: c["depth"], shp, torch.float32), rows)
+        mask = D.allgatherv_rows(stacked(lambda c: c["mask"].view(torch.uint8), shp, torch.uint8), rows)
+        K = D.allgatherv_rows(stacked(lambda c: torch.as_tensor(c["K"], dtype=torch.float64, device=device), (3, 3), torch.float64), rows)
+        E = D.allgatherv_rows(stacked(lambda c: torch.as_tensor(c["E"], dtype=torch.float64, device=device), (3, 4), torch.float64), rows)
+        floater_votes(cloud.points, cloud.normals, depth, K.cpu().numpy(), E.cpu().numpy(), mask=mask,
+                      depth_threshold=depth_threshold, votes=votes)
+    return votes
+
+
 def main(config: ScriptConfig) -> dict:
-    """Densify one COLMAP scan; returns a small report (counts, timings)."""
+    """Densify one COLMAP scan; returns a small report (counts, timings).
+
+    Under ``torchrun`` (one process per GPU) with ``processing.shard_views`` the scan's views are sharded
+    contiguously over the ranks (``distributed.shard_views``): every rank refines and densifies its views into
+    its own cloud, the multi-view filter runs sharded by points, the surviving per-GPU clouds are fused with the
+    all-gatherv of ``distributed.gather_cloud`` (rank order = view order, so the result is the one-GPU cloud),
+    and rank 0 writes the model."""
     t_total = time.time()
     if not torch.cuda.is_available():
         raise RuntimeError("the densification core needs an AMD GPU (no CPU fallback)")
+    ranks = _Ranks(config.processing.shard_views)
     device = torch.device("cuda", torch.cuda.current_device())
+    say = print if ranks.rank == 0 else (lambda *a, **k: None)
+    try:
+        return _run(config, ranks, device, say, t_total)
+    finally:
+        ranks.close()
 
+
+def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> dict:
     t0 = time.time()
-    print(f"Loading depth source ({config.moge.cache_dir or config.moge.checkpoint})...")
+    say(f"Loading depth source ({config.moge.cache_dir or config.moge.checkpoint})...")
     source = make_depth_source(config.moge.checkpoint, config.moge.cache_dir, device)
-    print(f"-> Depth source ready in {time.time() - t0:.2f}s.")
+    say(f"-> Depth source ready in {time.time() - t0:.2f}s.")
 
     t0 = time.time()
-    print(f"Loading COLMAP reconstruction from {config.paths.recon_path}...")
+    say(f"Loading COLMAP reconstruction from {config.paths.recon_path}...")
     rec = Reconstruction(config.paths.recon_path)
-    print(f"Loaded model with {rec.num_reg_images()} images and {rec.num_points3D()} sparse points.")
-    print(f"-> COLMAP reconstruction loaded in {time.time() - t0:.2f}s.")
+    say(f"Loaded model with {rec.num_reg_images()} images and {rec.num_points3D()} sparse points.")
+    say(f"-> COLMAP reconstruction loaded in {time.time() - t0:.2f}s.")
 
     refiner_cfg = dataclasses.asdict(config.refiner)
+    if ranks.rank != 0:
+        refiner_cfg["verbose"] = 0
     refiner = DepthRefiner(**refiner_cfg)                                       # :118-119
     verbose = refiner_cfg["verbose"] > 0
     f = config.processing.pipeline_downsample_factor
@@ -100,32 +196,40 @@ def main(config: ScriptConfig) -> dict:
 
     # view order: registered images by id (pycolmap iterates an unordered map; sorted is deterministic)
     image_list = [rec.images[i] for i in sorted(rec.images) if rec.images[i].has_pose]     # :130
+    todo = [im for im in image_list if len(im.observed_point3D_ids()) > 0]      # :135-137
+    num_views = len(todo)
+    if ranks.world > 1:
+        from .distributed import shard_views
+        lo, hi = shard_views(num_views, ranks.world, ranks.rank)
+        say(f"Sharding {num_views} views over {ranks.world} GPUs (rank 0: views [{lo}, {hi})).")
+    else:
+        lo, hi = 0, num_views
+    mine = todo[lo:hi]
     capacity = 0
-    for im in image_list:
+    for im in mine:
         cam = rec.cameras[im.camera_id]
         capacity += (-(-(cam.height // f) // s)) * (-(-(cam.width // f) // s))
     builder = CloudBuilder(capacity, normals=True, colors=True, pixel_index=False, device=device)
     cached = []                                                                 # :128 cached_refinement_data
     stage = {"image_decode": 0.0, "depth_source": 0.0, "refine": 0.0, "densify": 0.0}     # host seconds per stage
     clock = time.perf_counter
-    todo = [im for im in image_list if len(im.observed_point3D_ids()) > 0]      # :135-137
 
     def fetch(im):                                                              # host-only: safe on an I/O thread
         rgb = _load_rgb(config.paths.image_dir / im.name, f)                    # :145-152
         return rgb, source.prepare(im.name, rgb)
 
-    # decode / cache reads run `depth` views ahead of the GPU on a small pool; order of consumption is unchanged
+    # decode / cache reads run `ahead` views in front of the GPU on a small pool; order of consumption is unchanged
     pool = ThreadPoolExecutor(max_workers=config.processing.io_threads) if config.processing.io_threads > 0 else None
     ahead = 2 * config.processing.io_threads
-    pending: deque = deque(pool.submit(fetch, im) for im in todo[:ahead]) if pool else deque()
+    pending: deque = deque(pool.submit(fetch, im) for im in mine[:ahead]) if pool else deque()
     t_loop = time.time()
-    for k, image in enumerate(todo):
+    for k, image in enumerate(mine):
         pts_world = rec.xyz_of(image.observed_point3D_ids())                    # :139
         t1 = clock()
         if pool:
             rgb, prepared = pending.popleft().result()
-            if k + ahead < len(todo):
-                pending.append(pool.submit(fetch, todo[k + ahead]))
+            if k + ahead < len(mine):
+                pending.append(pool.submit(fetch, mine[k + ahead]))
         else:
             rgb, prepared = fetch(image)
         new_h, new_w = rgb.shape[:2]
@@ -153,7 +257,7 @@ def main(config: ScriptConfig) -> dict:
         # :194 "refined_depth[~moge_mask] = 0" is the kernels' validity rule (mask AND depth > 0);
         # :203-240 densify + append
         batch = ViewBatch(refined, camera.pinhole_params()[None], E[None], mask=maps["mask"], normal=normal, rgb=rgb,
-                          stride=s, view_index_base=len(cached), device=device, depth_positive_on_mask=was_refined)
+                          stride=s, view_index_base=lo + len(cached), device=device, depth_positive_on_mask=was_refined)
         builder.append(batch)
         cached.append(dict(depth=refined, mask=maps["mask"], K=K, E=E))         # :197-201
         t5 = clock()
@@ -161,46 +265,46 @@ def main(config: ScriptConfig) -> dict:
         stage["refine"] += t4 - t3; stage["densify"] += t5 - t4                  # refine syncs (scale_factor), densify only enqueues
     if pool:
         pool.shutdown(wait=False, cancel_futures=True)
-    print(f"-> Image processing loop finished in {time.time() - t_loop:.2f}s.")
+    say(f"-> Image processing loop finished in {time.time() - t_loop:.2f}s.")
 
-    report = {"views": len(cached), "dense_points": 0, "removed": 0, "timings": stage}
-    if not cached:
-        print("No dense points were generated. Skipping save.")                 # :366-367
+    report = {"views": num_views, "dense_points": 0, "removed": 0, "timings": stage}
+    if num_views == 0:
+        say("No dense points were generated. Skipping save.")                   # :366-367
         return report
     cloud = builder.finish()
-    print(f"number of dense points: {len(cloud)}")                              # :244-245
-    if len(cloud) == 0:
-        print("No dense points were generated. Skipping save.")
+    n_before = ranks.total(len(cloud), device)
+    say(f"number of dense points: {n_before}")                                  # :244-245
+    if n_before == 0:
+        say("No dense points were generated. Skipping save.")
         return report
 
-    print("\n--- Filtering point cloud for geometric consistency ---")          # :270
+    say("\n--- Filtering point cloud for geometric consistency ---")            # :270
     t0 = time.time()
-    votes = None
-    groups: dict = {}
-    for c in cached:                                                            # views of one size share a launch
-        groups.setdefault(tuple(c["depth"].shape), []).append(c)
-    for views in groups.values():
-        votes = floater_votes(cloud.points, cloud.normals, torch.stack([c["depth"] for c in views]),
-                              np.stack([c["K"] for c in views]), np.stack([c["E"] for c in views]),
-                              mask=torch.stack([c["mask"] for c in views]),
-                              depth_threshold=config.filtering.depth_threshold, votes=votes)
+    if ranks.world == 1:
+        votes = _votes_single(cloud, cached, config.filtering.depth_threshold)
+    else:
+        votes = _votes_sharded(cloud, cached, config.filtering.depth_threshold, ranks, num_views, device)
     kept = compact_cloud(cloud, votes, config.filtering.vote_threshold)        # :330-332
-    points = kept.points.cpu().numpy().astype(np.float64)
-    colors = kept.colors.cpu().numpy()
-    removed = len(cloud) - len(kept)
-    print(f"-> Filtering removed {removed} points ({removed / len(cloud) * 100:.2f}%)")
-    print(f"-> Filtering finished in {time.time() - t0:.2f}s.")
+    if ranks.world > 1:                 # fuse: all-gatherv of the per-GPU clouds, rank order = view order
+        from . import distributed as D
+        kept = D.gather_cloud(D.fuse_sharded(kept, num_views))
+    removed = n_before - len(kept)
+    say(f"-> Filtering removed {removed} points ({removed / n_before * 100:.2f}%)")
+    say(f"-> Filtering finished in {time.time() - t0:.2f}s.")
     stage["filter"] = time.time() - t0
 
     t0 = time.time()
-    print(f"Adding {len(points)} new dense points...")
-    rec.add_points3D(points, colors)                                            # :355-358, bulk
-    config.paths.output_model_dir.mkdir(parents=True, exist_ok=True)
-    rec.write_binary(config.paths.output_model_dir)                             # :363
-    print(f"COLMAP binary model saved to: {config.paths.output_model_dir}")
-    print(f"-> COLMAP model written in {time.time() - t0:.2f}s.")
+    report.update(dense_points=len(kept), removed=removed, total_points=rec.num_points3D() + len(kept))
+    if ranks.rank == 0:
+        points = kept.points.cpu().numpy().astype(np.float64)
+        colors = kept.colors.cpu().numpy()
+        say(f"Adding {len(points)} new dense points...")
+        rec.add_points3D(points, colors)                                        # :355-358, bulk
+        config.paths.output_model_dir.mkdir(parents=True, exist_ok=True)
+        rec.write_binary(config.paths.output_model_dir)                         # :363
+        say(f"COLMAP binary model saved to: {config.paths.output_model_dir}")
+        say(f"-> COLMAP model written in {time.time() - t0:.2f}s.")
     stage["write_model"] = time.time() - t0
     stage["total"] = time.time() - t_total
-    print(f"\nTotal script execution time: {time.time() - t_total:.2f}s")
-    report.update(dense_points=len(points), removed=removed, total_points=rec.num_points3D())
+    say(f"\nTotal script execution time: {time.time() - t_total:.2f}s")
     return report

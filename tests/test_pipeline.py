@@ -147,6 +147,40 @@ def test_pipeline_end_to_end_on_gpu(tmp_path):
                (tmp_path / "out" / "plane" / "sparse" / "0" / name).read_bytes(), name
 
 
+@pytest.mark.gpu
+def test_view_sharded_scan_matches_single_gpu(tmp_path):
+    """``scripts/test.py`` under torchrun: 2 ranks (sharing this box's one GPU, gloo collectives) shard the views, filter
+    sharded by points, all-gatherv the surviving clouds; the model written by rank 0 equals the one-process model
+    byte for byte."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from scan_factory import make_scan
+    scan, cache, _ = make_scan(tmp_path / "scans", "plane", V=7, seed=3, floaters=0.03)
+    root = Path(__file__).resolve().parent.parent
+    args = ["--paths.recon-path", str(scan / "sparse" / "0"), "--paths.image-dir", str(scan / "images"),
+            "--moge.cache-dir", str(cache), "--processing.downsample-density", "2", "--refiner.no-use-fp16",
+            "--refiner.no-adaptive-correspondences", "--filtering.vote-threshold", "2", "--refiner.verbose", "0"]
+    one = subprocess.run([sys.executable, str(root / "scripts" / "test.py"), *args, "--paths.output-model-dir", str(tmp_path / "one")],
+                         capture_output=True, text=True, timeout=240)
+    assert one.returncode == 0, one.stdout + one.stderr
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, DD_DIST_BACKEND="gloo", DD_ALLGATHERV="broadcast")      # gloo has no CUDA send/recv
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), str(root / "scripts" / "test.py"), *args, "--paths.output-model-dir", str(tmp_path / "two")],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert two.returncode == 0, two.stdout + two.stderr
+    assert "Sharding 7 views over 2 GPUs" in two.stdout
+    for name in ("cameras.bin", "images.bin", "points3D.bin"):
+        assert (tmp_path / "one" / name).read_bytes() == (tmp_path / "two" / name).read_bytes(), name
+
+
 def test_batch_cache_dir_placeholder(tmp_path):
     """``moge.cache_dir`` with ``{scan}`` is resolved per scan folder; a plain path is shared as given."""
     import run_batch
