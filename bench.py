@@ -154,6 +154,9 @@ def cpu_baseline(cfg: dict, scene: dict, params: np.ndarray, E: np.ndarray, budg
 def _timed_gather(D, dd, dist, cloud, cfg, args, step, fence, total_views, n_total, H, W, device) -> dict:
     rec = 12 + (12 if cfg["normal"] else 0) + (3 if cfg["rgb"] else 0) + (4 if args.pixel_index else 0)
     free, _ = torch.cuda.mem_get_info(device)
+    fmin = torch.tensor([free], dtype=torch.int64, device=device)
+    dist.all_reduce(fmin, op=dist.ReduceOp.MIN)          # one decision for all ranks
+    free = int(fmin.item())
     if n_total * rec > 0.8 * free:
         return {"skipped": f"replicated cloud of {n_total * rec / 1e9:.1f} GB does not fit the free HBM ({free / 1e9:.1f} GB)"}
     sharded = D.fuse_sharded(cloud, total_views)
