@@ -208,10 +208,25 @@ class Reconstruction:
         self.point_xyz = np.zeros((0, 3), np.float64)
         self.point_rgb = np.zeros((0, 3), np.uint8)
         self.point_error = np.zeros((0,), np.float64)
-        self._tracks: list = []                 # per original point: (T,2) int32 array
+        # tracks of the first len(_track_len) points, CSR: (sum T, 2) int32 (image_id, point2D_idx) rows + lengths;
+        # points appended later (add_points3D) have empty tracks
+        self._track_flat = np.zeros((0, 2), np.int32)
+        self._track_len = np.zeros((0,), np.int64)
         self._idx: Optional[dict] = None
         if path is not None:
             self.read(path)
+
+    @property
+    def _tracks(self) -> list:
+        """Per-point (T,2) int32 arrays (a list view of the CSR storage)."""
+        cuts = np.cumsum(self._track_len)[:-1] if len(self._track_len) else []
+        return np.split(self._track_flat, cuts) if len(self._track_len) else []
+
+    @_tracks.setter
+    def _tracks(self, tracks) -> None:
+        tracks = [np.asarray(t, dtype=np.int32).reshape(-1, 2) for t in tracks]
+        self._track_len = np.array([len(t) for t in tracks], dtype=np.int64)
+        self._track_flat = np.concatenate(tracks).astype(np.int32) if tracks else np.zeros((0, 2), np.int32)
 
     # -- queries ------------------------------------------------------------------------
     @property
@@ -319,22 +334,43 @@ class Reconstruction:
             self.images[iid] = Image(iid, qt[:4].copy(), qt[4:].copy(), cam, name, o["xy"].copy(), o["pid"].copy())
 
     def _read_points(self, f: Path) -> None:
-        buf = f.read_bytes()
-        (n,), off = struct.unpack_from("<Q", buf, 0), 8
-        ids = np.empty(n, np.uint64)
-        xyz = np.empty((n, 3))
-        rgb = np.empty((n, 3), np.uint8)
-        err = np.empty(n)
-        tracks = []
-        for i in range(n):
-            ids[i] = struct.unpack_from("<Q", buf, off)[0]
-            xyz[i] = np.frombuffer(buf, "<f8", 3, off + 8)
-            rgb[i] = np.frombuffer(buf, "u1", 3, off + 32)
-            err[i], t = struct.unpack_from("<dQ", buf, off + 35)
-            off += 51
-            tracks.append(np.frombuffer(buf, "<i4", 2 * t, off).reshape(t, 2).copy())
-            off += 8 * t
-        self.point_ids, self.point_xyz, self.point_rgb, self.point_error, self._tracks = ids, xyz, rgb, err, tracks
+        """``points3D.bin``: per point a 43-byte head (id u64, xyz 3 f64, rgb 3 u8, error f64, track length u64)
+        followed by the track (8 bytes per element).  Only the walk over the record boundaries is sequential
+        (one integer per point, and it stops as soon as the rest of the file can hold no track element);
+        heads and tracks are then gathered with array operations."""
+        raw = f.read_bytes()
+        buf = np.frombuffer(raw, np.uint8)
+        n = struct.unpack_from("<Q", raw, 0)[0]
+        H = _POINT_NO_TRACK.itemsize                      # 43
+        off, size, unpack = 8, len(raw), struct.Struct("<Q").unpack_from
+        walked, left = [], n * H                          # left = bytes the remaining heads need
+        while left and size - off != left:                # records with (possibly) non-empty tracks
+            walked.append(off)
+            off += H + 8 * unpack(raw, off + H - 8)[0]
+            left -= H
+        i = len(walked)
+        starts = np.array(walked, dtype=np.int64)
+        if off + left != size:
+            raise ValueError(f"{f}: file size does not match the {n} points announced")
+        # heads of the walked records are gathered; the rest of the file (no track elements) IS a record array
+        parts = []
+        if i:
+            parts.append(buf[starts[:, None] + np.arange(H)].reshape(-1).view(_POINT_NO_TRACK))
+        if n - i:
+            parts.append(np.frombuffer(raw, _POINT_NO_TRACK, n - i, off))
+        head = np.concatenate(parts) if parts else np.zeros(0, _POINT_NO_TRACK)
+        self.point_ids = head["id"].astype(np.uint64)
+        self.point_xyz = head["xyz"].astype(np.float64).reshape(-1, 3)
+        self.point_rgb = head["rgb"].astype(np.uint8).reshape(-1, 3)
+        self.point_error = head["error"].astype(np.float64)
+        self._track_len = head["track"].astype(np.int64)
+        if int(self._track_len.sum()):
+            is_head = np.zeros(off, bool)                 # tracks live inside [8, off), between the walked heads
+            is_head[:8] = True
+            is_head[(starts[:, None] + np.arange(H)).reshape(-1)] = True
+            self._track_flat = buf[:off][~is_head].view("<i4").reshape(-1, 2).astype(np.int32)
+        else:
+            self._track_flat = np.zeros((0, 2), np.int32)
         self._idx = None
 
     # -- growing ------------------------------------------------------------------------
@@ -377,15 +413,22 @@ class Reconstruction:
                 o["xy"], o["pid"] = im.xys, im.point3D_ids
                 f.write(o.tobytes())
         with open(path / "points3D.bin", "wb") as f:
-            n_old = len(self._tracks)
+            n_old = len(self._track_len)                             # points that may carry tracks come first
             f.write(struct.pack("<Q", len(self.point_ids)))
-            for i in range(n_old):                                  # original sparse points keep their tracks
-                t = self._tracks[i]
-                f.write(struct.pack("<Q", int(self.point_ids[i])))
-                f.write(self.point_xyz[i].astype("<f8").tobytes())
-                f.write(self.point_rgb[i].tobytes())
-                f.write(struct.pack("<dQ", float(self.point_error[i]), len(t)))
-                f.write(t.astype("<i4").tobytes())
+            if n_old:                                                # heads scattered, tracks poured into the gaps
+                H = _POINT_NO_TRACK.itemsize
+                head = np.empty(n_old, _POINT_NO_TRACK)
+                head["id"], head["xyz"], head["rgb"] = self.point_ids[:n_old], self.point_xyz[:n_old], self.point_rgb[:n_old]
+                head["error"], head["track"] = self.point_error[:n_old], self._track_len
+                sizes = H + 8 * self._track_len
+                starts = np.cumsum(sizes) - sizes
+                out = np.empty(int(sizes.sum()), np.uint8)
+                at = (starts[:, None] + np.arange(H)).reshape(-1)
+                out[at] = head.view(np.uint8)
+                gaps = np.ones(len(out), bool)
+                gaps[at] = False
+                out[gaps] = np.ascontiguousarray(self._track_flat, dtype="<i4").view(np.uint8).reshape(-1)
+                out.tofile(f)
             n_new = len(self.point_ids) - n_old                      # dense points: one structured array
             if n_new:
                 rec = np.empty(n_new, _POINT_NO_TRACK)
