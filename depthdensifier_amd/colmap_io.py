@@ -247,8 +247,26 @@ class Reconstruction:
     def xyz_of(self, ids: np.ndarray) -> np.ndarray:
         """(n,3) coordinates of the given point ids (vectorised ``[rec.points3D[p].xyz for p in ids]``,
         ``scripts/test.py:139``)."""
-        order = np.argsort(self.point_ids, kind="stable")
-        pos = np.searchsorted(self.point_ids[order], np.asarray(ids, dtype=np.uint64))
+        cache = getattr(self, "_lookup", None)
+        if cache is None or cache[0] is not self.point_ids:          # id array replaced (read / add_points3D) -> rebuild
+            n = len(self.point_ids)
+            top = int(self.point_ids.max()) if n else 0
+            if top <= 8 * n + (1 << 20):                             # COLMAP ids are dense: direct table id -> row
+                table = np.full(top + 1, -1, np.int64)
+                table[self.point_ids.astype(np.int64)] = np.arange(n, dtype=np.int64)
+                cache = (self.point_ids, table, None, None)
+            else:
+                order = np.argsort(self.point_ids, kind="stable")
+                cache = (self.point_ids, None, order, self.point_ids[order])
+            self._lookup = cache
+        _, table, order, sorted_ids = cache
+        ids = np.asarray(ids)
+        if table is not None:
+            rows = table[ids.astype(np.int64)]
+            if len(rows) and rows.min() < 0:
+                raise KeyError("xyz_of: unknown point3D id")
+            return self.point_xyz[rows]
+        pos = np.searchsorted(sorted_ids, ids.astype(np.uint64))
         return self.point_xyz[order[pos]]
 
     # -- reading ------------------------------------------------------------------------
