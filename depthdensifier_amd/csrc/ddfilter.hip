@@ -43,88 +43,185 @@ struct FArgs {
     double grazing_cos;
 };
 
-__global__ __launch_bounds__(256) void floater_votes_kernel(const FArgs a) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.n) return;
-    const double x = a.xyz[3 * i], y = a.xyz[3 * i + 1], z = a.xyz[3 * i + 2];
-    const double nx = a.normal[3 * i], ny = a.normal[3 * i + 1], nz = a.normal[3 * i + 2];
-    const double wlim = (double)a.W, hlim = (double)a.H;
-    int votes = a.accumulate ? a.votes[i] : 0;
-    for (int v = 0; v < a.V; ++v) {
-        const double *c = a.cams + (size_t)v * 24;          // wave-uniform: scalar loads
-        // scripts/test.py:63-68  camera-frame point and depth
-        const double zc = c[8] * x + c[9] * y + c[10] * z + c[11];
-        if (!(zc > 0.0)) continue;                           // :301 depths > 0
+// One (point, view) pair: true when the view votes against the point.  `c` is the view's camera block.
+__device__ __forceinline__ bool pair_votes(const FArgs &a, const double *c, const int v, const double x, const double y,
+                                           const double z, const double nx, const double ny, const double nz,
+                                           const double wlim, const double hlim) {
+    // scripts/test.py:63-68  camera-frame point and depth
+    const double zc = c[8] * x + c[9] * y + c[10] * z + c[11];
+    if (!(zc > 0.0)) return false;                           // :301 depths > 0
 #if DD_VOTES_STAGE == 1
-        ++votes; continue;
+    return true;
 #endif
-        const double xc = c[0] * x + c[1] * y + c[2] * z + c[3];
-        const double yc = c[4] * x + c[5] * y + c[6] * z + c[7];
-        // :71-75  normalise by (depth + 1e-8), apply K.  Filtered predicate: the decisions below depend on u, w
-        // only through comparisons with integers (image bounds, truncation to a pixel), so a cheaper
-        // evaluation (one reciprocal instead of three divisions; error ~1e-15 relative) decides whenever
-        // it is farther than 1e-9 from every integer; inside that band the exact formulation is used.
-        const double den = zc + 1e-8;
-        double u, w;
+    const double xc = c[0] * x + c[1] * y + c[2] * z + c[3];
+    const double yc = c[4] * x + c[5] * y + c[6] * z + c[7];
+    // :71-75  normalise by (depth + 1e-8), apply K.  Filtered predicate: the decisions below depend on u, w
+    // only through comparisons with integers (image bounds, truncation to a pixel), so a cheaper
+    // evaluation (one reciprocal instead of three divisions; error ~1e-15 relative) decides whenever
+    // it is farther than 1e-9 from every integer; inside that band the exact formulation is used.
+    const double den = zc + 1e-8;
+    double u, w;
 #if DD_VOTES_FAST
-        {
-            const double rden = 1.0 / den;
-            const double xf = xc * rden, yf = yc * rden, zf = zc * rden;
-            u = c[12] * xf + c[13] * yf + c[14] * zf;
-            w = c[15] * xf + c[16] * yf + c[17] * zf;
-            const double gu = 1e-9 * (fabs(u) + 1.0), gw = 1e-9 * (fabs(w) + 1.0);
-            const bool safe = fabs(u - rint(u)) > gu && fabs(w - rint(w)) > gw && fabs(u) < 1e12 && fabs(w) < 1e12;
-            if (!safe) {
-                const double xn = xc / den, yn = yc / den, zn = zc / den;
-                u = c[12] * xn + c[13] * yn + c[14] * zn;
-                w = c[15] * xn + c[16] * yn + c[17] * zn;
-            }
-        }
-#else
-        {
+    {
+        const double rden = 1.0 / den;
+        const double xf = xc * rden, yf = yc * rden, zf = zc * rden;
+        u = c[12] * xf + c[13] * yf + c[14] * zf;
+        w = c[15] * xf + c[16] * yf + c[17] * zf;
+        const double gu = 1e-9 * (fabs(u) + 1.0), gw = 1e-9 * (fabs(w) + 1.0);
+        const bool safe = fabs(u - rint(u)) > gu && fabs(w - rint(w)) > gw && fabs(u) < 1e12 && fabs(w) < 1e12;
+        if (!safe) {
             const double xn = xc / den, yn = yc / den, zn = zc / den;
             u = c[12] * xn + c[13] * yn + c[14] * zn;
             w = c[15] * xn + c[16] * yn + c[17] * zn;
         }
-#endif
-        if (!(u >= 0.0 && u < wlim && w >= 0.0 && w < hlim)) continue;      // :300-302
-#if DD_VOTES_STAGE == 2
-        ++votes; continue;
-#endif
-        // :284-295  grazing-angle test against the direction camera centre -> point.  Same idea: with
-        // d = p - centre, facing = -(n . d)/|d| > g  <=>  -(n . d) > g |d|; decided without the three
-        // divisions unless the two sides are within 1e-9 of each other.
-        double dx = x - c[18], dy = y - c[19], dz = z - c[20];
-        const double len = sqrt(dx * dx + dy * dy + dz * dz);
-#if DD_VOTES_FAST
-        {
-            const double t = -(nx * dx + ny * dy + nz * dz), rhs = a.grazing_cos * len;
-            const double guard = 1e-9 * (fabs(t) + fabs(rhs));
-            if (fabs(t - rhs) > guard && fabs(t) < 1e300) {
-                if (!(t > rhs)) continue;
-            } else {
-                dx /= len; dy /= len; dz /= len;
-                const double facing = nx * -dx + ny * -dy + nz * -dz;
-                if (!(facing > a.grazing_cos)) continue;
-            }
-        }
+    }
 #else
-        dx /= len; dy /= len; dz /= len;
-        const double facing = nx * -dx + ny * -dy + nz * -dz;
-        if (!(facing > a.grazing_cos)) continue;
+    {
+        const double xn = xc / den, yn = yc / den, zn = zc / den;
+        u = c[12] * xn + c[13] * yn + c[14] * zn;
+        w = c[15] * xn + c[16] * yn + c[17] * zn;
+    }
+#endif
+    if (!(u >= 0.0 && u < wlim && w >= 0.0 && w < hlim)) return false;      // :300-302
+#if DD_VOTES_STAGE == 2
+    return true;
+#endif
+    // :284-295  grazing-angle test against the direction camera centre -> point.  Same idea: with
+    // d = p - centre, facing = -(n . d)/|d| > g  <=>  -(n . d) > g |d|; decided without the three
+    // divisions unless the two sides are within 1e-9 of each other.
+    double dx = x - c[18], dy = y - c[19], dz = z - c[20];
+    const double len = sqrt(dx * dx + dy * dy + dz * dz);
+#if DD_VOTES_FAST
+    {
+        const double t = -(nx * dx + ny * dy + nz * dz), rhs = a.grazing_cos * len;
+        const double guard = 1e-9 * (fabs(t) + fabs(rhs));
+        if (fabs(t - rhs) > guard && fabs(t) < 1e300) {
+            if (!(t > rhs)) return false;
+        } else {
+            dx /= len; dy /= len; dz /= len;
+            const double facing = nx * -dx + ny * -dy + nz * -dz;
+            if (!(facing > a.grazing_cos)) return false;
+        }
+    }
+#else
+    dx /= len; dy /= len; dz /= len;
+    const double facing = nx * -dx + ny * -dy + nz * -dz;
+    if (!(facing > a.grazing_cos)) return false;
 #endif
 #if DD_VOTES_STAGE == 3
-        ++votes; continue;
+    return true;
 #endif
-        // :308-312  truncating lookup of the view's (mask-zeroed) refined depth
-        const long long pix = (long long)v * a.hw + (long long)(int)w * a.W + (int)u;
-        float seen = a.depth[pix];
-        if (a.mask && a.mask[pix] == 0) seen = 0.0f;        // :194 refined_depth[~mask] = 0
-        if (!(seen > 0.0f)) continue;                        // :315
-        const float limit = a.depth_threshold * seen;        // :320 float32 product (NEP 50)
-        if (zc < (double)limit) ++votes;                     // :319-328
+    // :308-312  truncating lookup of the view's (mask-zeroed) refined depth
+    const long long pix = (long long)v * a.hw + (long long)(int)w * a.W + (int)u;
+    float seen = a.depth[pix];
+    if (a.mask && a.mask[pix] == 0) seen = 0.0f;        // :194 refined_depth[~mask] = 0
+    if (!(seen > 0.0f)) return false;                        // :315
+    const float limit = a.depth_threshold * seen;        // :320 float32 product (NEP 50)
+    return zc < (double)limit;                           // :319-328
+}
+
+#ifndef DD_VOTES_CULL
+#define DD_VOTES_CULL 0      // 1 = per-workgroup view culling (bounding sphere vs frustum).  Measured on MI355X: identical
+                             // votes but 18-23 % SLOWER on the ring scene (rejected pairs are already cheap in the exact
+                             // test and skip a whole wave at a time; the cull adds LDS-indexed view lookups + barriers)
+#endif
+
+// Can ANY point of the sphere (centre cx,cy,cz, radius r) pass "in front of the camera and inside the image" of the
+// view with camera block c?  The exact per-pair conditions (zc > 0, 0 <= u < W, 0 <= w < H with
+// u = (K0 . Pcam) / (zc + 1e-8)) are, for zc > 0, linear inequalities in the world point:
+//   zc > 0;  U.p >= 0;  (U - W Z).p - W 1e-8 < 0;  Wv.p >= 0;  (Wv - H Z).p - H 1e-8 < 0
+// (U, Wv, Z: rows K0 [R|t], K1 [R|t], [R|t]_z as 4-vectors, p = (x,y,z,1)).  A plane whose value over the whole
+// sphere has the failing sign -- with a 1e-6 relative safety margin, ten orders of magnitude above the rounding
+// of the exact evaluation -- rejects the view for every point of the workgroup.  NaN / inf anywhere compares
+// false and keeps the view, so the exact test still decides.
+__device__ __forceinline__ bool sphere_may_project(const double *c, const double cx, const double cy, const double cz,
+                                                   const double r, const double cnorm, const double wlim, const double hlim) {
+    double P[5][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double X = c[k], Y = c[4 + k], Z = c[8 + k];
+        const double U = c[12] * X + c[13] * Y + c[14] * Z, Wv = c[15] * X + c[16] * Y + c[17] * Z;
+        P[0][k] = Z; P[1][k] = U; P[2][k] = U - wlim * Z; P[3][k] = Wv; P[4][k] = Wv - hlim * Z;
     }
+    P[2][3] -= wlim * 1e-8;
+    P[4][3] -= hlim * 1e-8;
+    bool out = false;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const double an = sqrt(P[k][0] * P[k][0] + P[k][1] * P[k][1] + P[k][2] * P[k][2]);
+        const double f = P[k][0] * cx + P[k][1] * cy + P[k][2] * cz + P[k][3];
+        const double margin = 1e-6 * (an * (cnorm + r) + fabs(P[k][3]));
+        if (k == 0 || k == 1 || k == 3) out = out || (f + an * r < -margin);      // needs value > 0 / >= 0: all negative
+        else out = out || (f - an * r > margin);                                  // needs value < 0: all positive
+    }
+    return !out;
+}
+
+__global__ __launch_bounds__(256) void floater_votes_kernel(const FArgs a) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < a.n;
+    const double wlim = (double)a.W, hlim = (double)a.H;
+#if DD_VOTES_CULL
+    __shared__ float s_box[4][6];
+    __shared__ unsigned short s_views[256];
+    __shared__ int s_cnt[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float qnan = __builtin_nanf("");
+    const float fx = live ? a.xyz[3 * i] : qnan, fy = live ? a.xyz[3 * i + 1] : qnan, fz = live ? a.xyz[3 * i + 2] : qnan;
+    const double x = fx, y = fy, z = fz;
+    double nx = 0, ny = 0, nz = 0;
+    if (live) { nx = a.normal[3 * i]; ny = a.normal[3 * i + 1]; nz = a.normal[3 * i + 2]; }
+    // bounding box of the workgroup's points (fminf / fmaxf skip NaN: idle lanes and NaN points do not count;
+    // a NaN point never votes anyway)
+    float lo0 = fx, lo1 = fy, lo2 = fz, hi0 = fx, hi1 = fy, hi2 = fz;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo0 = fminf(lo0, __shfl_xor(lo0, o)); lo1 = fminf(lo1, __shfl_xor(lo1, o)); lo2 = fminf(lo2, __shfl_xor(lo2, o));
+        hi0 = fmaxf(hi0, __shfl_xor(hi0, o)); hi1 = fmaxf(hi1, __shfl_xor(hi1, o)); hi2 = fmaxf(hi2, __shfl_xor(hi2, o));
+    }
+    if (lane == 0) { s_box[wave][0] = lo0; s_box[wave][1] = lo1; s_box[wave][2] = lo2; s_box[wave][3] = hi0; s_box[wave][4] = hi1; s_box[wave][5] = hi2; }
+    __syncthreads();
+    double bl[3], bh[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        bl[k] = fminf(fminf(s_box[0][k], s_box[1][k]), fminf(s_box[2][k], s_box[3][k]));
+        bh[k] = fmaxf(fmaxf(s_box[0][k + 3], s_box[1][k + 3]), fmaxf(s_box[2][k + 3], s_box[3][k + 3]));
+    }
+    const double cx = 0.5 * (bl[0] + bh[0]), cy = 0.5 * (bl[1] + bh[1]), cz = 0.5 * (bl[2] + bh[2]);
+    const double ex = bh[0] - bl[0], ey = bh[1] - bl[1], ez = bh[2] - bl[2];
+    const double r = 0.5 * sqrt(ex * ex + ey * ey + ez * ez) * (1.0 + 1e-9);     // half diagonal: every point is inside
+    const double cnorm = fabs(cx) + fabs(cy) + fabs(cz);
+    int votes = (live && a.accumulate) ? a.votes[i] : 0;
+    for (int v0 = 0; v0 < a.V; v0 += 256) {
+        // phase A: one lane per view of this chunk decides whether the workgroup can see it at all
+        const int mine = v0 + (int)threadIdx.x;
+        const bool keep = mine < a.V && sphere_may_project(a.cams + (size_t)mine * 24, cx, cy, cz, r, cnorm, wlim, hlim);
+        const unsigned long long b = __ballot(keep);
+        if (keep) s_views[wave * 64 + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)threadIdx.x;
+        if (lane == 0) s_cnt[wave] = __popcll(b);
+        __syncthreads();
+        // phase B: every lane runs the exact test against the surviving views only
+        if (live) {
+            for (int w = 0; w < 4; ++w) {
+                const int cnt = __builtin_amdgcn_readfirstlane(s_cnt[w]);
+                for (int k = 0; k < cnt; ++k) {
+                    const int v = v0 + __builtin_amdgcn_readfirstlane((int)s_views[w * 64 + k]);      // uniform: scalar loads
+                    votes += pair_votes(a, a.cams + (size_t)v * 24, v, x, y, z, nx, ny, nz, wlim, hlim) ? 1 : 0;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (live) a.votes[i] = votes;
+#else
+    if (!live) return;
+    const double x = a.xyz[3 * i], y = a.xyz[3 * i + 1], z = a.xyz[3 * i + 2];
+    const double nx = a.normal[3 * i], ny = a.normal[3 * i + 1], nz = a.normal[3 * i + 2];
+    int votes = a.accumulate ? a.votes[i] : 0;
+    for (int v = 0; v < a.V; ++v)
+        votes += pair_votes(a, a.cams + (size_t)v * 24, v, x, y, z, nx, ny, nz, wlim, hlim) ? 1 : 0;   // wave-uniform block: scalar loads
     a.votes[i] = votes;
+#endif
 }
 
 // ==================================================================================================
