@@ -20,7 +20,9 @@
 #include "ddcore.h"
 
 #ifndef DD_VOTES_FAST
-#define DD_VOTES_FAST 1      // filtered predicates (identical decisions, fewer f64 divisions); 0 = always exact
+#define DD_VOTES_FAST 2      // filtered predicates (identical decisions): 1 = one IEEE reciprocal instead of three divisions +
+                             // division-free grazing test; 2 = additionally rcp + two Newton steps instead of the IEEE
+                             // division and a squared grazing comparison instead of the sqrt; 0 = always the exact formulation
 #endif
 #ifndef DD_VOTES_STAGE
 #define DD_VOTES_STAGE 0     // diagnostic builds stop after stage 1 (depth sign), 2 (bounds), 3 (grazing)
@@ -63,7 +65,13 @@ __device__ __forceinline__ bool pair_votes(const FArgs &a, const double *c, cons
     double u, w;
 #if DD_VOTES_FAST
     {
+#if DD_VOTES_FAST >= 2
+        double rden = __builtin_amdgcn_rcp(den);             // seed, then two Newton steps: relative error ~1e-16,
+        rden = fma(fma(-den, rden, 1.0), rden, rden);        // seven orders below the 1e-9 guard band
+        rden = fma(fma(-den, rden, 1.0), rden, rden);        // (inf / NaN propagate to u, w and fail `safe`)
+#else
         const double rden = 1.0 / den;
+#endif
         const double xf = xc * rden, yf = yc * rden, zf = zc * rden;
         u = c[12] * xf + c[13] * yf + c[14] * zf;
         w = c[15] * xf + c[16] * yf + c[17] * zf;
@@ -90,8 +98,25 @@ __device__ __forceinline__ bool pair_votes(const FArgs &a, const double *c, cons
     // d = p - centre, facing = -(n . d)/|d| > g  <=>  -(n . d) > g |d|; decided without the three
     // divisions unless the two sides are within 1e-9 of each other.
     double dx = x - c[18], dy = y - c[19], dz = z - c[20];
+#if DD_VOTES_FAST >= 2
+    {
+        // t > g |d| with g > 0  <=>  t > 0 and t^2 > g^2 |d|^2: no square root unless the two sides are within
+        // 2.5e-9 of each other (or anything is not finite) -- then the exact formulation decides.
+        const double len2 = dx * dx + dy * dy + dz * dz;
+        const double t = -(nx * dx + ny * dy + nz * dz), g = a.grazing_cos;
+        const double s = t * t, q = g * g * len2;
+        if (g > 0.0 && t <= 0.0) return false;              // facing <= 0 < g (0/0 = NaN for a zero direction fails too)
+        if (g > 0.0 && fabs(s - q) > 2.5e-9 * (s + q) && s < 1e300) {
+            if (!(s > q)) return false;
+        } else {
+            const double len = sqrt(len2);
+            dx /= len; dy /= len; dz /= len;
+            const double facing = nx * -dx + ny * -dy + nz * -dz;
+            if (!(facing > a.grazing_cos)) return false;
+        }
+    }
+#elif DD_VOTES_FAST
     const double len = sqrt(dx * dx + dy * dy + dz * dz);
-#if DD_VOTES_FAST
     {
         const double t = -(nx * dx + ny * dy + nz * dz), rhs = a.grazing_cos * len;
         const double guard = 1e-9 * (fabs(t) + fabs(rhs));
@@ -104,6 +129,7 @@ __device__ __forceinline__ bool pair_votes(const FArgs &a, const double *c, cons
         }
     }
 #else
+    const double len = sqrt(dx * dx + dy * dy + dz * dz);
     dx /= len; dy /= len; dz /= len;
     const double facing = nx * -dx + ny * -dy + nz * -dz;
     if (!(facing > a.grazing_cos)) return false;
