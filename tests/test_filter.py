@@ -87,6 +87,43 @@ def test_gpu_votes_match_oracle(with_mask):
 
 
 @pytest.mark.gpu
+def test_gpu_votes_on_decision_boundaries():
+    """Pairs built to sit ON the decision thresholds: projections at (or 1e-14 from) integer pixel coordinates and
+    the image edges -- the 1e-8 in the denominator puts them just below the integer -- and normals whose facing
+    cosine equals the grazing threshold up to float32 rounding.  Both the cheap evaluation and the exact fallback
+    of the filtered predicates are hit; every vote must equal the float64 NumPy restatement."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import depthdensifier_amd as dd
+
+    H, W, fx = 48, 64, 64.0
+    K = np.tile(np.array([[fx, 0, 32.0], [0, fx, 24.0], [0, 0, 1.0]]), (3, 1, 1))
+    E = np.tile(np.hstack([np.eye(3), np.zeros((3, 1))]), (3, 1, 1))
+    E[1, 0, 3] = 0.25; E[2, 1, 3] = -0.5                      # exactly representable shifts
+    depth = np.full((3, H, W), 1e9, np.float32)
+    rng = np.random.default_rng(11)
+    pts, nrm = [], []
+    # (a) pixel-grid points: u = j / (1 + 1e-8 / z) for integer j -- far from / inside the guard band as z grows
+    for z in (1.0, 1024.0, 1048576.0):
+        j, i = np.meshgrid(np.arange(-1, W + 2), np.arange(-1, H + 2))
+        p = np.stack([(j - 32.0) / fx * z, (i - 24.0) / fx * z, np.full(j.shape, z)], -1).reshape(-1, 3)
+        pts.append(p); nrm.append(np.tile([0.0, 0.0, -1.0], (len(p), 1)))
+    # (b) facing cosine = 0.087 in exact arithmetic, perturbed by the float32 rounding of the normal
+    g = 0.087
+    p = np.stack([rng.uniform(-0.3, 0.3, 20000), rng.uniform(-0.2, 0.2, 20000), np.ones(20000)], -1) * rng.uniform(1, 5, (20000, 1))
+    p = p.astype(np.float32).astype(np.float64)
+    d = p / np.linalg.norm(p, axis=1, keepdims=True)
+    perp = np.cross(d, [0.0, 1.0, 0.0]); perp /= np.linalg.norm(perp, axis=1, keepdims=True)
+    pts.append(p); nrm.append(-(g * d + np.sqrt(1 - g * g) * perp))
+    pts = np.concatenate(pts).astype(np.float32); nrm = np.concatenate(nrm).astype(np.float32)
+    ref = forc.floater_votes(pts, nrm, depth, K, E)
+    got = dd.floater_votes(torch.from_numpy(pts).cuda(), torch.from_numpy(nrm).cuda(), depth, K, E).cpu().numpy()
+    assert np.array_equal(got, ref)
+    assert 0 < (ref[-20000:] > 0).mean() < 1 and ref[:-20000].max() == 3 and ref[:-20000].min() == 0     # both outcomes occur
+
+
+@pytest.mark.gpu
 def test_gpu_filter_floaters_matches_oracle():
     import torch
     if not torch.cuda.is_available():
