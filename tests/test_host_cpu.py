@@ -64,6 +64,38 @@ def test_invalid_arguments_return_codes(libmod, kw, text):
     assert libmod.lib.dd_count_valid(C.byref(b), None, None) == -1
 
 
+def test_neighbour_entry_points_validate_before_launching(libmod):
+    """dd_floater_votes / dd_compact_cloud / dd_refine_apply reject bad arguments with DD_ERR_* and a message -- no GPU
+    work is attempted (this runs on a machine without one)."""
+    L = libmod.lib
+    fv = libmod.DDFilterViews(num_views=0, height=8, width=8, depth=0x1000, cams=0x2000, grazing_cos=0.087, depth_threshold=0.7)
+    assert L.dd_floater_votes(C.byref(fv), 0x10, 0x20, 5, 0x30, 0, None) == -1 and b"positive" in L.dd_filter_last_error()
+    fv.num_views, fv.depth = 2, None
+    assert L.dd_floater_votes(C.byref(fv), 0x10, 0x20, 5, 0x30, 0, None) == -1 and b"NULL" in L.dd_filter_last_error()
+    fv.depth = 0x1000
+    assert L.dd_floater_votes(C.byref(fv), None, 0x20, 5, 0x30, 0, None) == -1
+    assert L.dd_floater_votes(C.byref(fv), 0x10, 0x20, -1, 0x30, 0, None) == -1 and b"negative" in L.dd_filter_last_error()
+    assert L.dd_floater_votes(C.byref(fv), None, None, 0, None, 0, None) == 0            # nothing to do is not an error
+    assert L.dd_floater_votes(None, 0x10, 0x20, 5, 0x30, 0, None) == -1
+
+    src = libmod.DDCloudOut(xyz=0x100, capacity=10)
+    dst = libmod.DDCloudOut(xyz=0x200, normal=0x300, capacity=10)
+    assert L.dd_compact_workspace_bytes(-1) == -1 and L.dd_compact_workspace_bytes(0) >= 16
+    assert L.dd_compact_cloud(C.byref(src), 10, 0x40, 5, C.byref(dst), 0x50, None, None, 0, 0x1000, 1 << 20, None) == -1
+    assert b"no input field" in L.dd_filter_last_error()
+    dst.normal = None
+    assert L.dd_compact_cloud(C.byref(src), 11, 0x40, 5, C.byref(dst), 0x50, None, None, 0, 0x1000, 1 << 20, None) == -1
+    assert b"capacity" in L.dd_filter_last_error()
+    assert L.dd_compact_cloud(C.byref(src), 10, 0x40, 5, C.byref(dst), 0x50, 0x60, None, 3, 0x1000, 1 << 20, None) == -1
+    assert L.dd_compact_cloud(C.byref(src), 10, 0x40, 5, C.byref(dst), 0x50, None, None, 0, None, 0, None) == -3        # DD_ERR_WORKSPACE
+    assert L.dd_compact_cloud(C.byref(src), 10, 0x40, 5, C.byref(dst), 0x50, None, None, 0, 0x1008, 1 << 20, None) == -3   # mis-aligned
+
+    assert L.dd_refine_apply(None, 0, None, 8, 8, 0x10, 0x20, 4, 0, 0x30, None) == -1 and b"NULL" in L.dd_refine_last_error()
+    assert L.dd_refine_apply(0x100, 0, None, 0, 8, 0x10, 0x20, 4, 0, 0x30, None) == -1
+    assert L.dd_refine_apply(0x100, 9, None, 8, 8, 0x10, 0x20, 4, 0, 0x30, None) == -1 and b"depth_dtype" in L.dd_refine_last_error()
+    assert L.dd_refine_apply(0x100, 0, None, 8, 8, 0x10, 0x20, 1, 0, 0x30, None) == -1 and b"two" in L.dd_refine_last_error()
+
+
 def test_workspace_size_and_null_outputs(libmod):
     b = _batch(libmod, height=1080, width=1920, num_views=3)
     n = libmod.lib.dd_workspace_bytes(C.byref(b))
