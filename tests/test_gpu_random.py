@@ -1,12 +1,18 @@
 """Randomised parity sweep: HIP path vs oracle over random shapes, strides, dtypes, field subsets,
 semantics and kernel variants (seeded, so failures reproduce)."""
 
+import os
+
 import numpy as np
 import pytest
 
 from test_gpu_parity import assert_cloud, scene_radius  # noqa: E402  (shared helpers)
 
 pytestmark = pytest.mark.gpu
+
+# soak runs: DD_RANDOM_SEEDS=1000 DD_RANDOM_SCALE=6 python -m pytest tests/test_gpu_random.py  (defaults: 60 seeds, scale 1)
+N_SEEDS = int(os.environ.get("DD_RANDOM_SEEDS", "60"))
+SCALE = int(os.environ.get("DD_RANDOM_SCALE", "1"))      # multiplies H and W: several look-back tiles per view
 
 
 def _case(seed):
@@ -19,6 +25,7 @@ def _case(seed):
     else:
         H, W = int(rng.integers(1, 150)), int(rng.integers(1, 150))
     dtype = np.float16 if rng.uniform() < 0.4 else np.float32
+    H, W = H * SCALE, W * SCALE
     d = make_views(seed, V, H, W, rho=float(rng.uniform(0.05, 1.0)), specials=bool(rng.uniform() < 0.7), depth_dtype=dtype)
     d["params"] = np.stack([[W * rng.uniform(0.5, 1.5), W * rng.uniform(0.5, 1.5), W / 2 + rng.uniform(-5, 5),
                              H / 2 + rng.uniform(-5, 5)] for _ in range(V)])
@@ -32,7 +39,7 @@ def _case(seed):
     return d, opts
 
 
-@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("seed", range(N_SEEDS))
 def test_random_configuration(seed):
     import torch
     if not torch.cuda.is_available():
