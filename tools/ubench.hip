@@ -35,6 +35,9 @@ __global__ void w_x4_nt(f4 *o, size_t n) { for (size_t i = blockIdx.x * (size_t)
 __global__ void w_x4_const(f4 *o, size_t n) { const f4 v = {1.f, 1.f, 1.f, 1.f}; for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) o[i] = v; }
 __global__ void c_x4_oneshot(const f4 *a, f4 *o, size_t n) { const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; if (i < n) o[i] = a[i]; }
 __global__ void c_x3_oneshot(const float *a, float *o, size_t n) { const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; if (i < n) *reinterpret_cast<f3 *>(o + i * 3) = *reinterpret_cast<const f3 *>(a + i * 3); }
+// cross shapes: which side of a copy pays for 12-byte accesses?
+__global__ void c_r4w3_oneshot(const f4 *a, float *o, size_t n) { const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; if (i < n) { const f4 v = a[i]; f3 w = {v.x, v.y, v.z + v.w}; *reinterpret_cast<f3 *>(o + i * 3) = w; } }
+__global__ void c_r3w4_oneshot(const float *a, f4 *o, size_t n) { const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; if (i < n) { const f3 v = *reinterpret_cast<const f3 *>(a + i * 3); f4 w = {v.x, v.y, v.z, 1.f}; o[i] = w; } }
 // read 12-B elements, write the same stream as 16-B chunks (lane j of a 768-thread block reads 3 dwords, 576 lanes store dwordx4 via LDS)
 __global__ __launch_bounds__(768) void c_x3_to_x4(const float *a, float *o, size_t npts) {
   __shared__ float st[768 * 3];
@@ -69,6 +72,8 @@ int main(int argc, char **argv) {
       run("write dwordx4 one-shot +4B misaligned", BYTES, [&] { w_x4_oneshot<<<dim3((unsigned)(BYTES / 16 / 256) - 1), blk>>>((f4 *)((char *)b + 4), BYTES / 16 - 256); });
       run("copy dwordx4 one-shot", 2 * BYTES, [&] { c_x4_oneshot<<<dim3((unsigned)(BYTES / 16 / 256)), blk>>>((const f4 *)a, (f4 *)b, BYTES / 16); });
       run("copy dwordx3 one-shot", 2 * BYTES, [&] { c_x3_oneshot<<<dim3((unsigned)(BYTES / 12 / 256)), blk>>>((const float *)a, (float *)b, BYTES / 12); });
+      { const size_t n = BYTES / 16; run("copy read x4 -> write x3 one-shot", n * 28, [&] { c_r4w3_oneshot<<<dim3((unsigned)(n / 256)), blk>>>((const f4 *)a, (float *)b, n); }); }
+      { const size_t n = BYTES / 16; run("copy read x3 -> write x4 one-shot", n * 28, [&] { c_r3w4_oneshot<<<dim3((unsigned)(n / 256)), blk>>>((const float *)a, (f4 *)b, n); }); }
       run("copy read x3 -> LDS -> write x4", 2 * BYTES, [&] { c_x3_to_x4<<<dim3((unsigned)(BYTES / 12 / 768)), dim3(768)>>>((const float *)a, (float *)b, BYTES / 12); });
       run("write dwordx4 block chunks 64K", BYTES, [&] { w_x4_chunk<<<dim3((unsigned)(BYTES / 65536)), blk>>>((f4 *)b, BYTES / 16, 4096); });
       run("write dwordx4 block chunks 1M", BYTES, [&] { w_x4_chunk<<<dim3((unsigned)(BYTES / 1048576)), blk>>>((f4 *)b, BYTES / 16, 65536); });
