@@ -185,21 +185,65 @@ def allgather_views(local: torch.Tensor, num_views_total: int, group=None) -> to
     return allgatherv_rows(local.contiguous(), shard_sizes(num_views_total, world), group=group)
 
 
+def floater_votes_sharded(local_cloud, local_views: Sequence[dict], num_views_total: int, depth_threshold: float = 0.7,
+                          group=None) -> torch.Tensor:
+    """Votes of this rank's points against ALL views of a view-sharded scan.
+
+    ``local_views``: this rank's views in order, each ``{"depth": (H,W) f32 device tensor, "mask": (H,W) bool or None,
+    "K": (3,3), "E": (3,4)}``; sizes may differ between views.  Depth maps, masks and cameras are all-gathered size
+    group by size group (2000 x 1080p = 16.6 GB, small next to 288 GB of HBM), then every rank votes on its own
+    points: the O(N*V) work splits by points and no point moves.  Votes are counts over the same set of views, so
+    they equal the one-GPU votes."""
+    import numpy as np
+    from .filtering import floater_votes
+
+    world = dist.get_world_size(group)
+    dev = local_cloud.points.device
+    parts: list = [None] * world
+    dist.all_gather_object(parts, [tuple(v["depth"].shape) for v in local_views], group=group)    # control plane
+    all_shapes = [shp for part in parts for shp in part]
+    if len(all_shapes) != num_views_total:
+        raise ValueError(f"ranks hold {len(all_shapes)} views in total, expected {num_views_total}")
+    bounds, start = [], 0
+    for part in parts:
+        bounds.append((start, start + len(part)))
+        start += len(part)
+    votes = torch.zeros(len(local_cloud), dtype=torch.int32, device=dev)
+    for shp in dict.fromkeys(all_shapes):                         # distinct sizes, first-seen order (same on all ranks)
+        rows = [sum(1 for k in range(lo, hi) if all_shapes[k] == shp) for lo, hi in bounds]
+        mine = [v for v in local_views if tuple(v["depth"].shape) == shp]
+
+        def stacked(make, tail, dtype):
+            if mine:
+                return torch.stack([make(v) for v in mine]).contiguous()
+            return torch.empty((0,) + tuple(tail), dtype=dtype, device=dev)
+
+        f64 = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64), device=dev)
+        depth = allgatherv_rows(stacked(lambda v: v["depth"].to(torch.float32), shp, torch.float32), rows, group=group)
+        ones = lambda v: torch.ones(shp, dtype=torch.uint8, device=dev)
+        mask = allgatherv_rows(stacked(lambda v: ones(v) if v.get("mask") is None else v["mask"].view(torch.uint8) if v["mask"].dtype == torch.bool
+                                       else (v["mask"] > 0).view(torch.uint8), shp, torch.uint8), rows, group=group)
+        K = allgatherv_rows(stacked(lambda v: f64(v["K"])[:3, :3], (3, 3), torch.float64), rows, group=group)
+        E = allgatherv_rows(stacked(lambda v: f64(v["E"])[:3, :4], (3, 4), torch.float64), rows, group=group)
+        floater_votes(local_cloud.points, local_cloud.normals, depth, K.cpu().numpy(), E.cpu().numpy(), mask=mask,
+                      depth_threshold=depth_threshold, votes=votes)
+    return votes
+
+
 def filter_floaters_sharded(local_cloud, local_depth: torch.Tensor, local_intrinsics, local_cam_from_world,
                             num_views_total: int, local_mask: Optional[torch.Tensor] = None, config=None, group=None):
-    """The multi-view filter on a sharded cloud: the depth maps and cameras of ALL views are
-    all-gathered (2000 x 1080p = 16.6 GB, small next to 288 GB of HBM), then every rank votes on and compacts
-    its own slice of the points -- the O(N*V) work splits by points, no point ever moves."""
+    """The multi-view filter on a sharded cloud: ``floater_votes_sharded`` on this rank's stack of views, then the
+    stable compaction of its own slice.  Returns ``(kept_local_cloud, votes)``."""
     import numpy as np
     from .densify import intrinsics_matrix
-    from .filtering import filter_floaters
+    from .filtering import FilteringConfig, compact_cloud
 
-    dev = local_depth.device
-    depth = allgather_views(local_depth, num_views_total, group)
-    mask = None if local_mask is None else allgather_views(local_mask.view(torch.uint8) if local_mask.dtype == torch.bool
-                                                           else local_mask, num_views_total, group)
-    K = torch.from_numpy(intrinsics_matrix(local_intrinsics)).to(dev)
-    E = torch.as_tensor(np.asarray(local_cam_from_world, dtype=np.float64)).to(dev)
-    K_all = allgather_views(K, num_views_total, group).cpu().numpy()
-    E_all = allgather_views(E, num_views_total, group).cpu().numpy()
-    return filter_floaters(local_cloud, depth, K_all, E_all, mask=mask, config=config)
+    cfg = config or FilteringConfig()
+    K = intrinsics_matrix(local_intrinsics)
+    E = np.asarray(local_cam_from_world.cpu() if isinstance(local_cam_from_world, torch.Tensor) else local_cam_from_world, dtype=np.float64)
+    n = local_depth.shape[0]
+    if K.shape[0] == 1 and n > 1:
+        K = np.repeat(K, n, axis=0)
+    views = [dict(depth=local_depth[i], mask=None if local_mask is None else local_mask[i], K=K[i], E=E[i]) for i in range(n)]
+    votes = floater_votes_sharded(local_cloud, views, num_views_total, cfg.depth_threshold, group)
+    return compact_cloud(local_cloud, votes, cfg.vote_threshold), votes

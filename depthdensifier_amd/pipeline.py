@@ -123,37 +123,6 @@ def _votes_single(cloud, cached, depth_threshold):
     return votes
 
 
-def _votes_sharded(cloud, cached, depth_threshold, ranks: _Ranks, num_views: int, device):
-    """The filter on a view-sharded scan: depth maps / masks / cameras of ALL views are all-gathered size group by
-    size group (a 185-view 1080p scan is 1.9 GB), then every rank votes on its own points -- the O(N*V) work
-    splits by points and no point moves.  Same votes as one GPU: they are counts over the same set of views."""
-    import torch.distributed as dist
-    from . import distributed as D
-
-    local_shapes = [tuple(c["depth"].shape) for c in cached]
-    parts: list = [None] * ranks.world
-    dist.all_gather_object(parts, local_shapes)                   # control plane: a few tuples per rank
-    bounds = [D.shard_views(num_views, ranks.world, r) for r in range(ranks.world)]
-    all_shapes = [shp for part in parts for shp in part]
-    votes = torch.zeros(len(cloud), dtype=torch.int32, device=device)
-    for shp in dict.fromkeys(all_shapes):                         # distinct sizes, first-seen order (same on all ranks)
-        rows = [sum(1 for k in range(lo, hi) if all_shapes[k] == shp) for lo, hi in bounds]
-        mine = [c for c in cached if tuple(c["depth"].shape) == shp]
-
-        def stacked(make, tail, dtype):
-            if mine:
-                return torch.stack([make(c) for c in mine]).contiguous()
-            return torch.empty((0,) + tail, dtype=dtype, device=device)
-
-        depth = D.allgatherv_rows(stacked(lambda c: c["depth"], shp, torch.float32), rows)
-        mask = D.allgatherv_rows(stacked(lambda c: c["mask"].view(torch.uint8), shp, torch.uint8), rows)
-        K = D.allgatherv_rows(stacked(lambda c: torch.as_tensor(c["K"], dtype=torch.float64, device=device), (3, 3), torch.float64), rows)
-        E = D.allgatherv_rows(stacked(lambda c: torch.as_tensor(c["E"], dtype=torch.float64, device=device), (3, 4), torch.float64), rows)
-        floater_votes(cloud.points, cloud.normals, depth, K.cpu().numpy(), E.cpu().numpy(), mask=mask,
-                      depth_threshold=depth_threshold, votes=votes)
-    return votes
-
-
 def main(config: ScriptConfig) -> dict:
     """Densify one COLMAP scan; returns a small report (counts, timings).
 
@@ -283,7 +252,8 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
     if ranks.world == 1:
         votes = _votes_single(cloud, cached, config.filtering.depth_threshold)
     else:
-        votes = _votes_sharded(cloud, cached, config.filtering.depth_threshold, ranks, num_views, device)
+        from .distributed import floater_votes_sharded
+        votes = floater_votes_sharded(cloud, cached, num_views, config.filtering.depth_threshold)
     kept = compact_cloud(cloud, votes, config.filtering.vote_threshold)        # :330-332
     if ranks.world > 1:                 # fuse: all-gatherv of the per-GPU clouds, rank order = view order
         from . import distributed as D
