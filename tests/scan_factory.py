@@ -15,7 +15,8 @@ def rot_to_qvec(R):
     return np.array([w, x, y, z])
 
 
-def make_scan(root: Path, name: str, V=5, H=96, W=128, seed=0, floaters=0.02):
+def make_scan(root: Path, name: str, V=5, H=96, W=128, seed=0, floaters=0.02, second_size=None):
+    """``second_size=(H2, W2)``: odd-numbered views use a second camera of that size (mixed resolutions in one scan)."""
     from PIL import Image as PILImage
     rng = np.random.default_rng(seed)
     scan = Path(root) / name
@@ -23,13 +24,17 @@ def make_scan(root: Path, name: str, V=5, H=96, W=128, seed=0, floaters=0.02):
     (scan / "sparse" / "0").mkdir(parents=True)
     cache = scan / "moge_cache"
     cache.mkdir()
-    fx = fy = 0.9 * W
-    cx, cy = W / 2.0, H / 2.0
     rec = Reconstruction()
-    rec.cameras[1] = Camera(1, 1, W, H, np.array([fx, fy, cx, cy]))
+    sizes = [(H, W)] + ([tuple(second_size)] if second_size else [])
+    for k, (h, w) in enumerate(sizes):
+        rec.cameras[k + 1] = Camera(k + 1, 1, w, h, np.array([0.9 * w, 0.9 * w, w / 2.0, h / 2.0]))
     ids, xyz, rgbs, next_id = [], [], [], 1
     truth = []
     for v in range(V):
+        cam_id = 1 + (v % len(sizes))
+        H, W = sizes[cam_id - 1]
+        fx = fy = 0.9 * W
+        cx, cy = W / 2.0, H / 2.0
         a = -0.5 + v * (1.0 / max(V - 1, 1))
         c = np.array([3.0 * np.sin(a), -2.0, -3.0 * np.cos(a)])          # camera centre above the plane y = 0
         zax = -c / np.linalg.norm(c)                                      # looks at the origin
@@ -64,7 +69,7 @@ def make_scan(root: Path, name: str, V=5, H=96, W=128, seed=0, floaters=0.02):
         pid = np.arange(next_id, next_id + len(world)); next_id += len(world)
         ids.append(pid); xyz.append(world); rgbs.append(np.full((len(world), 3), 200, np.uint8))
         xys = np.stack([np.floor(pu), np.floor(pv)], -1)
-        rec.images[v + 1] = Image(v + 1, rot_to_qvec(R), t, 1, f"{stem}.png", xys, pid.astype(np.int64))
+        rec.images[v + 1] = Image(v + 1, rot_to_qvec(R), t, cam_id, f"{stem}.png", xys, pid.astype(np.int64))
         truth.append(dict(R=R, t=t, depth_true=depth_true, mono=mono_f, mask=mask, normal=normal, rgb=img))
     rec.point_ids = np.concatenate(ids).astype(np.uint64)
     rec.point_xyz = np.concatenate(xyz)

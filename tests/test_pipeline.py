@@ -160,7 +160,7 @@ def test_view_sharded_scan_matches_single_gpu(tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from scan_factory import make_scan
-    scan, cache, _ = make_scan(tmp_path / "scans", "plane", V=7, seed=3, floaters=0.03)
+    scan, cache, _ = make_scan(tmp_path / "scans", "plane", V=7, seed=3, floaters=0.03, second_size=(72, 104))   # two view sizes
     root = Path(__file__).resolve().parent.parent
     args = ["--paths.recon-path", str(scan / "sparse" / "0"), "--paths.image-dir", str(scan / "images"),
             "--moge.cache-dir", str(cache), "--processing.downsample-density", "2", "--refiner.no-use-fp16",
@@ -177,6 +177,9 @@ def test_view_sharded_scan_matches_single_gpu(tmp_path):
                          capture_output=True, text=True, timeout=300, env=env)
     assert two.returncode == 0, two.stdout + two.stderr
     assert "Sharding 7 views over 2 GPUs" in two.stdout
+    from depthdensifier_amd.colmap_io import Reconstruction
+    n_sparse = Reconstruction(scan / "sparse" / "0").num_points3D()
+    assert Reconstruction(tmp_path / "one").num_points3D() > n_sparse + 1000        # dense points were produced
     for name in ("cameras.bin", "images.bin", "points3D.bin"):
         assert (tmp_path / "one" / name).read_bytes() == (tmp_path / "two" / name).read_bytes(), name
 
