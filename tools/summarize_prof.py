@@ -12,7 +12,7 @@ def main(src: str, dst: str, note: str = "") -> None:
         sys.exit(f"no *_kernel_stats.csv under {src}")
     rows = list(csv.DictReader(stats[0].open()))
     mine = ("compact_generic", "compact_lean", "count_lean", "count_generic", "scan_view_tiles", "scan_views",
-            "floater_", "dd_")
+            "floater_", "dd_", "compact_count", "compact_scan", "compact_scatter", "compact_view", "refine_apply")
     ours = [r for r in rows if any(m in r["Name"] for m in mine)]
     rest = [r for r in rows if r not in ours]
     with open(dst, "w") as f:
