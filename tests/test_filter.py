@@ -1,6 +1,8 @@
 """Floater filter: oracle vs the reference's project_points golden (CPU) and the
 HIP vote kernel vs the oracle (GPU; votes are integers -> bit-exact)."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -84,6 +86,27 @@ def test_gpu_votes_match_oracle(with_mask):
     v2 = dd.floater_votes(cloud.points, cloud.normals, depth_in[:3], K[:3], d["cam_from_world"][:3], mask=None if mask is None else mask[:3])
     v2 = dd.floater_votes(cloud.points, cloud.normals, depth_in[3:], K[3:], d["cam_from_world"][3:], mask=None if mask is None else mask[3:], votes=v2)
     assert np.array_equal(v2.cpu().numpy(), votes)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(100, 100 + int(os.environ.get("DD_VOTE_SEEDS", "8"))))      # soak: DD_VOTE_SEEDS=60
+def test_gpu_votes_random_scenes(seed):
+    """Random ring scenes (views, size, threshold drawn per seed): every vote equals the oracle's."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import depthdensifier_amd as dd
+    rng = np.random.default_rng(seed)
+    V, H, W = int(rng.integers(2, 9)), int(rng.integers(20, 90)), int(rng.integers(20, 120))
+    d = _scene(seed, V, H, W)
+    depth = np.where(np.isfinite(d["depth"]) & (d["depth"] > 0), d["depth"], 1.0).astype(np.float32)
+    cloud = dd.unproject_views(depth, d["params"], d["cam_from_world"], mask=d["mask"], normal=d["normal"], rgb=d["rgb"])
+    K = dd.intrinsics_matrix(d["params"])
+    thr = float(rng.choice([0.7, 0.9, 0.5]))
+    votes = dd.floater_votes(cloud.points, cloud.normals, depth, K, d["cam_from_world"], mask=d["mask"], depth_threshold=thr).cpu().numpy()
+    culled = np.where(d["mask"], depth, 0).astype(np.float32)
+    ref = forc.floater_votes(cloud.points.cpu().numpy(), cloud.normals.cpu().numpy(), culled, K, d["cam_from_world"], depth_threshold=thr)
+    assert np.array_equal(votes, ref)
 
 
 @pytest.mark.gpu

@@ -7,7 +7,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 import bench, depthdensifier_amd as dd
 
-ap = argparse.ArgumentParser(); ap.add_argument("--views", type=int, default=32); ap.add_argument("--cpu-views", type=int, default=0)
+ap = argparse.ArgumentParser(); ap.add_argument("--views", type=int, default=32); 
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 cfg = dict(bench.WORKLOADS["garden185"]); cfg["V"] = a.views
@@ -28,10 +28,4 @@ pairs = len(cloud) * a.views
 print(f"points {len(cloud)/1e6:.1f} M x views {a.views} = {pairs/1e9:.2f} G pairs in {dt*1e3:.1f} ms -> {pairs/dt/1e9:.1f} Gpairs/s; "
       f"votes>=5: {(votes >= 5).float().mean().item()*100:.2f} %  max {int(votes.max())}")
 print("votes checksum", int(votes.long().sum()), int((votes.long() * (torch.arange(len(votes), device=votes.device) % 1000003)).sum()))
-if a.cpu_views:
-    from oracle import filter_oracle as forc
-    n = 2_000_000
-    p = cloud.points[:n].cpu().numpy(); nn = cloud.normals[:n].cpu().numpy()
-    cd = torch.where(scene["mask"], scene["depth"], torch.zeros_like(scene["depth"]))[:a.cpu_views].cpu().numpy()
-    t0 = time.perf_counter(); forc.floater_votes(p, nn, cd, K[:a.cpu_views], E[:a.cpu_views]); dt = time.perf_counter() - t0
-    print(f"oracle (NumPy, 1 core): {n*a.cpu_views/dt/1e6:.1f} Mpairs/s")
+# the NumPy baseline of this stage is timed by tests/time_filter_oracle.py (the oracle is test infrastructure)
