@@ -53,7 +53,7 @@ class ProcessingConfig:
     """Factor to downsample images before processing. Larger is faster."""
     downsample_density: int = 32
     """Controls final point cloud density (1=densest)."""
-    io_threads: int = 4
+    io_threads: int = 8
     """Host threads that decode images / read cached maps ahead of the GPU (0 = inline, like the reference)."""
     shard_views: bool = True
     """Under torchrun (one process per GPU): shard this scan's views over the ranks.  The batch driver turns it
