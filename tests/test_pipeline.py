@@ -184,6 +184,59 @@ def test_view_sharded_scan_matches_single_gpu(tmp_path):
         assert (tmp_path / "one" / name).read_bytes() == (tmp_path / "two" / name).read_bytes(), name
 
 
+def test_moge_adapter_with_a_stub_model(monkeypatch, tmp_path):
+    """``MoGeSource`` feeds ``MoGeModel.infer`` a (1,3,H,W) float image in [0,1] (scripts/test.py:154-155) and returns
+    squeezed depth / normal / bool mask; ``make_depth_source`` prefers the cache and explains a missing MoGe."""
+    import sys
+    import types
+    import torch
+    from depthdensifier_amd import depth_source as ds
+
+    seen = {}
+
+    class StubModel:
+        @classmethod
+        def from_pretrained(cls, ckpt):
+            seen["ckpt"] = ckpt
+            return cls()
+
+        def to(self, device):
+            seen["device"] = device
+            return self
+
+        def eval(self):
+            return self
+
+        def infer(self, x):
+            seen["x"] = x
+            _, _, h, w = x.shape
+            return {"depth": torch.full((1, h, w), 2.0), "normal": torch.zeros((1, h, w, 3)), "mask": torch.ones((1, h, w))}
+
+    pkg, model, v2 = types.ModuleType("moge"), types.ModuleType("moge.model"), types.ModuleType("moge.model.v2")
+    v2.MoGeModel = StubModel
+    for name, mod in (("moge", pkg), ("moge.model", model), ("moge.model.v2", v2)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    cpu = torch.device("cpu")
+    src = ds.make_depth_source(Path("models/x.pt"), None, cpu)
+    assert isinstance(src, ds.MoGeSource) and seen["ckpt"] == Path("models/x.pt") and seen["device"] == cpu
+    rgb = np.full((6, 8, 3), 255, np.uint8); rgb[0, 0] = (0, 51, 102)
+    out = src.infer("a.png", rgb, cpu)
+    x = seen["x"]
+    assert x.shape == (1, 3, 6, 8) and x.dtype == torch.float32 and float(x.max()) == 1.0
+    assert torch.allclose(x[0, :, 0, 0], torch.tensor([0.0, 0.2, 0.4]))
+    assert out["depth"].shape == (6, 8) and out["normal"].shape == (6, 8, 3) and out["mask"].dtype == torch.bool
+    assert src.prepare("a.png", rgb) is None                              # nothing to read ahead for a live model
+
+    (tmp_path / "cache").mkdir()
+    assert isinstance(ds.make_depth_source(Path("models/x.pt"), tmp_path / "cache", cpu), ds.CachedSource)
+    for name in ("moge", "moge.model", "moge.model.v2"):
+        monkeypatch.setitem(sys.modules, name, None)                      # import now fails
+    with pytest.raises(ImportError, match="cache-dir"):
+        ds.make_depth_source(Path("models/x.pt"), None, cpu)
+    with pytest.raises(FileNotFoundError):
+        ds.CachedSource(tmp_path / "nope")
+
+
 def test_batch_cache_dir_placeholder(tmp_path):
     """``moge.cache_dir`` with ``{scan}`` is resolved per scan folder; a plain path is shared as given."""
     import run_batch
