@@ -370,9 +370,27 @@ template <> __device__ __forceinline__ float raw_depth<_Float16>(const uint4 &d,
     return (float)f;
 }
 
-// Loads + validity bits of the CH groups a lane owns.  Addresses of out-of-range groups are clamped
-// (P % VEC == 0, so a group is entirely in or out) to keep every load unconditional: the compiler
-// then issues them all before the first use.
+// element-aligned (not vector-aligned) wide loads: a view of H*W pixels starts wherever the previous one ended, and
+// gfx950 serves dword- / byte-aligned dwordx4 accesses in hardware (tools/ubench.hip: -25 % at worst on a pure
+// store stream; nothing measurable on aligned addresses, where the instruction is the same)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef u32x4 u32x4_unaligned __attribute__((aligned(2)));
+typedef u32x2 u32x2_unaligned __attribute__((aligned(2)));
+
+template <typename DepthT> __device__ __forceinline__ void set_raw(uint4 &d, int k, unsigned bits);
+template <> __device__ __forceinline__ void set_raw<float>(uint4 &d, int k, unsigned bits) {
+    if (k == 0) d.x = bits; else if (k == 1) d.y = bits; else if (k == 2) d.z = bits; else d.w = bits;
+}
+template <> __device__ __forceinline__ void set_raw<_Float16>(uint4 &d, int k, unsigned bits) {
+    unsigned &w = (k >> 1) == 0 ? d.x : (k >> 1) == 1 ? d.y : (k >> 1) == 2 ? d.z : d.w;
+    w = (k & 1) ? ((w & 0x0000ffffu) | (bits << 16)) : ((w & 0xffff0000u) | (bits & 0xffffu));
+}
+
+// Loads + validity bits of the CH groups (vectors of VEC pixels) a lane owns.  Every load is unconditional so that
+// the compiler issues them all before the first use: a vector that would cross the end of the view is read from
+// the view's last VEC pixels instead (P >= VEC), and -- only in the wave that holds the end of a view whose pixel
+// count is not a multiple of VEC, a wave-uniform branch -- the one partial vector is re-read element by element.
 template <typename DepthT, bool HAS_MASK, bool NEED_DEPTH>
 __device__ __forceinline__ void lean_load_test(const KArgs &a, long long vbase, unsigned qw, int lane,
                                                uint4 (&d)[L_PXT / (16 / (int)sizeof(DepthT))],
@@ -380,29 +398,32 @@ __device__ __forceinline__ void lean_load_test(const KArgs &a, long long vbase, 
     // NEED_DEPTH = false: pass 1 under a mask-only validity rule touches 1 B/px instead of 5
     constexpr int VEC = 16 / (int)sizeof(DepthT), CH = L_PXT / VEC;
     unsigned mk[CH][VEC / 4];
-    bool inside[CH];
+    unsigned nvalid[CH];                      // pixels of the vector that exist: VEC, 0, or 1..VEC-1 at a ragged view end
+    long long eload[CH];
 #pragma unroll
     for (int ch = 0; ch < CH; ++ch) {
-        unsigned qb = qw + (unsigned)(ch * 64 + lane) * VEC;
-        inside[ch] = qb < a.P;
-        if (!inside[ch]) qb = a.P - VEC;
-        const long long e = vbase + qb;
+        const unsigned qb = qw + (unsigned)(ch * 64 + lane) * VEC;
+        nvalid[ch] = qb < a.P ? (a.P - qb < (unsigned)VEC ? a.P - qb : (unsigned)VEC) : 0u;
+        const long long e = vbase + (nvalid[ch] == (unsigned)VEC ? qb : a.P - VEC);
+        eload[ch] = e;
         if constexpr (!NEED_DEPTH) { d[ch].x = d[ch].y = d[ch].z = d[ch].w = 0u; }
 #if DD_NT_LOAD
         if constexpr (NEED_DEPTH) {
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 w = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(reinterpret_cast<const DepthT *>(a.depth) + e));
+            const u32x4 w = __builtin_nontemporal_load(reinterpret_cast<const u32x4_unaligned *>(reinterpret_cast<const DepthT *>(a.depth) + e));
             d[ch].x = w.x; d[ch].y = w.y; d[ch].z = w.z; d[ch].w = w.w;
         }
         if constexpr (HAS_MASK) {
 #pragma unroll
-            for (int i = 0; i < VEC / 4; ++i) mk[ch][i] = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(a.mask + e + 4 * i));
+            for (int i = 0; i < VEC / 4; ++i) mk[ch][i] = __builtin_nontemporal_load(reinterpret_cast<const u32_unaligned *>(a.mask + e + 4 * i));
         }
 #else
-        if constexpr (NEED_DEPTH) d[ch] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const DepthT *>(a.depth) + e);
+        if constexpr (NEED_DEPTH) {
+            const u32x4 w = *reinterpret_cast<const u32x4_unaligned *>(reinterpret_cast<const DepthT *>(a.depth) + e);
+            d[ch].x = w.x; d[ch].y = w.y; d[ch].z = w.z; d[ch].w = w.w;
+        }
         if constexpr (HAS_MASK) {
 #pragma unroll
-            for (int i = 0; i < VEC / 4; ++i) mk[ch][i] = *reinterpret_cast<const unsigned *>(a.mask + e + 4 * i);
+            for (int i = 0; i < VEC / 4; ++i) mk[ch][i] = *reinterpret_cast<const u32_unaligned *>(a.mask + e + 4 * i);
         }
 #endif
     }
@@ -412,24 +433,51 @@ __device__ __forceinline__ void lean_load_test(const KArgs &a, long long vbase, 
     if (use_conf) {
 #pragma unroll
         for (int ch = 0; ch < CH; ++ch) {
-            unsigned qb = qw + (unsigned)(ch * 64 + lane) * VEC;
-            if (!inside[ch]) qb = a.P - VEC;
-            const long long e = vbase + qb;
+            const long long e = eload[ch];
             if (a.conf_f16) {
                 const unsigned short *c = reinterpret_cast<const unsigned short *>(a.conf) + e;
-                if constexpr (VEC == 8) cfa[ch] = *reinterpret_cast<const uint4 *>(c);
-                else { const uint2 w = *reinterpret_cast<const uint2 *>(c); cfa[ch].x = w.x; cfa[ch].y = w.y; }
+                if constexpr (VEC == 8) { const u32x4 w = *reinterpret_cast<const u32x4_unaligned *>(c); cfa[ch].x = w.x; cfa[ch].y = w.y; cfa[ch].z = w.z; cfa[ch].w = w.w; }
+                else { const u32x2 w = *reinterpret_cast<const u32x2_unaligned *>(c); cfa[ch].x = w.x; cfa[ch].y = w.y; }
             } else {
                 const float *c = reinterpret_cast<const float *>(a.conf) + e;
-                cfa[ch] = *reinterpret_cast<const uint4 *>(c);
-                if constexpr (VEC == 8) cfb[ch] = *reinterpret_cast<const uint4 *>(c + 4);
+                { const u32x4 w = *reinterpret_cast<const u32x4_unaligned *>(c); cfa[ch].x = w.x; cfa[ch].y = w.y; cfa[ch].z = w.z; cfa[ch].w = w.w; }
+                if constexpr (VEC == 8) { const u32x4 w = *reinterpret_cast<const u32x4_unaligned *>(c + 4); cfb[ch].x = w.x; cfb[ch].y = w.y; cfb[ch].z = w.z; cfb[ch].w = w.w; }
+            }
+        }
+    }
+    // ragged end of a view (P % VEC != 0): this wave holds it iff its span crosses P.  One lane re-reads its
+    // partial vector element by element (indices clamped to the view, validity comes from nvalid).
+    if ((a.P % (unsigned)VEC) != 0u && qw < a.P && qw + (unsigned)L_WSPAN > a.P) {
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) {
+            if (nvalid[ch] != 0u && nvalid[ch] != (unsigned)VEC) {
+                const unsigned qb = qw + (unsigned)(ch * 64 + lane) * VEC;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    const unsigned q = qb + (unsigned)k < a.P ? qb + (unsigned)k : a.P - 1u;
+                    const long long e = vbase + q;
+                    if constexpr (NEED_DEPTH) {
+                        unsigned raw;
+                        if constexpr (sizeof(DepthT) == 2) raw = reinterpret_cast<const unsigned short *>(a.depth)[e];
+                        else raw = reinterpret_cast<const unsigned *>(a.depth)[e];
+                        set_raw<DepthT>(d[ch], k, raw);
+                    }
+                    if constexpr (HAS_MASK) {
+                        unsigned &w = mk[ch][k >> 2];
+                        w = (w & ~(0xffu << (8 * (k & 3)))) | ((unsigned)a.mask[e] << (8 * (k & 3)));
+                    }
+                    if (use_conf) {
+                        if (a.conf_f16) set_raw<_Float16>(cfa[ch], k, reinterpret_cast<const unsigned short *>(a.conf)[e]);
+                        else set_raw<float>(k < 4 ? cfa[ch] : cfb[ch], k & 3, reinterpret_cast<const unsigned *>(a.conf)[e]);
+                    }
+                }
             }
         }
     }
     const bool use_depth = NEED_DEPTH && (a.flags & DD_VALID_DEPTH_POSITIVE);
 #pragma unroll
     for (int ch = 0; ch < CH; ++ch) {
-        unsigned b = inside[ch] ? ((1u << VEC) - 1u) : 0u;
+        unsigned b = (1u << nvalid[ch]) - 1u;
         if constexpr (HAS_MASK) {
 #pragma unroll
             for (int k = 0; k < VEC; ++k)
@@ -949,9 +997,10 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
 
     p.f16 = (b->depth_dtype == DD_F16);
     const int vec = p.f16 ? 8 : 4;
-    bool aligned = (b->stride == 1) && (hw % vec == 0) && ((uintptr_t)b->depth % 16 == 0);
-    if (b->flags & DD_VALID_MASK) aligned = aligned && ((uintptr_t)b->mask % 4 == 0);
-    if (b->flags & DD_VALID_CONF) aligned = aligned && ((uintptr_t)b->conf % 16 == 0);
+    // lean kernels: stride 1, any view size of at least one vector; pointers need element alignment only (views of
+    // H*W % vec != 0 pixels start off the 16-byte grid anyway; the wide loads are element-aligned)
+    bool aligned = (b->stride == 1) && (hw >= vec) && ((uintptr_t)b->depth % (p.f16 ? 2 : 4) == 0);
+    if (b->flags & DD_VALID_CONF) aligned = aligned && ((uintptr_t)b->conf % (b->conf_dtype == DD_F16 ? 2 : 4) == 0);
     if (b->tuning & TUNE_FORCE_GENERIC) aligned = false;
     p.lean = aligned;
     // fused call: single-pass on the lean path (measured 8-23 % faster than plan + scatter on MI355X with
