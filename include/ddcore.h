@@ -81,7 +81,7 @@ typedef struct DDViewBatch {
     uint32_t flags;
     int32_t view_index_base;  /* added to the per-point view index (global view id of view 0) */
     uint32_t tuning;          /* 0 = default; 1 = force the scalar kernels; 4 / 8 = dd_unproject_compact as
-                                 plan + scatter / as the single-pass look-back kernel (default on aligned maps) */
+                                 plan + scatter / as the single-pass look-back kernel (default on stride-1 maps) */
 } DDViewBatch;
 
 /*
@@ -136,7 +136,7 @@ int dd_scatter(const DDViewBatch *batch, const DDCloudOut *out, const int64_t *v
 /*
  * The whole hot path for one batch, appended to the cloud, enqueued on `stream` without a host
  * round trip, so chaining calls fuses any number of batches (scripts/test.py:238-240 list append +
- * :264-266 concatenate).  On aligned stride-1 maps this is ONE pass over the inputs (ticket +
+ * :264-266 concatenate).  On stride-1 maps (any view size) this is ONE pass over the inputs (ticket +
  * decoupled look-back inside the kernel); otherwise dd_plan + dd_scatter.  Same rows either way.
  *
  *  cursor_dev       (1) int64, device, in/out: advanced by the batch's number of points.
