@@ -160,10 +160,10 @@ def test_view_sharded_scan_matches_single_gpu(tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from scan_factory import make_scan
-    scan, cache, _ = make_scan(tmp_path / "scans", "plane", V=7, seed=3, floaters=0.03, second_size=(72, 104))   # two view sizes
+    scan, cache, _ = make_scan(tmp_path / "scans", "plane", V=7, seed=3, floaters=0.03, second_size=(71, 103))   # two view sizes, one with an odd pixel count
     root = Path(__file__).resolve().parent.parent
     args = ["--paths.recon-path", str(scan / "sparse" / "0"), "--paths.image-dir", str(scan / "images"),
-            "--moge.cache-dir", str(cache), "--processing.downsample-density", "2", "--refiner.no-use-fp16",
+            "--moge.cache-dir", str(cache), "--processing.downsample-density", "1", "--refiner.no-use-fp16",
             "--refiner.no-adaptive-correspondences", "--filtering.vote-threshold", "2", "--refiner.verbose", "0"]
     one = subprocess.run([sys.executable, str(root / "scripts" / "test.py"), *args, "--paths.output-model-dir", str(tmp_path / "one")],
                          capture_output=True, text=True, timeout=240)
