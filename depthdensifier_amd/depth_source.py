@@ -5,7 +5,9 @@ are not available offline, so the source is pluggable:
 
 * ``MoGeSource``   -- ``MoGeModel.from_pretrained(checkpoint).infer(image)`` when ``moge`` imports;
 * ``CachedSource`` -- precomputed maps ``<cache_dir>/<image stem>.npz`` with ``depth`` (H,W) f32/f16,
-  ``mask`` (H,W) bool, optional ``normal`` (H,W,3) -- e.g. dumped once on a machine that has MoGe.
+  ``mask`` (H,W) bool, optional ``normal`` (H,W,3) -- or the same arrays as ``<stem>_depth.npy`` /
+  ``<stem>_mask.npy`` / ``<stem>_normal.npy`` -- e.g. dumped once on a machine that has MoGe
+  (``dump_cache`` below, ``tools/dump_moge_cache.py``).
 
 Every source returns DEVICE tensors: the maps go from the producer to the densify kernels
 without the reference's ``.cpu().numpy()`` round trip (``scripts/test.py:166-168``).
@@ -51,11 +53,20 @@ class CachedSource(DepthSource):
             raise FileNotFoundError(f"depth cache directory not found: {self.dir}")
 
     def prepare(self, image_name, rgb_u8):
-        f = self.dir / (Path(image_name).stem + ".npz")
-        if not f.exists():
-            raise FileNotFoundError(f"no cached depth for {image_name}: {f}")
-        with np.load(f) as z:
-            maps = {k: z[k] for k in ("depth", "mask", "normal") if k in z.files}
+        stem = Path(image_name).stem
+        f = self.dir / (stem + ".npz")
+        if f.exists():
+            with np.load(f) as z:
+                maps = {k: z[k] for k in ("depth", "mask", "normal") if k in z.files}
+        else:
+            f = self.dir / (stem + "_depth.npy")
+            if not f.exists():
+                raise FileNotFoundError(f"no cached depth for {image_name}: {self.dir / (stem + '.npz')} or {f}")
+            maps = {"depth": np.load(f)}
+            for k in ("mask", "normal"):
+                g = self.dir / f"{stem}_{k}.npy"
+                if g.exists():
+                    maps[k] = np.load(g)
         h, w = rgb_u8.shape[:2]
         if maps["depth"].shape != (h, w):
             raise ValueError(f"{f}: depth is {maps['depth'].shape}, image at processing resolution is {(h, w)}")
@@ -68,6 +79,27 @@ class CachedSource(DepthSource):
         mask = g("mask")
         return {"depth": g("depth"), "normal": g("normal"),
                 "mask": mask.bool() if mask is not None else torch.ones((h, w), dtype=torch.bool, device=device)}
+
+
+def dump_cache(source: DepthSource, image_dir: Path, cache_dir: Path, device: torch.device, factor: int = 1,
+               fp16_depth: bool = False) -> int:
+    """Run ``source`` over every image of ``image_dir`` (resized like the pipeline, ``scripts/test.py:145-152``) and
+    write ``<stem>.npz`` maps that ``CachedSource`` reads back; returns the number of images written."""
+    from PIL import Image as PILImage
+    cache_dir.mkdir(parents=True, exist_ok=True)
+    n = 0
+    for f in sorted(p for p in Path(image_dir).iterdir() if p.suffix.lower() in (".png", ".jpg", ".jpeg")):
+        img = PILImage.open(f).convert("RGB")
+        w, h = img.size
+        rgb = np.array(img.resize((w // factor, h // factor), PILImage.Resampling.LANCZOS))
+        maps = source.infer(f.name, rgb, device)
+        out = {"depth": maps["depth"].float().cpu().numpy().astype(np.float16 if fp16_depth else np.float32),
+               "mask": maps["mask"].cpu().numpy().astype(bool)}
+        if maps.get("normal") is not None:
+            out["normal"] = maps["normal"].float().cpu().numpy()
+        np.savez(cache_dir / (f.stem + ".npz"), **out)
+        n += 1
+    return n
 
 
 def make_depth_source(checkpoint: Path, cache_dir: Optional[Path], device: torch.device) -> DepthSource:

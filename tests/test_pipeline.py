@@ -227,8 +227,20 @@ def test_moge_adapter_with_a_stub_model(monkeypatch, tmp_path):
     assert out["depth"].shape == (6, 8) and out["normal"].shape == (6, 8, 3) and out["mask"].dtype == torch.bool
     assert src.prepare("a.png", rgb) is None                              # nothing to read ahead for a live model
 
-    (tmp_path / "cache").mkdir()
-    assert isinstance(ds.make_depth_source(Path("models/x.pt"), tmp_path / "cache", cpu), ds.CachedSource)
+    # dump_cache writes what CachedSource reads back (.npz), and the per-map .npy flavour is accepted too
+    from PIL import Image as PILImage
+    (tmp_path / "imgs").mkdir()
+    PILImage.fromarray(rgb).save(tmp_path / "imgs" / "a.png")
+    assert ds.dump_cache(src, tmp_path / "imgs", tmp_path / "cache", cpu) == 1
+    cached = ds.make_depth_source(Path("models/x.pt"), tmp_path / "cache", cpu)
+    assert isinstance(cached, ds.CachedSource)
+    back = cached.infer("a.png", rgb, cpu)
+    assert torch.equal(back["depth"], out["depth"]) and torch.equal(back["mask"], out["mask"]) and back["normal"].shape == (6, 8, 3)
+    np.save(tmp_path / "cache" / "b_depth.npy", np.full((6, 8), 3.0, np.float32))
+    only_depth = cached.infer("b.jpg", rgb, cpu)
+    assert float(only_depth["depth"][0, 0]) == 3.0 and only_depth["normal"] is None and bool(only_depth["mask"].all())
+    with pytest.raises(FileNotFoundError, match="c_depth.npy"):
+        cached.infer("c.png", rgb, cpu)
     for name in ("moge", "moge.model", "moge.model.v2"):
         monkeypatch.setitem(sys.modules, name, None)                      # import now fails
     with pytest.raises(ImportError, match="cache-dir"):

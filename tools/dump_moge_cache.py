@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Dump MoGe maps once (on a machine that has `moge` and the weights) so that the pipeline can run from a cache:
+
+    python tools/dump_moge_cache.py --images SCAN/images --out SCAN/moge_cache [--checkpoint models/moge/.../model.pt]
+    python scripts/test.py ... --moge.cache-dir SCAN/moge_cache
+"""
+import argparse
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from depthdensifier_amd.depth_source import MoGeSource, dump_cache  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--images", type=Path, required=True)
+ap.add_argument("--out", type=Path, required=True)
+ap.add_argument("--checkpoint", type=Path, default=Path("models/moge/moge-2-vitl-normal/model.pt"))
+ap.add_argument("--factor", type=int, default=1, help="pipeline_downsample_factor the cache is for")
+ap.add_argument("--fp16-depth", action="store_true")
+a = ap.parse_args()
+device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+n = dump_cache(MoGeSource(a.checkpoint, device), a.images, a.out, device, a.factor, a.fp16_depth)
+print(f"wrote {n} maps to {a.out}")
