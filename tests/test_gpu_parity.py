@@ -164,7 +164,7 @@ def _rand_case(seed, V, H, W, dtype=np.float32, rho=0.8, specials=True):
 @pytest.mark.parametrize("stride", (1, 2, 7))
 @pytest.mark.parametrize("tuning", (0, 4))
 def test_oracle_sweep_script(dd, orc, shape, dtype, stride, tuning):
-    """Ragged sizes (scalar path), vector path (H*W % 8 == 0), both depth dtypes, strides,
+    """Ragged sizes (lean kernels with a ragged view end at stride 1, scalar kernels otherwise), H*W % 8 == 0 sizes, both depth dtypes, strides,
     two-pass and single-pass variants."""
     V, H, W = shape
     d = _rand_case(1000 + H * W + stride, V, H, W, dtype)
@@ -173,6 +173,27 @@ def test_oracle_sweep_script(dd, orc, shape, dtype, stride, tuning):
     ref = orc.densify_scene_script(d["depth"], d["params"], d["cam_from_world"], mask=d["mask"], normal=d["normal"],
                                    rgb=d["rgb"], stride=stride)
     assert_cloud(cloud, ref, scene_radius(d["cam_from_world"], d["depth"]))
+
+
+@pytest.mark.parametrize("dtype", (np.float32, np.float16))
+@pytest.mark.parametrize("shape", [(67, 129), (33, 35), (1, 9)])
+@pytest.mark.parametrize("tuning", (0, 4))
+def test_element_aligned_inputs(dd, orc, shape, dtype, tuning):
+    """Device tensors whose base pointers are only ELEMENT aligned: views 1.. of a stack with an odd pixel count
+    (depth on a 4- / 2-byte boundary, mask and colours on a 1-byte boundary, confidence likewise).  The lean kernels
+    take them with element-aligned wide loads; every output equals the oracle."""
+    import torch
+    H, W = shape
+    d = _rand_case(4242 + H * W, 4, H, W, dtype)
+    dev = torch.device("cuda")
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    depth, mask, normal, rgb, conf = (up(d[k])[1:] for k in ("depth", "mask", "normal", "rgb", "conf"))
+    assert depth.data_ptr() % 16 != 0 or (H * W * depth.element_size()) % 16 == 0
+    cloud = dd.unproject_views(depth, d["params"][1:], d["cam_from_world"][1:], mask=mask, normal=normal, rgb=rgb, conf=conf,
+                               conf_threshold=0.4, view_index=True, tuning=tuning)
+    ref = orc.densify_scene_script(d["depth"][1:], d["params"][1:], d["cam_from_world"][1:], mask=d["mask"][1:], normal=d["normal"][1:],
+                                   rgb=d["rgb"][1:], conf=d["conf"][1:], conf_threshold=0.4)
+    assert_cloud(cloud, ref, scene_radius(d["cam_from_world"][1:], d["depth"][1:]))
 
 
 @pytest.mark.parametrize("conf_dtype", (np.float32, np.float16))
