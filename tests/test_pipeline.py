@@ -231,12 +231,15 @@ def test_moge_adapter_with_a_stub_model(monkeypatch, tmp_path):
     from PIL import Image as PILImage
     (tmp_path / "imgs").mkdir()
     PILImage.fromarray(rgb).save(tmp_path / "imgs" / "a.png")
-    assert ds.dump_cache(src, tmp_path / "imgs", tmp_path / "cache", cpu) == 1
-    cached = ds.make_depth_source(Path("models/x.pt"), tmp_path / "cache", cpu)
-    assert isinstance(cached, ds.CachedSource)
-    back = cached.infer("a.png", rgb, cpu)
-    assert torch.equal(back["depth"], out["depth"]) and torch.equal(back["mask"], out["mask"]) and back["normal"].shape == (6, 8, 3)
-    np.save(tmp_path / "cache" / "b_depth.npy", np.full((6, 8), 3.0, np.float32))
+    for layout in ("npz", "npy"):
+        cdir = tmp_path / f"cache_{layout}"
+        assert ds.dump_cache(src, tmp_path / "imgs", cdir, cpu, layout=layout) == 1
+        assert (cdir / ("a.npz" if layout == "npz" else "a_depth.npy")).exists()
+        cached = ds.make_depth_source(Path("models/x.pt"), cdir, cpu)
+        assert isinstance(cached, ds.CachedSource)
+        back = cached.infer("a.png", rgb, cpu)
+        assert torch.equal(back["depth"], out["depth"]) and torch.equal(back["mask"], out["mask"]) and back["normal"].shape == (6, 8, 3)
+    np.save(cached.dir / "b_depth.npy", np.full((6, 8), 3.0, np.float32))
     only_depth = cached.infer("b.jpg", rgb, cpu)
     assert float(only_depth["depth"][0, 0]) == 3.0 and only_depth["normal"] is None and bool(only_depth["mask"].all())
     with pytest.raises(FileNotFoundError, match="c_depth.npy"):

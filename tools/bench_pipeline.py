@@ -13,10 +13,18 @@ with tempfile.TemporaryDirectory() as tmp:
     t0 = time.time()
     scan, _cache, _truth = make_scan(Path(tmp), "scan", V=V, H=1080, W=1920, seed=1)
     print(f"scan of {V} views generated in {time.time() - t0:.1f}s", flush=True)
-    for stride, nio in ((32, 0), (32, 4), (4, 4), (1, 0), (1, 4), (1, 8)):
+    import numpy as np
+    npy_cache = scan / "moge_cache_npy"
+    npy_cache.mkdir()
+    for f in sorted((scan / "moge_cache").glob("*.npz")):
+        with np.load(f) as z:
+            for k in z.files:
+                np.save(npy_cache / f"{f.stem}_{k}.npy", z[k])
+    for stride, nio in ((32, 0), (32, 4), (32, 8), (4, 8), (1, 8)):
+      for cache in ("moge_cache", "moge_cache_npy"):
         cfg = P.ScriptConfig()
         cfg.paths = P.PathsConfig(recon_path=scan / "sparse" / "0", image_dir=scan / "images", output_model_dir=Path(tmp) / f"out_s{stride}")
-        cfg.moge.cache_dir = scan / "moge_cache"
+        cfg.moge.cache_dir = scan / cache
         cfg.processing.downsample_density = stride
         cfg.processing.pipeline_downsample_factor = 1
         cfg.processing.io_threads = nio
@@ -26,4 +34,4 @@ with tempfile.TemporaryDirectory() as tmp:
             rep = P.main(cfg)
         torch.cuda.synchronize()
         t = {k: round(v, 3) for k, v in rep["timings"].items()}
-        print(json.dumps({"stride": stride, "io_threads": nio, "views": rep["views"], "dense_points": rep["dense_points"], "removed": rep["removed"], "seconds": t}), flush=True)
+        print(json.dumps({"stride": stride, "io_threads": nio, "cache": "npy" if cache.endswith("npy") else "npz", "views": rep["views"], "dense_points": rep["dense_points"], "removed": rep["removed"], "seconds": t}), flush=True)

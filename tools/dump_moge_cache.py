@@ -19,7 +19,8 @@ ap.add_argument("--out", type=Path, required=True)
 ap.add_argument("--checkpoint", type=Path, default=Path("models/moge/moge-2-vitl-normal/model.pt"))
 ap.add_argument("--factor", type=int, default=1, help="pipeline_downsample_factor the cache is for")
 ap.add_argument("--fp16-depth", action="store_true")
+ap.add_argument("--layout", choices=("npy", "npz"), default="npy", help="npy: one file per map, 10x faster to read back")
 a = ap.parse_args()
 device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
-n = dump_cache(MoGeSource(a.checkpoint, device), a.images, a.out, device, a.factor, a.fp16_depth)
+n = dump_cache(MoGeSource(a.checkpoint, device), a.images, a.out, device, a.factor, a.fp16_depth, a.layout)
 print(f"wrote {n} maps to {a.out}")
