@@ -124,13 +124,15 @@ def cpu_baseline(cfg: dict, scene: dict, params: np.ndarray, E: np.ndarray, budg
     -- exactly how the reference runs -- on the first views of the same workload, for about
     `budget_s` seconds of CPU work."""
     from oracle import densify_oracle as orc          # reported baseline only, never the product path
+    from threadpoolctl import threadpool_limits
 
     P = cfg["H"] * cfg["W"]
     n_views = 0
     t_total = 0.0
     pts = 0
     max_views = scene["depth"].shape[0]
-    while t_total < budget_s and n_views < max_views:
+    one_thread = threadpool_limits(limits=1)            # "cores": 1 means one thread: BLAS would otherwise fan the small
+    while t_total < budget_s and n_views < max_views:   # matmuls out over every host core it can see
         i = n_views
         d = scene["depth"][i].cpu().numpy()
         m = None if scene["mask"] is None else scene["mask"][i].cpu().numpy()
@@ -143,10 +145,11 @@ def cpu_baseline(cfg: dict, scene: dict, params: np.ndarray, E: np.ndarray, budg
         t_total += time.perf_counter() - t0
         pts += len(out.points)
         n_views += 1
+    one_thread.restore_original_limits()
     return {
         "value": round(n_views * P / t_total / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-        "sample": f"first {n_views} of {max_views} views of the same workload, {t_total:.1f} s single-process NumPy "
-                  f"{np.__version__} (the reference is single-threaded NumPy; oracle/densify_oracle.py)",
+        "sample": f"first {n_views} of {max_views} views of the same workload, {t_total:.1f} s single-process, single-thread NumPy "
+                  f"{np.__version__} (the reference is one Python process; oracle/densify_oracle.py)",
         "mpoints_per_s": round(pts / t_total / 1e6, 3),
     }
 
@@ -177,6 +180,59 @@ def _timed_gather(D, dd, dist, cloud, cfg, args, step, fence, total_views, n_tot
     return {"value": round(total_views * H * W / float(gt.item()) / 1e6, 1), "unit": "Mpixels/s",
             "ms_per_step": round(float(gt.item()) * 1e3, 3), "cloud_bytes": n_total * rec,
             "note": "densify + replicated all-gatherv of xyz/rgb/normal to every rank"}
+
+
+def _cpu_worker(job):
+    """One process of the all-cores courtesy baseline: the oracle over this worker's views (arrays staged as .npy in
+    shared memory by the parent; only the oracle calls are timed)."""
+    import numpy as _np
+    from oracle import densify_oracle as orc          # reported baseline only, never the product path
+    stage, views, params, E, fields, conf_thr = job
+    load = lambda k, i: _np.load(f"{stage}/{k}_{i}.npy", mmap_mode="r") if k in fields else None
+    t, pts = 0.0, 0
+    for i in views:
+        d, m, n, c, cf = (None if a is None else _np.array(a) for a in (load(k, i) for k in ("depth", "mask", "normal", "rgb", "conf")))
+        t0 = time.perf_counter()
+        out = orc.fuse_views([orc.densify_view_script(d, params[i], E[i], mask=m, normal=n, rgb=c, conf=cf, conf_threshold=conf_thr)])
+        t += time.perf_counter() - t0
+        pts += len(out.points)
+    return t, pts
+
+
+def cpu_baseline_all_cores(cfg: dict, scene: dict, params: np.ndarray, E: np.ndarray, budget_s: float, single_mpix_s: float,
+                           procs: int) -> dict:
+    """Courtesy upper bound (SURVEY.md 8d ii): the same oracle, one process per host core over views -- NOT something
+    the reference does (it is a single Python process).  Workers are spawned (no fork of a GPU process), the sample
+    views are staged in /dev/shm, throughput = sample pixels / slowest worker's oracle time."""
+    import multiprocessing as mp
+    import shutil
+    import tempfile
+    P = cfg["H"] * cfg["W"]
+    max_views = scene["depth"].shape[0]
+    per_proc = max(1, int(single_mpix_s * 1e6 * budget_s / P))            # views one core gets through in the budget
+    n_views = min(max_views, per_proc * procs)
+    procs = min(procs, n_views)
+    stage = tempfile.mkdtemp(prefix="dd_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        fields = [k for k in ("depth", "mask", "normal", "rgb", "conf") if scene.get(k) is not None]
+        for i in range(n_views):
+            for k in fields:
+                np.save(f"{stage}/{k}_{i}.npy", scene[k][i].cpu().numpy())
+        jobs = [(stage, list(range(r, n_views, procs)), params, E, fields, cfg.get("conf")) for r in range(procs)]
+        saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
+        os.environ.update({k: "1" for k in saved})          # one math thread per worker (inherited by the spawned children)
+        try:
+            with mp.get_context("spawn").Pool(procs) as pool:
+                res = pool.map(_cpu_worker, jobs)
+        finally:
+            for k, v in saved.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    finally:
+        shutil.rmtree(stage, ignore_errors=True)
+    wall = max(t for t, _ in res)
+    return {"value": round(n_views * P / wall / 1e6, 3), "unit": "Mpixels/s", "cores": procs, "kind": "port",
+            "sample": f"first {n_views} views over {procs} spawned processes (one per host core available to this job), "
+                      f"slowest worker {wall:.1f} s; a courtesy upper bound, the reference itself is one process"}
 
 
 # ------------------------------------------------------------------------------ main
@@ -228,6 +284,8 @@ def main() -> None:
     ap.add_argument("--views", type=int, default=0, help="override views per GPU (garden185) / total views (scene2000)")
     ap.add_argument("--pixel-index", action="store_true", help="also emit the int32 pixel index per point")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--cpu-procs", type=int, default=-1,
+                    help="also time the oracle over this many processes (courtesy all-cores figure); -1 = the cores this job may use, 0/1 = skip")
     ap.add_argument("--gather-steps", type=int, default=2, help="N>1: timed replicated all-gatherv passes (0 = skip)")
     ap.add_argument("--gather-timeout", type=float, default=240.0, help="watchdog for the all-gatherv leg, seconds")
     ap.add_argument("--mask-kind", default="blob", choices=("blob", "bernoulli"),
@@ -417,6 +475,13 @@ def main() -> None:
         }
         if args.cpu_seconds > 0 and world == 1:      # reported at N=1 only, on rank 0
             line["cpu_baseline"] = cpu_baseline(cfg, scene, params, E, args.cpu_seconds)
+            procs = args.cpu_procs if args.cpu_procs >= 0 else min(len(os.sched_getaffinity(0)), 16)      # a GPU box's CPU share is 16 cores
+            if procs > 1:
+                try:
+                    line["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(cfg, scene, params, E, args.cpu_seconds / 2,
+                                                                               line["cpu_baseline"]["value"], procs)
+                except Exception as e:      # noqa: BLE001  (a courtesy figure must not cost the result)
+                    line["cpu_baseline"]["all_cores"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     else:
         line = None
 
