@@ -476,7 +476,10 @@ def main() -> None:
         if args.cpu_seconds > 0 and world == 1:      # reported at N=1 only, on rank 0
             line["cpu_baseline"] = cpu_baseline(cfg, scene, params, E, args.cpu_seconds)
             procs = args.cpu_procs if args.cpu_procs >= 0 else min(len(os.sched_getaffinity(0)), 16)      # a GPU box's CPU share is 16 cores
-            if procs > 1:
+            profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+            if profiled:        # spawned workers would inherit the profiler's preload (and its GPU initialisation): keep to one process
+                line["cpu_baseline"]["all_cores"] = {"skipped": "running under a profiler"}
+            elif procs > 1:
                 try:
                     line["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(cfg, scene, params, E, args.cpu_seconds / 2,
                                                                                line["cpu_baseline"]["value"], procs)
