@@ -81,6 +81,35 @@ def test_gpu_fp32_matches_golden_and_stays_on_device(g, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_gpu_fp16_default_mode(g, name):
+    """The reference's DEFAULT on a GPU is half precision (``use_fp16=True``, depth_refiner.py:85-86).  No golden
+    exists for it (the goldens are the reference on CPU/FP32); this pins the contract -- float32 output, early exits
+    alias the input, same correspondence counts up to the few that sit on an edge -- and closeness to the FP32
+    result at half-precision accuracy."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from depthdensifier_amd.depth_refiner import DepthRefiner
+    r = DepthRefiner(adaptive_correspondences=False, **VARIANTS[name])          # use_fp16 defaults to True
+    assert r.device.type == "cuda" and r.dtype == torch.float16
+    depth = g[f"{name}_in_depth"].copy()
+    out = r.refine_depth(depth, None, g[f"{name}_in_points3D"], g[f"{name}_in_cam_from_world"][:3], g[f"{name}_in_K"],
+                         g.get(f"{name}_in_mask"))
+    exp = g[f"{name}_exp_refined_depth__refine_depth"]
+    aliased = bool(g[f"{name}_exp_returns_input_object"])
+    assert aliased == (out["refined_depth"] is depth)
+    if aliased:
+        return
+    assert out["refined_depth"].dtype == np.float32 and out["refined_depth"].shape == exp.shape
+    assert abs(out["num_correspondences"] - int(g[f"{name}_exp_num_correspondences__refine_depth"])) <= 0.05 * out["num_correspondences"] + 3
+    assert abs(out["scale_factor"] - float(g[f"{name}_exp_scale_factor__refine_depth"])) <= 2e-2 * abs(out["scale_factor"])
+    valid = exp > 0
+    assert np.array_equal(out["refined_depth"] > 0, valid) or (np.count_nonzero((out["refined_depth"] > 0) != valid) <= 1e-3 * valid.size)
+    rel = np.abs(out["refined_depth"][valid] - exp[valid]) / exp[valid]
+    assert np.median(rel) <= 5e-3 and np.quantile(rel, 0.99) <= 5e-2
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("skip", (False, True))
 @pytest.mark.parametrize("shape", [(96, 128), (37, 53), (1, 1), (33, 65)])
 @pytest.mark.parametrize("with_mask", (True, False))
