@@ -313,11 +313,12 @@ __global__ __launch_bounds__(BLOCK) void compact_generic(const KArgs a) {
 }
 
 // ==================================================================================================
-// Lean path (stride 1, vector-aligned maps).  Sized for latency tolerance: <= 80 VGPRs and 24 KiB of
-// LDS per 256-thread workgroup -> 6 workgroups (24 waves) per CU, every load of a tile issued
+// Lean path (stride 1, any view size; see lean_load_test for ragged / element-aligned views).  Sized for latency
+// tolerance: <= 80 VGPRs and 24 KiB of LDS per 256-thread workgroup -> 6 workgroups (24 waves) per CU in the
+// two-pass kernels (the single-pass variant runs 12-wave workgroups on 12288-pixel tiles, 2 per CU), every load of a tile issued
 // back to back, gathers of the next group of points in flight while the current group is stored.
 //
-//  * a tile is 4096 consecutive pixels of one view; wave w owns the contiguous span
+//  * a tile is 4096 (single-pass: 12288) consecutive pixels of one view; wave w owns the contiguous span
 //    [q0 + 1024 w, +1024); lane l owns CH groups of VEC pixels, group ch at
 //    q0 + 1024 w + (64 ch + l) VEC, so each load instruction of a wave is one contiguous run;
 //  * validity -> wave ballots -> tile-local rank; surviving pixels are listed in LDS (16-bit pixel
@@ -501,13 +502,15 @@ __device__ __forceinline__ void lean_load_test(const KArgs &a, long long vbase, 
     }
 }
 
-// Look-back for tiles of <= 4096 pixels.  Every lane inspects LB_K granules (window = 64*LB_K tiles per
+// Look-back over tile aggregates of at most 16 bits (tiles of <= 12288 pixels).  Every lane inspects LB_K granules (window = 64*LB_K tiles per
 // round trip, nearest tiles in lane 0).  Measured on MI355X (185x1080p): LB_K = 1 -> 3.57 ms, 4 -> 5.50 ms,
 // 8 -> 6.09 ms against 3.45 ms for the dependency-free two-pass path on the same GPU: the sc1 polling
 // loads are served across XCDs through the fabric and compete with the data streams, so a wider window
 // costs more than the round trips it saves.  Narrower is better still: 16 polling lanes (one or two
-// 128-B lines per poll) -> 3.02 ms.  LB_K stays 1, LB_LANES 16, and two-pass stays the default.
-// Aggregates fit 13 bits: their wave sum is taken with bit-sliced ballots (scalar popcounts) and the
+// 128-B lines per poll) -> 3.02 ms.  LB_K stays 1, LB_LANES 16.  With 12288-pixel tiles (one look-back per three
+// times the work) and the other waves gathering during the look-back, single-pass then beat two-pass on every
+// workload and became the default of dd_unproject_compact.
+// Aggregates fit 16 bits: their wave sum is taken with bit-sliced ballots (scalar popcounts) and the
 // single inclusive value with a readlane -- no cross-lane data movement.
 #ifndef DD_LB_K
 #define DD_LB_K 1
@@ -562,7 +565,7 @@ __device__ __forceinline__ long long lookback13(unsigned long long *state, unsig
             __builtin_amdgcn_s_sleep(DD_LB_SLEEP);
             continue;
         }
-        const unsigned mine = (lane <= L) ? agg_before : 0u;       // <= LB_K * 4096
+        const unsigned mine = (lane <= L) ? agg_before : 0u;       // <= LB_K * 12288 < 2^16
         unsigned sum = 0;
 #pragma unroll
         for (int b = 0; b < 16; ++b) sum += (unsigned)__popcll(__ballot((mine >> b) & 1u)) << b;
@@ -789,7 +792,7 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
     }
 }
 
-// ---- pass 1 of the two-pass mode (and dd_count_valid on aligned maps) ----------------------------
+// ---- pass 1 of the two-pass mode (and dd_count_valid on stride-1 maps) ----------------------------
 template <typename DepthT, bool HAS_MASK, bool NEED_DEPTH>
 __global__ __launch_bounds__(BLOCK) void count_lean(const KArgs a) {
     constexpr int VEC = 16 / (int)sizeof(DepthT), CH = L_PXT / VEC;
@@ -963,7 +966,7 @@ constexpr unsigned TUNE_SINGLE_PASS = 8u;     // dd_unproject_compact: ticket + 
 
 struct Plan {
     bool f16;
-    bool lean;      // stride-1, vector-aligned maps -> lean kernels; otherwise the generic scalar kernels
+    bool lean;      // stride-1 maps (any size >= one vector) -> lean kernels; otherwise the generic scalar kernels
     bool single;    // dd_unproject_compact runs the single-pass kernel
     int tile;
 };
