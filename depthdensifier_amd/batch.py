@@ -68,10 +68,22 @@ def format_report(rows: List[Tuple[str, Outcome]], total_s: float, width: int = 
 
 
 def assign_scans(jobs: List[ScanJob], world_size: int) -> List[int]:
-    """Owner rank of every job: longest scan first (image count; incomplete folders cost nothing) to the
-    least loaded rank, ties to the lower rank / earlier name -- a pure function of the folder listing."""
+    """Owner rank of every job: most expensive scan first (images x pixels per image; incomplete folders cost
+    nothing) to the least loaded rank, ties to the lower rank / earlier name -- a pure function of the folders."""
     def cost(job: ScanJob) -> int:
-        return sum(1 for f in job.images.iterdir() if f.is_file()) if job.complete else 0
+        if not job.complete:
+            return 0
+        n = sum(1 for f in job.images.iterdir() if f.is_file())
+        try:                                             # mean camera size from the (tiny) camera file; scenes differ 2.5x
+            from .colmap_io import Reconstruction
+            rec = Reconstruction()
+            if (job.recon / "cameras.bin").exists():
+                rec._read_cameras(job.recon / "cameras.bin")
+            cams = list(rec.cameras.values())
+            px = sum(c.width * c.height for c in cams) // len(cams) if cams else 1
+        except Exception:                                # noqa: BLE001 -- unreadable model: fall back to the image count
+            px = 1
+        return n * max(px, 1)
 
     costs = [cost(j) for j in jobs]
     load = [0] * world_size

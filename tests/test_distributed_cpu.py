@@ -78,6 +78,17 @@ def test_batch_assignment_is_balanced_and_deterministic(tmp_path):
     load = [sum(sizes[j.name] for j, o in zip(jobs, owner) if o == r and j.complete) for r in range(2)]
     assert abs(load[0] - load[1]) <= 2, load                             # 9+1+.. vs 5+4+3: longest-first deals evenly
     assert assign_scans(jobs, 1) == [0] * len(jobs)
+    # resolution counts: a 2-image scan of 4000x3000 pictures outweighs a 9-image scan of 640x480 ones
+    from depthdensifier_amd.colmap_io import Camera, Reconstruction
+    import numpy as np
+    for name, (w, h) in {"a": (640, 480), "b": (4000, 3000)}.items():
+        rec = Reconstruction()
+        rec.cameras[1] = Camera(1, 1, w, h, np.array([1.0, 1.0, w / 2, h / 2]))
+        rec.write_binary(tmp_path / name / "sparse" / "0")
+    (tmp_path / "b" / "images" / "1.png").write_bytes(b"")                       # b now has 2 images
+    jobs = [j for j in discover_scans(tmp_path, tmp_path / "out") if j.name in ("a", "b")]
+    owner = assign_scans(jobs, 2)
+    assert owner[[j.name for j in jobs].index("b")] == 0                          # dealt first -> rank 0
 
 
 @pytest.mark.parametrize("world", [2, 3])
