@@ -287,7 +287,7 @@ def main() -> None:
     ap.add_argument("--cpu-procs", type=int, default=-1,
                     help="also time the oracle over this many processes (courtesy all-cores figure); -1 = the cores this job may use, 0/1 = skip")
     ap.add_argument("--gather-steps", type=int, default=2, help="N>1: timed replicated all-gatherv passes (0 = skip)")
-    ap.add_argument("--gather-timeout", type=float, default=240.0, help="watchdog for the all-gatherv leg, seconds")
+    ap.add_argument("--gather-timeout", type=float, default=120.0, help="watchdog for the all-gatherv leg, seconds")
     ap.add_argument("--mask-kind", default="blob", choices=("blob", "bernoulli"),
                     help="blob: smooth regions (default); bernoulli: independent per-pixel cull, worst case for compaction")
     ap.add_argument("--colmap-path", type=Path, default=ROOT / "data" / "360_v2" / "garden" / "sparse" / "0",
