@@ -152,6 +152,7 @@ __device__ __forceinline__ bool pair_votes(const FArgs &a, const double *c, cons
                              // test and skip a whole wave at a time; the cull adds LDS-indexed view lookups + barriers)
 #endif
 
+#if DD_VOTES_CULL
 // Can ANY point of the sphere (centre cx,cy,cz, radius r) pass "in front of the camera and inside the image" of the
 // view with camera block c?  The exact per-pair conditions (zc > 0, 0 <= u < W, 0 <= w < H with
 // u = (K0 . Pcam) / (zc + 1e-8)) are, for zc > 0, linear inequalities in the world point:
@@ -182,6 +183,7 @@ __device__ __forceinline__ bool sphere_may_project(const double *c, const double
     }
     return !out;
 }
+#endif
 
 __global__ __launch_bounds__(256) void floater_votes_kernel(const FArgs a) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
