@@ -39,11 +39,18 @@ constexpr unsigned long long ST_INCL = 2ull << 62;  // value = slot after the ti
 constexpr unsigned long long VAL_MASK = (1ull << 62) - 1;
 constexpr unsigned SPIN_LIMIT = 1u << 21;
 
-struct WsHeader {          // 16 bytes at the start of the workspace, zeroed every call
-    unsigned int ticket;
+struct WsHeader {          // 32 bytes at the start of the workspace
+    // first 16 bytes: STICKY -- never zeroed by the library.  `error` (int32 word 1 of the workspace) is set when an
+    // in-kernel look-back gives up and stays set over later calls on the same workspace until the caller clears
+    // it, so a caller that chains many batches through one workspace checks it once at the end.
+    unsigned int pad0;
     int error;
-    unsigned int pad[2];
+    unsigned int pad1[2];
+    // second 16 bytes + the tile granules behind them: zeroed by every single-pass call (one 16-B aligned memset)
+    unsigned int ticket;
+    unsigned int pad2[3];
 };
+constexpr size_t WS_STICKY = 16;   // bytes in front of the per-call state
 
 struct KArgs {
     const void *depth;
@@ -78,6 +85,7 @@ struct KArgs {
     int conf_f16;
     int view_base;
     int sp_static;                // diagnostic: single-pass without tickets (tile = blockIdx.x)
+    int align_runs;               // lean kernels: shift the sweeps so that wave runs start on 128-byte lines (default on)
 };
 
 
@@ -379,6 +387,14 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef u32x4 u32x4_unaligned __attribute__((aligned(2)));
 typedef u32x2 u32x2_unaligned __attribute__((aligned(2)));
 
+// once-read streams (depth, mask, confidence): non-temporal unless built with -DDD_NT_LOAD=0.  A macro, not a
+// function template: the pointee's reduced alignment (element-aligned wide loads) must reach the builtin.
+#if DD_NT_LOAD
+#define LD_STREAM(p) __builtin_nontemporal_load(p)
+#else
+#define LD_STREAM(p) (*(p))
+#endif
+
 template <typename DepthT> __device__ __forceinline__ void set_raw(uint4 &d, int k, unsigned bits);
 template <> __device__ __forceinline__ void set_raw<float>(uint4 &d, int k, unsigned bits) {
     if (k == 0) d.x = bits; else if (k == 1) d.y = bits; else if (k == 2) d.z = bits; else d.w = bits;
@@ -437,12 +453,12 @@ __device__ __forceinline__ void lean_load_test(const KArgs &a, long long vbase, 
             const long long e = eload[ch];
             if (a.conf_f16) {
                 const unsigned short *c = reinterpret_cast<const unsigned short *>(a.conf) + e;
-                if constexpr (VEC == 8) { const u32x4 w = *reinterpret_cast<const u32x4_unaligned *>(c); cfa[ch].x = w.x; cfa[ch].y = w.y; cfa[ch].z = w.z; cfa[ch].w = w.w; }
-                else { const u32x2 w = *reinterpret_cast<const u32x2_unaligned *>(c); cfa[ch].x = w.x; cfa[ch].y = w.y; }
+                if constexpr (VEC == 8) { const u32x4 w = LD_STREAM(reinterpret_cast<const u32x4_unaligned *>(c)); cfa[ch].x = w.x; cfa[ch].y = w.y; cfa[ch].z = w.z; cfa[ch].w = w.w; }
+                else { const u32x2 w = LD_STREAM(reinterpret_cast<const u32x2_unaligned *>(c)); cfa[ch].x = w.x; cfa[ch].y = w.y; }
             } else {
                 const float *c = reinterpret_cast<const float *>(a.conf) + e;
-                { const u32x4 w = *reinterpret_cast<const u32x4_unaligned *>(c); cfa[ch].x = w.x; cfa[ch].y = w.y; cfa[ch].z = w.z; cfa[ch].w = w.w; }
-                if constexpr (VEC == 8) { const u32x4 w = *reinterpret_cast<const u32x4_unaligned *>(c + 4); cfb[ch].x = w.x; cfb[ch].y = w.y; cfb[ch].z = w.z; cfb[ch].w = w.w; }
+                { const u32x4 w = LD_STREAM(reinterpret_cast<const u32x4_unaligned *>(c)); cfa[ch].x = w.x; cfa[ch].y = w.y; cfa[ch].z = w.z; cfa[ch].w = w.w; }
+                if constexpr (VEC == 8) { const u32x4 w = LD_STREAM(reinterpret_cast<const u32x4_unaligned *>(c + 4)); cfb[ch].x = w.x; cfb[ch].y = w.y; cfb[ch].z = w.z; cfb[ch].w = w.w; }
             }
         }
     }
@@ -682,10 +698,26 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
     const float *__restrict__ nsrc = a.normal + vbase * 3;
     const unsigned char *__restrict__ csrc = a.rgb + vbase * 3;
 
-    struct Pt { float x, y, z; f32x3 nr; unsigned rgbw; unsigned q; };
+    // Which listed point a lane handles in sweep i.  Sweep 0 takes the tile's first BT points as they come (its
+    // gathers are issued before the tile's first row is known).  From sweep 1 on the points are shifted by `hrot`
+    // rows so that every wave's run of 64 rows starts on a 128-byte line of the (N,3) float32 outputs (32 rows = 3
+    // lines): a wave's store instruction then covers 6 whole lines instead of touching 7 (tools/ubench_tile.hip:
+    // 5.5 vs 4.8 TB/s of row stores).  The hrot points skipped behind sweep 0 are taken by the lanes that the
+    // shift pushes past the end of the list.
+    int hrot = 0;
+    auto point_of = [&](int i) -> int {
+        if (i == 0) return tid < (int)n ? tid : -1;
+        const int p = i * BT + tid + hrot;
+        if (p < (int)n) return p;
+        const int end = (int)n > BT + hrot ? (int)n : BT + hrot;
+        const int g = BT + (p - end);
+        return (g < BT + hrot && g < (int)n) ? g : -1;
+    };
+    struct Pt { float x, y, z; f32x3 nr; unsigned rgbw; unsigned q; int j; };
     auto prep = [&](int i, Pt &p) {
-        const int j = i * BT + tid;
-        const int jj = j < (int)n ? j : 0;
+        const int j = point_of(i);
+        p.j = j;
+        const int jj = j >= 0 ? j : 0;
         const unsigned q = q0 + s_q[jj];
         const float dd = s_d[jj];
         const unsigned r = q - rowstart;                 // < 4096 + W
@@ -703,10 +735,10 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
             p.rgbw = *reinterpret_cast<const u32_unaligned *>(csrc + (size_t)q * 3 - (q ? 1 : 0));
         }
     };
-    auto emit = [&](int i, const Pt &p) {
-        const int j = i * BT + tid;
+    auto emit = [&](const Pt &p) {
+        const int j = p.j;
         const long long slot = excl + j;
-        const bool act = (j < (int)n) && (slot < a.capacity);
+        const bool act = (j >= 0) && (slot < a.capacity);
         if (act) {
             f32x3 o; o.x = p.x; o.y = p.y; o.z = p.z;
 #if DD_NT_STORE
@@ -738,7 +770,10 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
             const unsigned c1w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)c0w, 0xF9, 0xF, 0xF, false);  // quad_perm [1,2,3,3]
             const unsigned c2w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)c0w, 0xFE, 0xF, 0xF, false);  // quad_perm [2,3,3,3]
             const unsigned c3w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)c0w, 0xFF, 0xF, 0xF, false);  // quad_perm [3,3,3,3]
-            const unsigned long long am = __ballot(act);
+            // a quad stores together only if its four lanes hold four consecutive rows (not so where the shifted
+            // sweep wraps around to the skipped points)
+            const int jq = __builtin_amdgcn_update_dpp(0, j, 0x00, 0xF, 0xF, false);               // quad_perm [0,0,0,0]
+            const unsigned long long am = __ballot(act && j == jq + (lane & 3));
             const unsigned quad = (unsigned)(am >> (lane & ~3)) & 0xFu;
             unsigned char *dst = a.out_rgb + slot * 3;
             if (quad == 0xFu) {
@@ -781,13 +816,14 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
         if (n == 0) return;
         prep(0, pa);
     }
+    if (a.align_runs) hrot = (int)((0ll - excl) & 31ll);
 #pragma unroll
     for (int i = 0; i < NI; i += 2) {
         prep(i + 1, pb);
-        emit(i, pa);
+        emit(pa);
         if ((i + 1) * BT >= (int)n) break;
         if (i + 2 < NI) prep(i + 2, pa);
-        emit(i + 1, pb);
+        emit(pb);
         if ((i + 2) * BT >= (int)n) break;
     }
 }
@@ -1010,6 +1046,7 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
     // 8192-pixel tiles and a 16-granule look-back window), two-pass on the generic path
     p.single = (b->tuning & TUNE_SINGLE_PASS) != 0 || (p.lean && !(b->tuning & TUNE_TWO_PASS));
     a.sp_static = (b->tuning & 16u) != 0;   // diagnostic only: relies on in-order dispatch
+    a.align_runs = (b->tuning & 32u) == 0;  // tuning bit 32: rows in list order (A/B of the line-aligned sweeps)
     p.tile = p.lean ? L_TILE : G_TILE;      // tiling of the two-pass kernels (count / plan / scatter)
     a.tiles_per_view = (a.P + p.tile - 1) / p.tile;
     const unsigned long long nt = (unsigned long long)a.tiles_per_view * (unsigned)a.V;
@@ -1018,9 +1055,9 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
     return DD_OK;
 }
 
-// workspace: [WsHeader][8 B per tile: look-back granules | (tile_cnt u32[T], tile_off u32[T])][8 B per view]
+// workspace: [WsHeader: 16 B sticky + 16 B per-call][8 B per tile, padded to 16: look-back granules | (tile_cnt u32[T], tile_off u32[T])][8 B per view]
 int64_t ws_bytes(const KArgs &a) {
-    return (int64_t)sizeof(WsHeader) + (int64_t)a.num_tiles * 8 + (int64_t)a.V * 8;
+    return (int64_t)sizeof(WsHeader) + (((int64_t)a.num_tiles * 8 + 15) & ~(int64_t)15) + (int64_t)a.V * 8;
 }
 
 int bind_workspace(KArgs &a, void *workspace, int64_t workspace_bytes) {
@@ -1031,7 +1068,7 @@ int bind_workspace(KArgs &a, void *workspace, int64_t workspace_bytes) {
     a.tile_state = reinterpret_cast<unsigned long long *>(w + sizeof(WsHeader));
     a.tile_cnt = reinterpret_cast<unsigned *>(w + sizeof(WsHeader));
     a.tile_off = a.tile_cnt + a.num_tiles;
-    a.view_tot = reinterpret_cast<long long *>(w + sizeof(WsHeader) + (size_t)a.num_tiles * 8);
+    a.view_tot = reinterpret_cast<long long *>(w + sizeof(WsHeader) + (((size_t)a.num_tiles * 8 + 15) & ~(size_t)15));
     return DD_OK;
 }
 
@@ -1183,8 +1220,10 @@ int dd_unproject_compact(const DDViewBatch *batch, const DDCloudOut *out, int64_
             a.tiles_per_view = (a.P + SP_WAVES * L_WSPAN - 1) / (SP_WAVES * L_WSPAN);
             a.num_tiles = a.tiles_per_view * (unsigned)a.V;
         }
-        // every look-back granule, the ticket and the error word start from zero on every call
-        if (hipMemsetAsync(workspace, 0, (size_t)(sizeof(WsHeader) + (size_t)a.num_tiles * 8), s) != hipSuccess)
+        // every look-back granule and the ticket start from zero on every call; the error word is sticky
+        // (16-B aligned start, byte count a multiple of 16: the cheap memset shape)
+        const size_t zero_bytes = (sizeof(WsHeader) - WS_STICKY + (size_t)a.num_tiles * 8 + 15) & ~(size_t)15;
+        if (hipMemsetAsync(reinterpret_cast<char *>(workspace) + WS_STICKY, 0, zero_bytes, s) != hipSuccess)
             return fail(DD_ERR_LAUNCH, "hipMemsetAsync(workspace) failed");
         launch_scatter<true>(p, a, s);
         if ((rc = check_launch("dd_unproject_compact")) != DD_OK) return rc;

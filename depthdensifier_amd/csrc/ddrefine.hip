@@ -35,6 +35,7 @@ __device__ __forceinline__ float read_depth(const RArgs &a, int idx) {
 // torch.searchsorted(xs, d, right=False) clamped to [1, n-1], then the linear blend of :160-176
 __device__ __forceinline__ float lut(const float *kx, const float *ky, int n, float d) {
 #pragma clang fp contract(off)   // the reference rounds after the multiply (separate tensor ops): no FMA here
+    if (d != d) return d;                   // torch.clamp / torch.maximum propagate a NaN depth (:168-176): the pixel later fails depth > 0
     int lo = 0, hi = n;                     // first index with kx[i] >= d
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
@@ -82,13 +83,14 @@ __global__ __launch_bounds__(256) void refine_apply_kernel(const RArgs a) {
             r = s_val[ly + 1][lx + 1];
         } else {                                                       // median of the 3x3 window (:194-200)
             float v[9];
+            bool has_nan = false;                                      // torch.median of a window holding a NaN is NaN
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) v[dy * 3 + dx] = s_val[ly + dy][lx + dx];
+                for (int dx = 0; dx < 3; ++dx) { v[dy * 3 + dx] = s_val[ly + dy][lx + dx]; has_nan |= v[dy * 3 + dx] != v[dy * 3 + dx]; }
             CSWAP(1, 2) CSWAP(4, 5) CSWAP(7, 8) CSWAP(0, 1) CSWAP(3, 4) CSWAP(6, 7) CSWAP(1, 2) CSWAP(4, 5) CSWAP(7, 8)
             CSWAP(0, 3) CSWAP(5, 8) CSWAP(4, 7) CSWAP(3, 6) CSWAP(1, 4) CSWAP(2, 5) CSWAP(4, 7) CSWAP(4, 2) CSWAP(6, 4) CSWAP(4, 2)
-            r = v[4];
+            r = has_nan ? __builtin_nanf("") : v[4];
         }
         const int idx = gy * a.W + gx;
         const bool m = a.mask ? (a.mask[idx] != 0) : (read_depth(a, idx) > 0.0f);

@@ -359,9 +359,12 @@ class CloudBuilder:
 
     def _workspace(self, nbytes: int) -> torch.Tensor:
         if self._ws_cache is None or self._ws_cache.numel() < nbytes:
-            # zero-filled once: the two-pass kernels never touch the header's error word, the single-pass
-            # variant re-zeroes it on every call
+            # zero-filled once: the header's error word is sticky (the library only ever sets it), so a
+            # look-back timeout in ANY append since the last finish() is still there when finish() looks
+            old = self._ws_cache
             self._ws_cache = torch.zeros(max(nbytes, 1024), dtype=torch.uint8, device=self.device)
+            if old is not None:
+                self._ws_cache[:16].copy_(old[:16])          # carry a pending error over to the larger buffer
         return self._ws_cache
 
     def append(self, batch: ViewBatch) -> torch.Tensor:
@@ -406,7 +409,9 @@ class CloudBuilder:
         total = int(self.cursor.item())
         for ws in {id(w): w for w in self._workspaces}.values():
             if int(ws[:8].view(torch.int32)[1].item()) != 0:
-                raise RuntimeError("libddcore: in-kernel scan timed out (workspace error word set)")
+                ws[:16].zero_()                              # sticky word: cleared only here, once reported
+                raise RuntimeError("libddcore: in-kernel scan timed out in one of the appended batches "
+                                   "(workspace error word set); rows are invalid -- redo with tuning=4")
         if total > self.capacity:
             raise OverflowError(f"cloud capacity {self.capacity} < {total} valid points; "
                                 "allocate with capacity=batch.max_points or count_valid() first")

@@ -55,10 +55,12 @@ def median3x3(img: torch.Tensor) -> torch.Tensor:
     p = F.pad(img[None, None], (1, 1, 1, 1), mode="replicate")[0, 0]
     h, w = img.shape
     v = [p[dy:dy + h, dx:dx + w] for dy in range(3) for dx in range(3)]
+    has_nan = torch.isnan(torch.stack(v)).any(dim=0)        # torch.median of a window holding a NaN is NaN
+    v = [torch.nan_to_num(x, nan=0.0, posinf=float("inf"), neginf=float("-inf")) for x in v]
     for a, b in _MED9:
         lo, hi = torch.minimum(v[a], v[b]), torch.maximum(v[a], v[b])
         v[a], v[b] = lo, hi
-    return v[4].contiguous()
+    return torch.where(has_nan, torch.full_like(v[4], float("nan")), v[4]).contiguous()
 
 
 class DepthRefiner:

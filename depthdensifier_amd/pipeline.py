@@ -70,6 +70,15 @@ class ScriptConfig:
     filtering: FilteringConfig = field(default_factory=FilteringConfig)
 
 
+def _processing_size(path: Path, factor: int) -> tuple[int, int]:
+    """(width, height) a view is processed at: the image FILE's size over ``pipeline_downsample_factor``
+    (``scripts/test.py:149-152``) -- header-only read, the pixels are not decoded."""
+    from PIL import Image as PILImage
+    with PILImage.open(path) as img:
+        w, h = img.size
+    return w // factor, h // factor
+
+
 def _load_rgb(path: Path, factor: int) -> np.ndarray:
     from PIL import Image as PILImage
     img = PILImage.open(path).convert("RGB")                                   # scripts/test.py:146
@@ -174,10 +183,12 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
     else:
         lo, hi = 0, num_views
     mine = todo[lo:hi]
+    # capacity from the size the views are really processed at -- the image files', which the reference reconciles
+    # with the model through camera.rescale (:172-173); the sparse model's camera may have another size
     capacity = 0
     for im in mine:
-        cam = rec.cameras[im.camera_id]
-        capacity += (-(-(cam.height // f) // s)) * (-(-(cam.width // f) // s))
+        pw, ph = _processing_size(config.paths.image_dir / im.name, f)
+        capacity += (-(-ph // s)) * (-(-pw // s))
     builder = CloudBuilder(capacity, normals=True, colors=True, pixel_index=False, device=device)
     cached = []                                                                 # :128 cached_refinement_data
     stage = {"image_decode": 0.0, "depth_source": 0.0, "refine": 0.0, "densify": 0.0}     # host seconds per stage
@@ -218,15 +229,12 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
                                    mask=maps["mask"], return_tensor=True)        # :179-186
         refined = res["refined_depth"]
         t4 = clock()
-        # depth > 0 on the whole mask is guaranteed only for an un-smoothed refinement: early exits hand back
-        # the raw map (depth_refiner.py:259-299) and the 3x3 median can zero an isolated masked pixel (:194-203)
-        was_refined = "outliers_removed" in res and refiner.skip_smoothing
         refined = refined if isinstance(refined, torch.Tensor) else torch.as_tensor(refined, device=device)
         refined = refined.float()
         # :194 "refined_depth[~moge_mask] = 0" is the kernels' validity rule (mask AND depth > 0);
         # :203-240 densify + append
         batch = ViewBatch(refined, camera.pinhole_params()[None], E[None], mask=maps["mask"], normal=normal, rgb=rgb,
-                          stride=s, view_index_base=lo + len(cached), device=device, depth_positive_on_mask=was_refined)
+                          stride=s, view_index_base=lo + len(cached), device=device)
         builder.append(batch)
         cached.append(dict(depth=refined, mask=maps["mask"], K=K, E=E))         # :197-201
         t5 = clock()
@@ -266,6 +274,12 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
     t0 = time.time()
     report.update(dense_points=len(kept), removed=removed, total_points=rec.num_points3D() + len(kept))
     if ranks.rank == 0:
+        if ranks.world > 1:
+            # The reference rescales the camera of EVERY processed view in place (:172-173) before the model is
+            # written; this rank did so for its own shard only.  Same calls, same order, for the other ranks' views.
+            for im in todo[hi:]:
+                pw, ph = _processing_size(config.paths.image_dir / im.name, f)
+                rec.cameras[im.camera_id].rescale(new_width=pw, new_height=ph)
         points = kept.points.cpu().numpy().astype(np.float64)
         colors = kept.colors.cpu().numpy()
         say(f"Adding {len(points)} new dense points...")

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 5
+#define DD_ABI_VERSION 6
 
 enum {
     DD_OK = 0,
@@ -143,7 +143,10 @@ int dd_scatter(const DDViewBatch *batch, const DDCloudOut *out, const int64_t *v
  *  view_offsets_dev (V+1) int64, device, out.
  *  workspace        as above.  ((int32_t*)workspace)[1] != 0 after the stream has drained means the
  *                   in-kernel look-back gave up after ~2 s of polling (should never happen; rows
- *                   are then invalid -- redo the batch with tuning = 4).
+ *                   are then invalid -- redo the batch with tuning = 4).  The first 16 bytes of the
+ *                   workspace are STICKY: the library never zeroes them, so the caller zeroes the
+ *                   workspace once before its first use and a set error word survives any number
+ *                   of later calls on the same workspace until the caller clears it.
  */
 int dd_unproject_compact(const DDViewBatch *batch, const DDCloudOut *out,
                          int64_t *view_offsets_dev, int64_t *cursor_dev,

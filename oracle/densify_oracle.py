@@ -21,7 +21,12 @@ That published behaviour is restated in :func:`rigid_inverse_apply`.
 
 Parity pin: ``tests/golden/*.npz`` hold outputs captured from the reference's
 own importable functions (``tests/golden/make_goldens.py``);
-``tests/test_oracle_golden.py`` checks this file against them.  The pycolmap
+``tests/test_oracle_golden.py`` checks this file against them.  The inline
+densify block itself (``scripts/test.py:194, 203-232``) is pinned by
+``script_block_small.npz`` -- the arrays its own statements leave behind when
+``make_goldens.py`` executes them, as they stand, on seeded inputs -- which
+``tests/test_reference_blocks.py`` requires this file to reproduce bit for
+bit (pixel order, colours, normals, float64 camera-frame points).  The pycolmap
 step itself has no reference-side test, so it is pinned through the package
 formulation (``visualizer.py:325-334`` computes the same map with
 ``np.linalg.inv`` and needs no pycolmap).

@@ -12,8 +12,11 @@ NumPy promotion matters for parity and is reproduced as NumPy >= 2 (NEP 50) does
 ``depth_threshold * refined_depth`` is a Python float times a float32 array and therefore a
 FLOAT32 product, which is then compared with the float64 projected depth.
 
-Parity pin: ``project_points`` is importable from the reference (goldens ``filter_small.npz``);
-the vote loop is inline in ``main`` and is pinned by restatement only.
+Parity pin: ``project_points`` is importable from the reference (goldens ``filter_small.npz``).  The vote
+loop is inline in ``main``; ``tests/golden/make_goldens.py`` picks its statements (``:273-332``) out of the
+reference's syntax tree, executes them as they stand on a seeded scene and commits what they leave behind
+(``votes_small.npz``: votes, keep mask, filtered points / colours); ``tests/test_reference_blocks.py`` requires
+this file to reproduce those arrays bit for bit.
 """
 
 from __future__ import annotations

@@ -13,8 +13,15 @@ of a function imported from the reference tree:
 * ``project_points``                         (scripts/test.py:58-76)   -> filter_small.npz
 * ``DepthRefiner.refine_depth``              (src/depthdensifier/depth_refiner.py:207-328, CPU/FP32) -> refiner_small.npz
 
-The densify block of ``scripts/test.py:203-233`` is inline in ``main`` and not
-callable.  Its validity/order/stride semantics are pinned through the package
+The densify block of ``scripts/test.py:203-233`` and the vote loop ``:273-332`` are inline
+in ``main`` and not callable.  They are pinned twice.  (1) ``build_script_block`` /
+``build_votes`` take the reference's OWN statements: the module source is parsed with ``ast`` at
+run time, the statements of those two ranges are picked out of ``main``'s syntax tree (the mask
+fold-in ``:194`` + ``:203-232`` up to, not including, the pycolmap call at ``:233``; ``:273-332``),
+compiled as they stand and executed in a namespace holding seeded inputs and duck-typed
+``camera`` / ``image`` objects -> ``script_block_small.npz``, ``votes_small.npz``.  Only arrays
+land in the repository, never the statements' text.  (2) The validity/order/stride semantics
+are also pinned through the package
 formulation, which is the same map: the reference's
 ``_depth_to_pointcloud`` is fed the mask-zeroed depth sub-sampled with
 ``[::s, ::s]``, the mask ``depth > 0`` and the intrinsics ``diag(1/s,1/s,1) @ K``
@@ -313,11 +320,212 @@ def build_refiner():
     return g
 
 
+# ----------------------------------------------- the reference's own inline statements (ast)
+
+def _main_tree():
+    import ast
+    tree = ast.parse((REF / "scripts" / "test.py").read_text())
+    return next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
+
+
+def _names(node):
+    import ast
+    out = set()
+    for n in ast.walk(node):
+        if isinstance(n, ast.Name):
+            out.add(n.id)
+        elif isinstance(n, ast.Attribute):
+            out.add(n.attr)
+    return out
+
+
+def _assigns(node, name):
+    import ast
+    if not isinstance(node, ast.Assign):
+        return False
+    return any(name in {getattr(e, "id", None) for e in ([t] if not isinstance(t, ast.Tuple) else t.elts)} for t in node.targets)
+
+
+def _compile(stmts, label):
+    import ast
+    mod = ast.Module(body=list(stmts), type_ignores=[])
+    ast.fix_missing_locations(mod)
+    return compile(mod, f"<reference scripts/test.py {label}>", "exec")
+
+
+def _densify_block_code():
+    """``refined_depth[~moge_mask] = 0`` (:194) and the densify statements :203-232 of the per-image loop, minus the
+    [DEBUG] twin on the unrefined depth (:223-227, it calls pycolmap's Rigid3d) -- stops before :233."""
+    import ast
+    main = _main_tree()
+    loop = next(n for n in ast.walk(main) if isinstance(n, ast.For) and getattr(n.target, "id", None) == "image")
+    body = loop.body
+    fold = next(st for st in body if isinstance(st, ast.Assign) and isinstance(st.targets[0], ast.Subscript)
+                and getattr(st.targets[0].value, "id", None) == "refined_depth" and "moge_mask" in _names(st))
+    first = next(i for i, st in enumerate(body) if _assigns(st, "h") and "refined_depth" in _names(st))
+    last = next(i for i, st in enumerate(body) if _assigns(st, "points3D_camera"))
+    block = [st for st in body[first:last + 1] if not any("unrefined" in n for n in _names(st))]
+    assert fold.lineno == 194 and block[0].lineno == 205 and block[-1].lineno == 232, (fold.lineno, block[0].lineno, block[-1].lineno)
+    assert not any("inverse" in _names(st) for st in block)
+    return _compile([fold] + block, "194+203-232")
+
+
+def _vote_block_code():
+    """``floater_votes = np.zeros(...)`` (:273) through ``final_colors = final_colors[points_to_keep_mask]`` (:332)."""
+    import ast
+    main = _main_tree()
+    branch = next(n for n in ast.walk(main) if isinstance(n, ast.If) and getattr(n.test, "id", None) == "all_dense_points")
+    body = branch.body
+    first = next(i for i, st in enumerate(body) if _assigns(st, "floater_votes"))
+    last = next(i for i, st in enumerate(body) if _assigns(st, "final_colors") and "points_to_keep_mask" in _names(st))
+    block = body[first:last + 1]
+    assert block[0].lineno == 273 and block[-1].lineno == 332, (block[0].lineno, block[-1].lineno)
+    return _compile(block, "273-332")
+
+
+def run_reference_densify_block(depth, mask, normal, rgb, params, stride):
+    """One pass of the reference's own statements over one view; returns what they leave behind."""
+    import time
+    import types as _t
+    ns = dict(np=np, time=time, refined_depth=np.array(depth, copy=True), moge_mask=np.asarray(mask, bool), moge_normal=normal,
+              pil_image_rescaled=rgb, camera=_Cam(params), unproject_points=REF_SCRIPT.unproject_points,
+              config=_t.SimpleNamespace(processing=_t.SimpleNamespace(downsample_density=int(stride))),
+              refiner_config={"verbose": 0})
+    with np.errstate(invalid="ignore", over="ignore"):
+        exec(_densify_block_code(), ns)
+    return {k: ns[k] for k in ("pixels_x_valid", "pixels_y_valid", "colors", "normals", "depth_values", "points3D_camera")}
+
+
+def build_script_block():
+    """script_block_small.npz: the densify block's own outputs at strides 1, 3, 32 (two ragged views with special
+    depths, one f16 view stack, one identity-pose stack so that camera frame == world frame)."""
+    g = {}
+    cases = [("p", 21, 2, 23, 37, (41.5, 43.25, 18.0, 11.5), True, np.float32),
+             ("q", 22, 2, 40, 72, (80.0, 82.0, 36.0, 20.0), False, np.float16),
+             ("r", 23, 1, 67, 131, (150.0, 149.0, 65.5, 33.5), True, np.float32)]
+    for name, seed, V, H, W, params, specials, dt in cases:
+        d = make_views(seed, V, H, W, specials=specials, depth_dtype=dt)
+        for k, v in d.items():
+            g[f"{name}_in_{k}"] = v
+        g[f"{name}_in_params"] = np.asarray(params, np.float64)
+        g[f"{name}_in_strides"] = np.asarray((1, 3, 32), np.int64)
+        for s in (1, 3, 32):
+            outs = [run_reference_densify_block(d["depth"][v], d["mask"][v], d["normal"][v], d["rgb"][v], params, s) for v in range(V)]
+            g[f"{name}_exp_s{s}_counts"] = np.asarray([len(o["pixels_x_valid"]) for o in outs], np.int64)
+            for key in ("pixels_x_valid", "pixels_y_valid", "colors", "normals", "depth_values", "points3D_camera"):
+                g[f"{name}_exp_s{s}_{key}__test_py_203_232"] = np.concatenate([o[key] for o in outs])
+    np.savez_compressed(OUT / "script_block_small.npz", **g)
+    return g
+
+
+class _ImageP(_Image):
+    """``project_points`` calls ``cam_from_world().matrix()``; the vote loop also ``projection_center()``
+    (pycolmap: the camera centre ``-R^T t``; an input to the statements, not part of them)."""
+
+    def projection_center(self):
+        E = np.asarray(self._E, np.float64)
+        return -(E[:3, :3].T @ E[:3, 3])
+
+
+def votes_scene(seed=5, V=8, H=48, W=64, n_extra=300):
+    """Cameras on a ring INSIDE a sphere of radius 4, looking across its centre: every ray ends on the far wall, so the
+    depth maps are dense (own synthetic code: ray/sphere intersections).  The cloud = wall points seen by the views
+    (consistent: no votes) + floaters around the centre, in front of the wall for every camera (votes from each view
+    whose direction their normal faces: upward normals face all cameras, random ones about half) + random points
+    anywhere, some outside the wall / behind cameras.  Points are float32-representable (the HIP kernel takes
+    float32 rows)."""
+    rng = np.random.default_rng(seed)
+    f, cx, cy = 40.0, W / 2.0, H / 2.0
+    K = np.array([[f, 0, cx], [0, f + 1.5, cy], [0, 0, 1.0]])
+    Es, depths, pts, nrm = [], [], [], []
+    ys, xs = np.mgrid[0:H, 0:W]
+    for v in range(V):
+        a = 2 * np.pi * v / V
+        c = np.array([2.0 * np.cos(a), 0.8 + 0.2 * np.sin(2 * a), 2.0 * np.sin(a)])
+        z = -c / np.linalg.norm(c)
+        x = np.cross([0.0, 1.0, 0.0], z); x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        R = np.stack([x, y, z])
+        E = np.hstack([R, (-R @ c)[:, None]])
+        rays = np.stack([(xs - cx) / K[0, 0], (ys - cy) / K[1, 1], np.ones_like(xs, float)], -1)
+        dirs = rays @ R                                            # world directions of the unit-z rays
+        b = dirs @ c
+        aa = np.sum(dirs * dirs, -1)
+        t = (-b + np.sqrt(b * b - aa * (c @ c - 16.0))) / aa       # far root: the camera is inside the sphere
+        depth = t.astype(np.float32)                               # z-depth: the ray's z component is 1
+        depth[rng.uniform(size=depth.shape) < 0.05] = 0.0          # holes, like a folded mask
+        Es.append(E); depths.append(depth)
+        sel = (depth > 0) & (rng.uniform(size=depth.shape) < 0.06)
+        p = c + dirs[sel] * depth[sel][:, None].astype(np.float64)
+        pts.append(p); nrm.append(-p / np.linalg.norm(p, axis=1, keepdims=True))
+    n_fl = 500
+    fl = rng.standard_normal((n_fl, 3)); fl *= (0.7 * rng.uniform(size=n_fl) ** (1 / 3) / np.linalg.norm(fl, axis=1))[:, None]
+    up = np.tile([0.0, 1.0, 0.0], (n_fl, 1)) + 0.2 * rng.standard_normal((n_fl, 3))
+    rnd = rng.standard_normal((n_fl, 3))
+    nf = np.where((np.arange(n_fl) % 2 == 0)[:, None], up, rnd)
+    pts.append(fl); nrm.append(nf / np.linalg.norm(nf, axis=1, keepdims=True))
+    extra = rng.standard_normal((n_extra, 3)) * 3.0
+    pts.append(extra); n = rng.standard_normal((n_extra, 3)); nrm.append(n / np.linalg.norm(n, axis=1, keepdims=True))
+    points = np.concatenate(pts).astype(np.float32)
+    normals = np.concatenate(nrm).astype(np.float32)
+    colors = rng.integers(0, 256, size=(len(points), 3), dtype=np.uint8)
+    return dict(points=points, normals=normals, colors=colors, depth=np.stack(depths), K=np.stack([K] * V), cam_from_world=np.stack(Es))
+
+
+def run_reference_vote_block(points64, normals, colors, depth, K, E, depth_threshold, vote_threshold):
+    import types as _t
+    cached = {i + 1: {"refined_depth": depth[i], "image": _ImageP(E[i]), "camera": _CamK(K[i])} for i in range(len(depth))}
+    ns = dict(np=np, tqdm=lambda it, **kw: it, project_points=REF_SCRIPT.project_points, cached_refinement_data=cached,
+              final_point_cloud=points64, final_normals=normals, final_colors=colors,
+              config=_t.SimpleNamespace(filtering=_t.SimpleNamespace(depth_threshold=depth_threshold, vote_threshold=vote_threshold)))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        exec(_vote_block_code(), ns)
+    return ns["floater_votes"], ns["points_to_keep_mask"], ns["final_point_cloud"], ns["final_colors"]
+
+
+def build_votes():
+    """votes_small.npz: floater_votes / keep mask / filtered points+colours left behind by the reference's own vote
+    loop (scripts/test.py:273-332) on the seeded sphere scene, at the default thresholds and at (0.9, 2)."""
+    g = {}
+    sc = votes_scene()
+    for k, v in sc.items():
+        g[f"in_{k}"] = v
+    for tag, dthr, vthr in (("default", 0.7, 5), ("tight", 0.9, 2)):
+        votes, keep, pts, cols = run_reference_vote_block(sc["points"].astype(np.float64), sc["normals"], sc["colors"], sc["depth"],
+                                                          sc["K"], sc["cam_from_world"], dthr, vthr)
+        g[f"{tag}_in_thresholds"] = np.asarray([dthr, vthr], np.float64)
+        g[f"{tag}_exp_floater_votes__test_py_273_332"] = np.asarray(votes, np.int64)
+        g[f"{tag}_exp_keep_mask__test_py_273_332"] = np.asarray(keep, bool)
+        g[f"{tag}_exp_points__test_py_273_332"] = pts
+        g[f"{tag}_exp_colors__test_py_273_332"] = cols
+    np.savez_compressed(OUT / "votes_small.npz", **g)
+    return g
+
+
+ALL_FIXTURES = ("densify_small.npz", "densify_vga.npz", "filter_small.npz", "refiner_small.npz", "script_block_small.npz",
+                "votes_small.npz")
+
+
+def build_all():
+    a = build_small()
+    b = build_vga()
+    build_filter()
+    build_refiner()
+    build_script_block()
+    build_votes()
+    return a, b
+
+
 if __name__ == "__main__":
     a = build_small()
     b = build_vga()
     build_filter()
     build_refiner()
-    for f in ("densify_small.npz", "densify_vga.npz", "filter_small.npz", "refiner_small.npz"):
+    build_script_block()
+    v = build_votes()
+    for f in ALL_FIXTURES:
         print(f, (OUT / f).stat().st_size, "bytes")
+    for tag in ("default", "tight"):
+        vv = v[f"{tag}_exp_floater_votes__test_py_273_332"]
+        print(f"votes[{tag}]: n={len(vv)} histogram={np.bincount(vv).tolist()} kept={int(v[f'{tag}_exp_keep_mask__test_py_273_332'].sum())}")
     print("keys:", len(a), len(b))

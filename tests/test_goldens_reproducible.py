@@ -21,10 +21,10 @@ def test_committed_goldens_equal_a_fresh_capture(tmp_path, monkeypatch):
     try:
         spec.loader.exec_module(mg)
         monkeypatch.setattr(mg, "OUT", tmp_path)
-        mg.build_small(); mg.build_vga(); mg.build_filter(); mg.build_refiner()
+        mg.build_all()
     finally:
         sys.path.remove(str(GOLDEN))
-    for name in ("densify_small.npz", "densify_vga.npz", "filter_small.npz", "refiner_small.npz"):
+    for name in mg.ALL_FIXTURES:
         fresh, kept = np.load(tmp_path / name), np.load(GOLDEN / name)
         assert sorted(fresh.files) == sorted(kept.files), name
         for k in kept.files:
