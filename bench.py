@@ -10,7 +10,11 @@ BASELINE.json configs[1] ("garden": 185 views, 1920x1080, depth f32 + normal f32
 (torch.distributed.run); every rank densifies its own 185-view shard of a 185*N-view scene
 (weak scaling; views are independent) and the fuse step exchanges the per-view
 counts (RCCL all-gather) so every rank holds the global view offsets of the distributed cloud.
-The replicated all-gatherv of the clouds is timed separately and reported under "gathered".
+Every line, at every N, also carries a "strong2000" sub-record: BASELINE configs[2], the 2000-view
+1080p scene split over the N ranks (strong scaling), timed three ways -- sharded fuse (count
+exchange only), replicated fuse in place (all-gatherv of xyz + normals + colours, 27 B/point) and
+replicated fuse of the compact 16-byte xyz+rgba record -- with the bytes each rank received and
+the per-link rate against xGMI's 153 GB/s.
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
 """
@@ -145,41 +149,130 @@ def cpu_baseline(cfg: dict, scene: dict, params: np.ndarray, E: np.ndarray, budg
         t_total += time.perf_counter() - t0
         pts += len(out.points)
         n_views += 1
+    # the reference's own op sequence (np.mgrid + int64 fancy-index gathers, scripts/test.py:205-233), same views, same thread
+    lit = None
+    if cfg["mask"] and cfg["normal"] and cfg["rgb"] and not cfg.get("conf"):
+        lit_t, lit_n = 0.0, 0
+        while lit_t < budget_s / 3.0 and lit_n < min(n_views, max_views):
+            i = lit_n
+            d, m = scene["depth"][i].cpu().numpy(), scene["mask"][i].cpu().numpy()
+            n, c = scene["normal"][i].cpu().numpy(), scene["rgb"][i].cpu().numpy()
+            t0 = time.perf_counter()
+            orc.fuse_views([orc.densify_view_script_literal(d, params[i], E[i], m, n, c)])
+            lit_t += time.perf_counter() - t0
+            lit_n += 1
+        lit = {"value": round(lit_n * P / lit_t / 1e6, 3), "unit": "Mpixels/s", "cores": 1,
+               "sample": f"first {lit_n} views, {lit_t:.1f} s",
+               "what": "the densify block restated with the reference's literal op sequence: np.mgrid index grids, boolean-mask "
+                       "gathers of the int64 grids, fancy-index gathers, np.stack + three float64 temporaries (scripts/test.py:205-233); "
+                       "same outputs as the tuned port above, which uses np.nonzero on a strided view"}
     one_thread.restore_original_limits()
     return {
         "value": round(n_views * P / t_total / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port",
         "sample": f"first {n_views} of {max_views} views of the same workload, {t_total:.1f} s single-process, single-thread NumPy "
                   f"{np.__version__} (the reference is one Python process; oracle/densify_oracle.py)",
         "mpoints_per_s": round(pts / t_total / 1e6, 3),
+        "reference_formulation": lit,
     }
 
 
-def _timed_gather(D, dd, dist, cloud, cfg, args, step, fence, total_views, n_total, H, W, device) -> dict:
-    rec = 12 + (12 if cfg["normal"] else 0) + (3 if cfg["rgb"] else 0) + (4 if args.pixel_index else 0)
-    free, _ = torch.cuda.mem_get_info(device)
-    fmin = torch.tensor([free], dtype=torch.int64, device=device)
-    dist.all_reduce(fmin, op=dist.ReduceOp.MIN)          # one decision for all ranks
-    free = int(fmin.item())
-    if n_total * rec > 0.8 * free:
-        return {"skipped": f"replicated cloud of {n_total * rec / 1e9:.1f} GB does not fit the free HBM ({free / 1e9:.1f} GB)"}
-    sharded = D.fuse_sharded(cloud, total_views)
-    bufs = {"points": torch.empty((n_total, 3), dtype=torch.float32, device=device)}
-    if cfg["rgb"]:
-        bufs["colors"] = torch.empty((n_total, 3), dtype=torch.uint8, device=device)
-    if cfg["normal"]:
-        bufs["normals"] = torch.empty((n_total, 3), dtype=torch.float32, device=device)
-    D.gather_cloud(sharded, out=bufs)
-    fence()
-    g0 = time.perf_counter()
-    for _ in range(args.gather_steps):
-        step(False)
-        D.gather_cloud(sharded, out=bufs)
-    fence()
-    gt = torch.tensor([(time.perf_counter() - g0) / args.gather_steps], dtype=torch.float64, device=device)
-    dist.all_reduce(gt, op=dist.ReduceOp.MAX)
-    return {"value": round(total_views * H * W / float(gt.item()) / 1e6, 1), "unit": "Mpixels/s",
-            "ms_per_step": round(float(gt.item()) * 1e3, 3), "cloud_bytes": n_total * rec,
-            "note": "densify + replicated all-gatherv of xyz/rgb/normal to every rank"}
+def strong_scaling_record(args, dd, D, dist, use_dist, rank, world, device, fence) -> dict:
+    """BASELINE configs[2] on the N ranks of this job: `--strong-views` (2000) synthetic 1080p views, rank r holds the
+    contiguous shard shard_views(V, N, r), inputs resident in HBM.  Timed three ways (max over ranks, mean of the timed
+    passes): "sharded" = one fused kernel over the shard + the all-gather of per-view counts (cloud stays distributed,
+    globally indexed); "gathered" = distributed.fuse_replicated, every point written once at its final global row and
+    the chunks exchanged in place while the next chunk's kernel runs (xyz + normals + colours, 27 B/point);
+    "gathered_compact" = the same with one 16-byte xyz+rgba record per point."""
+    cfg = dict(WORKLOADS["scene2000"])
+    cfg["mask_kind"] = "blob"
+    V_total = args.strong_views
+    lo, hi = D.shard_views(V_total, world, rank)
+    H, W = cfg["H"], cfg["W"]
+    ids = np.arange(lo, hi)
+    t_gen = time.perf_counter()
+    scene = make_scene(cfg, ids, device)
+    params = np.tile([0.8 * W, 0.8 * W, W / 2.0, H / 2.0], (len(ids), 1))
+    batch = dd.ViewBatch(scene["depth"], params, ring_poses(ids, V_total), mask=scene["mask"], normal=scene["normal"], rgb=scene["rgb"],
+                         view_index_base=int(lo), device=device)
+    torch.cuda.synchronize(device)
+    t_gen = time.perf_counter() - t_gen
+    rec = {"views_total": V_total, "views_per_gpu": len(ids), "height": H, "width": W, "scaling": "strong", "chunks": args.chunks,
+           "scene_generation_s": round(t_gen, 2)}
+
+    def timed(fn, passes):
+        fn()                                            # warm-up (allocations, RCCL channels)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            out = fn()
+        fence()
+        dt = (time.perf_counter() - t0) / passes
+        if use_dist:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
+
+    # -- sharded fuse: the cloud stays distributed; max capacity, no sizing pass
+    builder = dd.CloudBuilder(batch.max_points, normals=True, colors=True, pixel_index=False, device=device)
+
+    def sharded():
+        builder.reset()
+        offs = builder.append(batch)
+        counts = offs[1:] - offs[:-1]
+        return D.offsets_from_counts(D.exchange_counts(counts, V_total) if use_dist else counts)
+
+    dt, goffs = timed(sharded, args.strong_steps)
+    builder.check()
+    n_total = int(goffs[-1].item())
+    n_own = int((goffs[hi] - goffs[lo]).item())
+    pixels = V_total * H * W
+    rec["points_total"] = n_total
+    rec["sharded"] = {"ms": round(dt * 1e3, 3), "mpixels_per_s": round(pixels / dt / 1e6, 1), "mpoints_per_s": round(n_total / dt / 1e6, 1),
+                      "what": "fused kernel over the shard + all-gather of per-view counts; cloud left distributed, globally indexed"}
+    del builder
+    torch.cuda.empty_cache()
+
+    for key, record, rec_bytes in (("gathered", "rows", 27), ("gathered_compact", "xyz_rgba", 16)):
+        need = n_total * rec_bytes
+        free = torch.cuda.mem_get_info(device)[0]
+        if use_dist:
+            fmin = torch.tensor([free], dtype=torch.int64, device=device)
+            dist.all_reduce(fmin, op=dist.ReduceOp.MIN)
+            free = int(fmin.item())
+        if need > 0.9 * free:
+            rec[key] = {"skipped": f"replicated cloud of {need / 1e9:.1f} GB does not fit the free HBM ({free / 1e9:.1f} GB)"}
+            continue
+        if record == "rows":
+            bufs = {"points": torch.empty((n_total, 3), dtype=torch.float32, device=device),
+                    "normals": torch.empty((n_total, 3), dtype=torch.float32, device=device),
+                    "colors": torch.empty((n_total, 3), dtype=torch.uint8, device=device)}
+        else:
+            bufs = {"packed": torch.empty((n_total, 4), dtype=torch.float32, device=device)}
+
+        def replicated():
+            if use_dist:
+                return D.fuse_replicated(batch, V_total, record=record, chunks=args.chunks, buffers=bufs)
+            counts = dd.count_valid(batch)              # N = 1: the same steps minus the wire
+            b = dd.CloudBuilder(n_total, points=record == "rows", normals=record == "rows", colors=record == "rows", pixel_index=False,
+                                packed=record != "rows", buffers=bufs, device=device)
+            for clo, chi in D._chunk_bounds(0, len(ids), args.chunks):
+                b.append(batch.slice(clo, chi))
+            return b.check(), counts
+
+        dt, _ = timed(replicated, args.strong_steps)
+        recv = (n_total - n_own) * rec_bytes
+        rec[key] = {"ms": round(dt * 1e3, 3), "mpixels_per_s": round(pixels / dt / 1e6, 1), "mpoints_per_s": round(n_total / dt / 1e6, 1),
+                    "record_bytes": rec_bytes, "cloud_bytes": need, "bytes_received_per_rank": recv,
+                    "ingress_GBps_per_rank": round(recv / dt / 1e9, 1),
+                    "GBps_per_link": round(recv / max(world - 1, 1) / dt / 1e9, 1) if world > 1 else None,
+                    "xgmi_link_peak_GBps": 153.0,
+                    "what": "count pass + count all-gather + fused kernel writing at final global rows, per-chunk grouped send/recv "
+                            "in place overlapped with the next chunk's kernel" if world > 1 else
+                            "N = 1: count pass + fused kernel per chunk (no wire)"}
+        del bufs
+        torch.cuda.empty_cache()
+    return rec
 
 
 def _cpu_worker(job):
@@ -286,8 +379,10 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--cpu-procs", type=int, default=-1,
                     help="also time the oracle over this many processes (courtesy all-cores figure); -1 = the cores this job may use, 0/1 = skip")
-    ap.add_argument("--gather-steps", type=int, default=2, help="N>1: timed replicated all-gatherv passes (0 = skip)")
-    ap.add_argument("--gather-timeout", type=float, default=120.0, help="watchdog for the all-gatherv leg, seconds")
+    ap.add_argument("--strong-views", type=int, default=2000, help="views of the strong-scaling sub-record (BASELINE configs[2]); 0 = skip")
+    ap.add_argument("--strong-steps", type=int, default=3, help="timed passes per leg of the strong-scaling sub-record")
+    ap.add_argument("--chunks", type=int, default=5, help="view chunks per rank whose exchange overlaps the next chunk's kernel")
+    ap.add_argument("--gather-timeout", type=float, default=240.0, help="watchdog for the strong-scaling leg, seconds")
     ap.add_argument("--mask-kind", default="blob", choices=("blob", "bernoulli"),
                     help="blob: smooth regions (default); bernoulli: independent per-pixel cull, worst case for compaction")
     ap.add_argument("--colmap-path", type=Path, default=ROOT / "data" / "360_v2" / "garden" / "sparse" / "0",
@@ -306,7 +401,7 @@ def main() -> None:
         args.gpus = world
     real_out = _claim_stdout()
     guard = None
-    if rank == 0 and args.gather_steps > 0 and (world > 1 or os.environ.get("DD_BENCH_FORCE_DIST") == "1"):
+    if rank == 0 and args.strong_views > 0 and (world > 1 or os.environ.get("DD_BENCH_FORCE_DIST") == "1"):
         guard = _spawn_line_guard(real_out)      # before anything touches the GPU
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
@@ -368,8 +463,9 @@ def main() -> None:
     batch = dd.ViewBatch(scene["depth"], params, E, mask=scene["mask"], normal=scene["normal"], rgb=scene["rgb"],
                          conf=scene["conf"], conf_threshold=cfg.get("conf"),
                          view_index_base=int(lo), device=device, tuning=args.tuning)
-    n_local = int(dd.count_valid(batch).sum().item())
-    builder = dd.CloudBuilder(n_local, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index,
+    # capacity = every visited pixel: no sizing pass exists anywhere, timed or not (SURVEY.md 8d defines the metric over
+    # count + scan + unproject + compact, which the fused kernel does in its one pass)
+    builder = dd.CloudBuilder(batch.max_points, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index,
                               device=device)
 
     ev = []
@@ -421,13 +517,13 @@ def main() -> None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    cloud = builder.finish()
-    assert len(cloud) == n_local
+    n_local = builder.check()
     n_total = int(goffs[-1].item())
     if os.environ.get("DD_BENCH_TRACE_STEPS") and rank == 0:      # per-step kernel times (diagnostic)
         print("steps_ms", [round(e[0].elapsed_time(e[2]), 3) for e in ev], file=sys.stderr)
     plan_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-    kernel_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) if not single_pass else plan_ms
+    k_all = [e[1].elapsed_time(e[2]) for e in ev] if not single_pass else [e[0].elapsed_time(e[1]) for e in ev]
+    kernel_ms = float(np.mean(k_all))
     if single_pass:
         plan_ms = 0.0
 
@@ -437,12 +533,15 @@ def main() -> None:
         pixels = total_views * H * W
         alg = algorithmic_bytes(cfg, V, n_local, args.pixel_index)
         achieved = alg / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         tfile = ROOT / "profiles" / "traffic.json"
         if tfile.exists():
-            rec = json.loads(tfile.read_text()).get(args.workload + ("" if single_pass else ":two-pass"))
+            tkey = args.workload + (":bernoulli" if args.mask_kind == "bernoulli" else "") + ("" if single_pass else ":two-pass")
+            rec = json.loads(tfile.read_text()).get(tkey)
             if rec:     # PMC bytes were collected on the full workload; a launch over fewer views moves proportionally fewer
                 traffic = int(rec["hbm_bytes_per_launch"] * V / rec["views"])
+                traffic_source = (f"profiles/traffic.json[{tkey}]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this kernel on this workload, "
+                                  "collected in separate profiling runs (tools/pmc_traffic.sh) -- NOT measured in this run")
         line = {
             "metric": "Mpixels/s unprojected+fused",
             "value": round(pixels / (elapsed / args.steps) / 1e6, 1),
@@ -467,8 +566,13 @@ def main() -> None:
                                    if single_pass else "compact_lean (dd_scatter: cull+unproject+transform+compact+write)",
                          "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": traffic, "algorithmic_bytes_per_launch": alg,
-                         "kernel_ms": round(kernel_ms, 4), "timer": "HIP events on the launch stream, mean over timed steps",
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_over_algorithmic": None if traffic is None else round(traffic / alg, 4),
+                         "algorithmic_bytes_per_launch": alg,
+                         "kernel_ms": round(kernel_ms, 4), "kernel_ms_min": round(float(np.min(k_all)), 4),
+                         "kernel_ms_median": round(float(np.median(k_all)), 4),
+                         "timer": "HIP events on the launch stream; achieved uses the mean over the timed steps",
+                         "sizing_pass": "none: the cloud is allocated for every visited pixel (capacity = V*H*W rows)",
                          "pass1_ms": round(plan_ms, 4),
                          "pass1_note": "two-pass mode only: count_lean + scan kernels re-read depth+mask (not credited)",
                          "whole_step_frac": round(alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
@@ -488,21 +592,24 @@ def main() -> None:
     else:
         line = None
 
-    # replicated fuse (the north-star all-gatherv of the per-GPU clouds), timed separately AFTER the main
-    # result exists.  Doubly guarded: an exception is reported in the line; a collective that does not
-    # finish within the watchdog's limit makes every rank print/exit with the main result intact.
-    if use_dist and args.gather_steps > 0 and os.environ.get("DD_BENCH_SHARE_GPU") != "1":
+    # BASELINE configs[2] (2000-view strong scaling: sharded / gathered / gathered-compact), timed AFTER the main
+    # result exists.  Doubly guarded: an exception is reported in the line; a collective that does not finish within
+    # the watchdog's limit makes every rank print the main result and exit NON-ZERO (a hung GPU process is a failed leg).
+    if args.strong_views > 0:
         import threading
+
+        del batch, builder, scene
+        torch.cuda.empty_cache()
 
         def bail():
             if rank == 0:
-                line["gathered"] = {"error": f"all-gatherv leg did not finish within {args.gather_timeout:.0f} s"}
+                line["strong2000"] = {"error": f"strong-scaling leg did not finish within {args.gather_timeout:.0f} s"}
                 print(json.dumps(line), file=real_out, flush=True)
                 _release_line_guard(guard)
-            os._exit(0)
+            os._exit(3)
 
         if guard is not None:       # from here on a hard crash of rank 0 still leaves the main result on stdout
-            held = dict(line, gathered={"error": "rank 0 died inside the all-gatherv leg (main result printed by the guard process)"})
+            held = dict(line, strong2000={"error": "rank 0 died inside the strong-scaling leg (main result printed by the guard process)"})
             guard.stdin.write((json.dumps(held) + "\n").encode())
             guard.stdin.flush()
         if os.environ.get("DD_BENCH_TEST_ABORT") == "1":      # test hook for the guard
@@ -512,12 +619,12 @@ def main() -> None:
         dog.daemon = True
         dog.start()
         try:
-            gathered = _timed_gather(D, dd, dist, cloud, cfg, args, step, fence, total_views, n_total, H, W, device)
+            strong = strong_scaling_record(args, dd, D, dist, use_dist, rank, world, device, fence)
         except Exception as e:      # noqa: BLE001  (reported, not fatal)
-            gathered = {"error": f"{type(e).__name__}: {e}"[:300]}
+            strong = {"error": f"{type(e).__name__}: {e}"[:300]}
         dog.cancel()
         if rank == 0:
-            line["gathered"] = gathered
+            line["strong2000"] = strong
     if rank == 0:
         print(json.dumps(line), file=real_out, flush=True)
         _release_line_guard(guard)

@@ -64,6 +64,7 @@ struct KArgs {
     uint8_t *out_rgb;
     int32_t *out_pix;
     int32_t *out_view;
+    uint32_t *out_packed;         // (capacity,4) dwords: x, y, z (float bits), r | g<<8 | b<<16 | 255<<24 -- the 16-byte gather record
     long long capacity;
     long long *view_offsets;
     const long long *cursor;
@@ -293,10 +294,20 @@ __global__ __launch_bounds__(BLOCK) void compact_generic(const KArgs a) {
         const float rx = fmaf(m00, fx, fmaf(m01, fy, m02));
         const float ry = fmaf(m10, fx, fmaf(m11, fy, m12));
         const float rz = fmaf(m20, fx, fmaf(m21, fy, m22));
-        float *o = a.out_xyz + slot * 3;
-        o[0] = fmaf(d, rx, c0);
-        o[1] = fmaf(d, ry, c1);
-        o[2] = fmaf(d, rz, c2);
+        const float ox = fmaf(d, rx, c0), oy = fmaf(d, ry, c1), oz = fmaf(d, rz, c2);
+        if (a.out_xyz) {
+            float *o = a.out_xyz + slot * 3;
+            o[0] = ox; o[1] = oy; o[2] = oz;
+        }
+        if (a.out_packed) {
+            unsigned c = 0xff000000u;
+            if (a.rgb) {
+                const uint8_t *cp = a.rgb + (vbase + pix) * 3;
+                c |= (unsigned)cp[0] | ((unsigned)cp[1] << 8) | ((unsigned)cp[2] << 16);
+            }
+            uint4 rec; rec.x = __float_as_uint(ox); rec.y = __float_as_uint(oy); rec.z = __float_as_uint(oz); rec.w = c;
+            *reinterpret_cast<uint4 *>(a.out_packed + slot * 4) = rec;
+        }
         if (a.out_normal) {
             const float *np = a.normal + (vbase + pix) * 3;
             float n0 = np[0], n1 = np[1], n2 = np[2];
@@ -741,11 +752,19 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
         const bool act = (j >= 0) && (slot < a.capacity);
         if (act) {
             f32x3 o; o.x = p.x; o.y = p.y; o.z = p.z;
+            if (a.out_xyz) {
 #if DD_NT_STORE
-            __builtin_nontemporal_store(o, reinterpret_cast<f32x3 *>(a.out_xyz + slot * 3));
+                __builtin_nontemporal_store(o, reinterpret_cast<f32x3 *>(a.out_xyz + slot * 3));
 #else
-            *reinterpret_cast<f32x3 *>(a.out_xyz + slot * 3) = o;
+                *reinterpret_cast<f32x3 *>(a.out_xyz + slot * 3) = o;
 #endif
+            }
+            if (a.out_packed) {     // one aligned 16-byte store per point: a wave writes 1 KiB of whole lines
+                unsigned c = 0xff000000u;
+                if constexpr (HAS_RGB) c |= p.q ? (p.rgbw >> 8) : (p.rgbw & 0xffffffu);
+                uint4 rec; rec.x = __float_as_uint(p.x); rec.y = __float_as_uint(p.y); rec.z = __float_as_uint(p.z); rec.w = c;
+                *reinterpret_cast<uint4 *>(a.out_packed + slot * 4) = rec;
+            }
             if (a.out_pix) a.out_pix[slot] = (int)p.q;
             if (a.out_view) a.out_view[slot] = a.view_base + (int)v;
         }
@@ -764,7 +783,7 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
             if (act) *reinterpret_cast<f32x3 *>(a.out_normal + slot * 3) = nv;
 #endif
         }
-        if constexpr (HAS_RGB) {
+        if (HAS_RGB && a.out_rgb != nullptr) {
             // rows of 4 consecutive lanes -> 12 contiguous bytes, stored by the quad's first lane
             const unsigned c0w = p.q ? (p.rgbw >> 8) : (p.rgbw & 0xffffffu);
             const unsigned c1w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)c0w, 0xF9, 0xF, 0xF, false);  // quad_perm [1,2,3,3]
@@ -1073,12 +1092,14 @@ int bind_workspace(KArgs &a, void *workspace, int64_t workspace_bytes) {
 }
 
 int bind_output(KArgs &a, const DDViewBatch *batch, const DDCloudOut *out) {
-    if (!out || !out->xyz) return fail(DD_ERR_INVALID_ARG, "out / out->xyz is NULL");
+    if (!out || (!out->xyz && !out->xyz_rgba)) return fail(DD_ERR_INVALID_ARG, "out is NULL or neither out->xyz nor out->xyz_rgba is given");
+    if (out->xyz_rgba && ((uintptr_t)out->xyz_rgba % 16) != 0) return fail(DD_ERR_INVALID_ARG, "out->xyz_rgba must be 16-byte aligned");
     if (out->capacity < 0) return fail(DD_ERR_INVALID_ARG, "capacity is negative");
     if (out->normal && !batch->normal) return fail(DD_ERR_INVALID_ARG, "out->normal requested but batch->normal is NULL");
     if (out->rgb && !batch->rgb) return fail(DD_ERR_INVALID_ARG, "out->rgb requested but batch->rgb is NULL");
     a.out_xyz = out->xyz; a.out_normal = out->normal; a.out_rgb = out->rgb;
     a.out_pix = out->pixel_index; a.out_view = out->view_index; a.capacity = out->capacity;
+    a.out_packed = out->xyz_rgba;
     return DD_OK;
 }
 
@@ -1086,7 +1107,7 @@ template <typename DepthT, bool SP, bool HM, bool HN>
 void launch_lean3(const KArgs &a, hipStream_t s) {
     constexpr int NW = SP ? SP_WAVES : WAVES;
     const dim3 grid(a.num_tiles), block(64 * NW);
-    if (a.out_rgb) hipLaunchKernelGGL((compact_lean<DepthT, HM, SP, HN, true, NW>), grid, block, 0, s, a);
+    if (a.rgb && (a.out_rgb || a.out_packed)) hipLaunchKernelGGL((compact_lean<DepthT, HM, SP, HN, true, NW>), grid, block, 0, s, a);   // colours gathered
     else hipLaunchKernelGGL((compact_lean<DepthT, HM, SP, HN, false, NW>), grid, block, 0, s, a);
 }
 

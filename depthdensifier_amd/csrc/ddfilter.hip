@@ -274,6 +274,8 @@ struct CArgs {
     float *o_xyz, *o_normal;
     uint8_t *o_rgb;
     int32_t *o_pix, *o_view;
+    uint32_t *o_packed;                  // (capacity,4) dwords x, y, z, r|g<<8|b<<16|255<<24 or NULL
+    long long capacity;                  // rows at or beyond it are counted, not written
     long long n;
     int thr;
     unsigned num_tiles, num_groups;
@@ -395,16 +397,25 @@ __global__ __launch_bounds__(C_BLOCK) void compact_scatter(const CArgs a) {
         const long long r = base + i * 64 + lane;
         if ((bal[i] >> lane) & 1ull) {
             const long long o = dst + __popcll(bal[i] & lt);
-            *reinterpret_cast<cf3 *>(a.o_xyz + o * 3) = *reinterpret_cast<const cf3 *>(a.xyz + r * 3);
-            if (a.o_normal) *reinterpret_cast<cf3 *>(a.o_normal + o * 3) = *reinterpret_cast<const cf3 *>(a.normal + r * 3);
-            if (a.o_rgb) {
-                const unsigned c = r ? (*reinterpret_cast<const cu1u *>(a.rgb + r * 3 - 1) >> 8)
-                                     : (*reinterpret_cast<const cu1u *>(a.rgb) & 0xffffffu);
-                uint8_t *d = a.o_rgb + o * 3;
-                d[0] = (uint8_t)c; d[1] = (uint8_t)(c >> 8); d[2] = (uint8_t)(c >> 16);
+            if (o < a.capacity) {
+                const cf3 p = *reinterpret_cast<const cf3 *>(a.xyz + r * 3);
+                if (a.o_xyz) *reinterpret_cast<cf3 *>(a.o_xyz + o * 3) = p;
+                if (a.o_normal) *reinterpret_cast<cf3 *>(a.o_normal + o * 3) = *reinterpret_cast<const cf3 *>(a.normal + r * 3);
+                unsigned c = 0;
+                if (a.rgb && (a.o_rgb || a.o_packed))
+                    c = r ? (*reinterpret_cast<const cu1u *>(a.rgb + r * 3 - 1) >> 8)
+                          : (*reinterpret_cast<const cu1u *>(a.rgb) & 0xffffffu);
+                if (a.o_rgb) {
+                    uint8_t *d = a.o_rgb + o * 3;
+                    d[0] = (uint8_t)c; d[1] = (uint8_t)(c >> 8); d[2] = (uint8_t)(c >> 16);
+                }
+                if (a.o_packed) {
+                    uint4 rec; rec.x = __float_as_uint(p.x); rec.y = __float_as_uint(p.y); rec.z = __float_as_uint(p.z); rec.w = c | 0xff000000u;
+                    *reinterpret_cast<uint4 *>(a.o_packed + o * 4) = rec;
+                }
+                if (a.o_pix) a.o_pix[o] = a.pix[r];
+                if (a.o_view) a.o_view[o] = a.view[r];
             }
-            if (a.o_pix) a.o_pix[o] = a.pix[r];
-            if (a.o_view) a.o_view[o] = a.view[r];
         }
         dst += __popcll(bal[i]);
     }
@@ -450,12 +461,13 @@ int dd_compact_cloud(const DDCloudOut *in, int64_t n, const int32_t *votes_dev, 
                      int64_t *new_view_offsets_dev, int32_t num_views, void *workspace, int64_t workspace_bytes,
                      void *stream) {
     auto fail = [](const char *m) { snprintf(g_ferr, sizeof(g_ferr), "%s", m); return DD_ERR_INVALID_ARG; };
-    if (!in || !out || !in->xyz || !out->xyz) return fail("in / out / xyz is NULL");
+    if (!in || !out || !in->xyz || (!out->xyz && !out->xyz_rgba)) return fail("in / out / xyz is NULL");
+    if (out->xyz_rgba && ((uintptr_t)out->xyz_rgba % 16) != 0) return fail("out->xyz_rgba must be 16-byte aligned");
     if (n < 0 || !kept_dev) return fail("n is negative or kept_dev is NULL");
     if (n > 0 && !votes_dev) return fail("votes_dev is NULL");
     if ((out->normal && !in->normal) || (out->rgb && !in->rgb) || (out->pixel_index && !in->pixel_index) ||
         (out->view_index && !in->view_index)) return fail("an output field has no input field");
-    if (out->capacity < n) return fail("out->capacity must be >= n (the kept count is not known on the host)");
+    if (out->capacity < 0) return fail("out->capacity is negative");
     if ((old_view_offsets_dev == nullptr) != (new_view_offsets_dev == nullptr)) return fail("old/new view offsets must be given together");
     const int64_t need = dd_compact_workspace_bytes(n);
     if (!workspace || workspace_bytes < need || ((uintptr_t)workspace % 16)) {
@@ -468,6 +480,7 @@ int dd_compact_cloud(const DDCloudOut *in, int64_t n, const int32_t *votes_dev, 
     CArgs a;
     a.votes = votes_dev; a.xyz = in->xyz; a.normal = in->normal; a.rgb = in->rgb; a.pix = in->pixel_index; a.view = in->view_index;
     a.o_xyz = out->xyz; a.o_normal = out->normal; a.o_rgb = out->rgb; a.o_pix = out->pixel_index; a.o_view = out->view_index;
+    a.o_packed = out->xyz_rgba; a.capacity = out->capacity;
     a.n = n; a.thr = vote_threshold; a.num_tiles = (unsigned)tiles; a.num_groups = (unsigned)groups;
     char *w = reinterpret_cast<char *>(workspace) + 16;
     a.tile_cnt = reinterpret_cast<unsigned *>(w);

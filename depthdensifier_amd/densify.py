@@ -94,9 +94,18 @@ class FusedCloud:
     view_index: Optional[torch.Tensor]     # (N,) int32
     view_offsets: torch.Tensor             # (V+1,) int64
     name: str = "Dense Cloud"
+    packed: Optional[torch.Tensor] = None  # (N,4) float32 rows x, y, z, bits(r | g<<8 | b<<16 | 255<<24): the 16-byte gather record
 
     def __len__(self) -> int:
         return int(self.points.shape[0])
+
+    @classmethod
+    def from_packed(cls, packed: torch.Tensor, view_offsets: torch.Tensor, name: str = "Dense Cloud", **fields) -> "FusedCloud":
+        """A cloud held as 16-byte records (``DDCloudOut.xyz_rgba``): ``points`` / ``colors`` are strided views of it."""
+        n = packed.shape[0]
+        rgba = packed.view(torch.uint8).view(n, 16)
+        return cls(points=packed[:, :3], colors=rgba[:, 12:15], normals=fields.get("normals"), pixel_index=fields.get("pixel_index"),
+                   view_index=fields.get("view_index"), view_offsets=view_offsets, name=name, packed=packed)
 
     @property
     def counts(self) -> torch.Tensor:
@@ -226,6 +235,18 @@ class ViewBatch:
         self.flags = flags
         self.device = dev
 
+    def slice(self, lo: int, hi: int) -> "ViewBatch":
+        """Views ``[lo, hi)`` of this batch as a batch of their own -- no copy, the maps are shared (used to
+        overlap the exchange of one chunk of views with the kernel of the next, ``distributed.fuse_replicated``)."""
+        if not 0 <= lo <= hi <= self.num_views:
+            raise ValueError(f"slice [{lo}, {hi}) outside a batch of {self.num_views} views")
+        sub = object.__new__(ViewBatch)
+        sub.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("_cstruct", "_ws_bytes")})
+        cut = lambda t: None if t is None else t[lo:hi]
+        sub.depth, sub.mask, sub.conf, sub.normal, sub.rgb, sub.params = (cut(t) for t in (self.depth, self.mask, self.conf, self.normal, self.rgb, self.params))
+        sub.view_index_base = self.view_index_base + lo
+        return sub
+
     # -- sizes -------------------------------------------------------------------------
     @property
     def num_views(self) -> int:
@@ -279,6 +300,8 @@ def _stream(device: torch.device) -> int:
 def count_valid(batch: ViewBatch) -> torch.Tensor:
     """(V,) int64 device tensor: valid visited pixels per view (the N of ``scripts/test.py:210-212``)."""
     counts = torch.empty(batch.num_views, dtype=torch.int64, device=batch.device)
+    if batch.num_views == 0:
+        return counts
     cb = batch.c_struct()
     check(lib.dd_count_valid(C.byref(cb), counts.data_ptr(), _stream(batch.device)))
     return counts
@@ -328,24 +351,55 @@ class CloudBuilder:
     the host.  ``finish()`` reads the count once and returns exact-size views.
     """
 
+    FIELDS = {"points": ((3,), torch.float32), "normals": ((3,), torch.float32), "colors": ((3,), torch.uint8),
+              "pixel_index": ((), torch.int32), "view_index": ((), torch.int32), "packed": ((4,), torch.float32)}
+
     def __init__(self, capacity: int, *, normals: bool = False, colors: bool = False,
-                 pixel_index: bool = True, view_index: bool = False, device=None):
+                 pixel_index: bool = True, view_index: bool = False, packed: bool = False, points: bool = True,
+                 buffers: Optional[dict] = None, start=None, device=None):
+        """``packed``: also (or, with ``points=False``, only) write the 16-byte ``x, y, z, rgba`` record per point
+        (``DDCloudOut.xyz_rgba``).  ``buffers``: caller-owned tensors to write into instead of allocating, keyed like
+        ``FIELDS`` -- the multi-GPU fuse hands in the GLOBAL cloud so that every point is written once, at its final
+        row.  ``start``: first row (int or (1,) int64 device tensor), e.g. ``rank_offsets[rank]``."""
         dev = _require_gpu(device)
         self.device = dev
         self.capacity = int(capacity)
         n = max(self.capacity, 1)
-        self.xyz = torch.empty((n, 3), dtype=torch.float32, device=dev)
-        self.normal = torch.empty((n, 3), dtype=torch.float32, device=dev) if normals else None
-        self.rgb = torch.empty((n, 3), dtype=torch.uint8, device=dev) if colors else None
-        self.pix = torch.empty((n,), dtype=torch.int32, device=dev) if pixel_index else None
-        self.view = torch.empty((n,), dtype=torch.int32, device=dev) if view_index else None
+        want = {"points": points, "normals": normals, "colors": colors, "pixel_index": pixel_index, "view_index": view_index, "packed": packed}
+        if not (points or packed):
+            raise ValueError("a cloud needs points or the packed record")
+        got = {}
+        for name, on in want.items():
+            tail, dtype = self.FIELDS[name]
+            t = None if buffers is None else buffers.get(name)
+            if t is not None:
+                if t.dtype != dtype or tuple(t.shape) != (t.shape[0],) + tail or t.shape[0] < self.capacity or not t.is_contiguous() or t.device != dev:
+                    raise ValueError(f"buffer '{name}' must be a contiguous {dtype} tensor of shape (>= {self.capacity},{','.join(map(str, tail))}) on {dev}")
+                got[name] = t
+            elif on and buffers is None:
+                got[name] = torch.empty((n,) + tail, dtype=dtype, device=dev)
+            elif on:
+                raise ValueError(f"buffers given without '{name}'")
+            else:
+                got[name] = None
+        self.xyz, self.normal, self.rgb, self.pix, self.view, self.packed = (got[k] for k in ("points", "normals", "colors", "pixel_index", "view_index", "packed"))
         self.cursor = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._start = start
+        self._set_start()
         self._offsets: list[torch.Tensor] = []
         self._workspaces: list[torch.Tensor] = []
         self._ws_cache: Optional[torch.Tensor] = None
 
+    def _set_start(self) -> None:
+        if self._start is None:
+            self.cursor.zero_()
+        elif isinstance(self._start, torch.Tensor):
+            self.cursor.copy_(self._start.reshape(1), non_blocking=True)
+        else:
+            self.cursor.fill_(int(self._start))
+
     def reset(self) -> None:
-        self.cursor.zero_()
+        self._set_start()
         self._offsets.clear()
         self._workspaces.clear()
 
@@ -374,6 +428,11 @@ class CloudBuilder:
             raise ValueError("this cloud carries normals but the batch has no normal map")
         if self.rgb is not None and batch.rgb is None:
             raise ValueError("this cloud carries colours but the batch has no rgb image")
+        if batch.num_views == 0:                       # an empty chunk of views: nothing to enqueue, the cursor stays
+            offsets = self._offsets_slice(1)
+            offsets.copy_(self.cursor, non_blocking=True)
+            self._offsets.append(offsets)
+            return offsets
         cb = batch.c_struct()
         ws = self._workspace(batch.workspace_bytes())
         out = self._out_struct()
@@ -388,7 +447,8 @@ class CloudBuilder:
         if getattr(self, "_out_cached", None) is None:
             ptr = lambda t: None if t is None else t.data_ptr()
             self._out_cached = DDCloudOut(xyz=ptr(self.xyz), normal=ptr(self.normal), rgb=ptr(self.rgb),
-                                          pixel_index=ptr(self.pix), view_index=ptr(self.view), capacity=self.capacity)
+                                          pixel_index=ptr(self.pix), view_index=ptr(self.view), capacity=self.capacity,
+                                          xyz_rgba=ptr(self.packed))
         return self._out_cached
 
     def scatter(self, batch: ViewBatch, plan: "BatchPlan") -> torch.Tensor:
@@ -404,9 +464,28 @@ class CloudBuilder:
         self._workspaces.append(plan.workspace)
         return plan.view_offsets
 
+    def check(self) -> int:
+        """Synchronise once: the row after the last appended point; raises if an in-kernel scan gave up or the
+        cloud overflowed."""
+        total = int(self.cursor.item())
+        self._check_status(total)
+        return total
+
     def finish(self, name: str = "Dense Cloud") -> FusedCloud:
         """Synchronise once, check the scan status words and the capacity, return exact-size views."""
-        total = int(self.cursor.item())
+        total = self.check()
+        if self._offsets:
+            offs = torch.cat([self._offsets[0]] + [o[1:] for o in self._offsets[1:]])
+        else:
+            offs = torch.zeros(1, dtype=torch.int64, device=self.device)
+        first = 0 if self._start is None else int(offs[0].item())
+        cut = lambda t: None if t is None else t[first:total]
+        if self.xyz is None:
+            return FusedCloud.from_packed(cut(self.packed), offs, name, normals=cut(self.normal), pixel_index=cut(self.pix), view_index=cut(self.view))
+        return FusedCloud(points=cut(self.xyz), colors=cut(self.rgb), normals=cut(self.normal),
+                          pixel_index=cut(self.pix), view_index=cut(self.view), view_offsets=offs, name=name, packed=cut(self.packed))
+
+    def _check_status(self, total: int) -> None:
         for ws in {id(w): w for w in self._workspaces}.values():
             if int(ws[:8].view(torch.int32)[1].item()) != 0:
                 ws[:16].zero_()                              # sticky word: cleared only here, once reported
@@ -415,13 +494,6 @@ class CloudBuilder:
         if total > self.capacity:
             raise OverflowError(f"cloud capacity {self.capacity} < {total} valid points; "
                                 "allocate with capacity=batch.max_points or count_valid() first")
-        if self._offsets:
-            offs = torch.cat([self._offsets[0]] + [o[1:] for o in self._offsets[1:]])
-        else:
-            offs = torch.zeros(1, dtype=torch.int64, device=self.device)
-        cut = lambda t: None if t is None else t[:total]
-        return FusedCloud(points=self.xyz[:total], colors=cut(self.rgb), normals=cut(self.normal),
-                          pixel_index=cut(self.pix), view_index=cut(self.view), view_offsets=offs, name=name)
 
 
 # --------------------------------------------------------------------------------------
@@ -434,7 +506,7 @@ def unproject_views(depth: ArrayLike, intrinsics: ArrayLike, cam_from_world: Arr
                     rgb: Optional[ArrayLike] = None, downsample_density: int = 1,
                     semantics: str = "script", rotate_normals: Optional[bool] = None,
                     capacity: Union[None, int, str] = None, pixel_index: bool = True,
-                    view_index: bool = False, device=None, tuning: int = 0) -> FusedCloud:
+                    view_index: bool = False, device=None, tuning: int = 0, record: str = "rows") -> FusedCloud:
     """Densify + fuse a stack of views: ``scripts/test.py:203-244`` per view and ``:262-266``.
 
     ``downsample_density`` is ``ProcessingConfig.downsample_density`` (``scripts/test.py:37``; the
@@ -442,13 +514,19 @@ def unproject_views(depth: ArrayLike, intrinsics: ArrayLike, cam_from_world: Arr
     (``dd_count_valid``, one streaming read of depth/mask), allocates exactly and runs the fused
     call ``dd_unproject_compact``; ``"max"`` allocates for every visited pixel and skips the count
     (no host round trip); an int is taken as given.  ``tuning=4`` uses ``dd_plan`` + ``dd_scatter``.
+    ``record``: ``"rows"`` = the reference's (N,3) arrays; ``"xyz_rgba"`` = one 16-byte record per point
+    (``FusedCloud.packed``; ``points`` / ``colors`` are views of it) -- the compact form of the multi-GPU gather;
+    ``"both"`` writes the two.
     """
+    if record not in ("rows", "xyz_rgba", "both"):
+        raise ValueError("record must be 'rows', 'xyz_rgba' or 'both'")
     batch = ViewBatch(depth, intrinsics, cam_from_world, mask=mask, conf=conf, conf_threshold=conf_threshold,
                       normal=normal, rgb=rgb, stride=downsample_density, semantics=semantics,
                       rotate_normals=rotate_normals, device=device, tuning=tuning)
     with_normals = batch.normal is not None and (semantics == "script" or batch.mask is not None)
-    fields = dict(normals=with_normals, colors=batch.rgb is not None, pixel_index=pixel_index,
-                  view_index=view_index, device=batch.device)
+    rows = record != "xyz_rgba"
+    fields = dict(normals=with_normals, colors=batch.rgb is not None and rows, pixel_index=pixel_index,
+                  view_index=view_index, device=batch.device, packed=record != "rows", points=rows)
     if capacity is None and (tuning & 4):        # forced two-pass: the plan's offsets feed the scatter directly
         plan = plan_batch(batch)
         builder = CloudBuilder(int(plan.num_points.item()), **fields)

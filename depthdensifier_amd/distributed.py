@@ -16,6 +16,13 @@ only exchange the path needs is the fuse itself:
   its final rows of the pre-allocated global buffer) -- no staging copy, no padding, every link
   driven at once.
 
+* ``fuse_replicated`` -- the replicated fuse done IN PLACE (what ``scripts/test.py:238-240, 262-266`` becomes on
+  N GPUs): count (``dd_count_valid``) -> ``plan_fuse`` (count all-gather, ONE device->host copy of the offsets) ->
+  allocate the global cloud once -> ``dd_unproject_compact`` with ``cursor = rank_offsets[rank]`` writes every point
+  at its final global row -> each chunk of views is exchanged (grouped send/recv straight from / into the final
+  rows, no staging, no local copy) on RCCL's stream while the kernel of the next chunk runs on the compute stream.
+  ``record="xyz_rgba"`` moves one 16-byte record per point instead of 27 bytes in three arrays.
+
 Works on any ``torch.distributed`` backend: ``nccl`` (= RCCL on ROCm) on GPUs, ``gloo`` in the
 CPU tests.
 """
@@ -110,7 +117,7 @@ def allgatherv_rows(local: torch.Tensor, rows_per_rank: Sequence[int], out: Opti
         starts.append(starts[-1] + rows[r])
     pieces = [out[starts[r]:starts[r + 1]] for r in range(world)]
     glob = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
-    if rows[rank]:
+    if rows[rank] and local.data_ptr() != pieces[rank].data_ptr():     # already in place when `local` IS its slice of `out`
         pieces[rank].copy_(local)
     if world == 1:
         return out
@@ -139,14 +146,16 @@ class ShardedCloud:
     rank_offsets: torch.Tensor         # (R+1,)       int64 global slot range of each rank
     rank: int
     world_size: int
+    rank_rows: Optional[list] = None   # host copy of rank_offsets (R+1 ints), read once when the counts were exchanged
 
     @property
     def total_points(self) -> int:
-        return int(self.view_offsets[-1])
+        return int(self.rank_rows[-1]) if self.rank_rows is not None else int(self.view_offsets[-1])
 
     @property
     def global_slots(self) -> tuple[int, int]:
-        return int(self.rank_offsets[self.rank]), int(self.rank_offsets[self.rank + 1])
+        ro = self.rank_rows if self.rank_rows is not None else self.rank_offsets.tolist()
+        return int(ro[self.rank]), int(ro[self.rank + 1])
 
 
 def fuse_sharded(local_cloud, num_views_total: int, group=None) -> ShardedCloud:
@@ -157,14 +166,15 @@ def fuse_sharded(local_cloud, num_views_total: int, group=None) -> ShardedCloud:
     view_offsets = offsets_from_counts(counts)
     bounds = [shard_views(num_views_total, world, r)[0] for r in range(world)] + [num_views_total]
     rank_offsets = view_offsets[torch.tensor(bounds, device=view_offsets.device)]
-    return ShardedCloud(local_cloud, view_offsets, rank_offsets, rank, world)
+    # the ONE host read of the exchange: send / receive sizes are host arguments of the collective
+    return ShardedCloud(local_cloud, view_offsets, rank_offsets, rank, world, rank_rows=rank_offsets.tolist())
 
 
 def gather_cloud(sharded: ShardedCloud, group=None, out: Optional[dict] = None):
     """All-gatherv every field of a sharded cloud; returns a ``FusedCloud`` replicated on all ranks."""
     from .densify import FusedCloud
 
-    ro = sharded.rank_offsets.cpu()
+    ro = sharded.rank_rows if sharded.rank_rows is not None else sharded.rank_offsets.tolist()
     rows = [int(ro[r + 1] - ro[r]) for r in range(sharded.world_size)]
     loc = sharded.local
     out = out or {}
@@ -176,6 +186,166 @@ def gather_cloud(sharded: ShardedCloud, group=None, out: Optional[dict] = None):
     return FusedCloud(points=g("points", loc.points), colors=g("colors", loc.colors), normals=g("normals", loc.normals),
                       pixel_index=g("pixel_index", loc.pixel_index), view_index=g("view_index", view_index),
                       view_offsets=sharded.view_offsets, name=loc.name)
+
+
+# --------------------------------------------------------------------------------------
+# replicated fuse, in place
+# --------------------------------------------------------------------------------------
+
+@dataclass
+class FusePlan:
+    """What every rank knows once the per-view counts have been exchanged (host-side numbers)."""
+
+    view_offsets: torch.Tensor            # (V_total+1,) int64 device: global row of every view's first point
+    offsets_host: list                    # the same on the host
+    rank: int
+    world_size: int
+    num_views_total: int
+    chunk_views: list                     # [chunk] -> (lo, hi) LOCAL view range of this rank's chunk
+    chunk_rows: list                      # [chunk][rank] -> (row_lo, row_hi) global rows of that rank's chunk
+
+    @property
+    def total_points(self) -> int:
+        return int(self.offsets_host[-1])
+
+    @property
+    def rank_rows(self) -> list:
+        """[rank] -> (row_lo, row_hi) of each rank's whole slice."""
+        return [(c[0][0], c[-1][1]) for c in zip(*self.chunk_rows)] if self.chunk_rows else []
+
+
+def _chunk_bounds(lo: int, hi: int, chunks: int) -> list:
+    n = hi - lo
+    return [(lo + (k * n) // chunks, lo + ((k + 1) * n) // chunks) for k in range(chunks)]
+
+
+def plan_fuse(local_counts: torch.Tensor, num_views_total: int, chunks: int = 1, group=None) -> FusePlan:
+    """All-gather the per-view counts and lay the global cloud out: views in order, rank r's shard split into
+    ``chunks`` contiguous pieces whose k-th pieces are exchanged together.  One device->host copy (V_total+1
+    int64) -- the sizes of the sends and receives are host arguments."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if chunks < 1:
+        raise ValueError("chunks must be >= 1")
+    counts = exchange_counts(local_counts, num_views_total, group)
+    view_offsets = offsets_from_counts(counts)
+    host = view_offsets.tolist()
+    shards = [shard_views(num_views_total, world, r) for r in range(world)]
+    per_rank = [_chunk_bounds(lo, hi, chunks) for lo, hi in shards]
+    chunk_rows = [[(host[per_rank[r][k][0]], host[per_rank[r][k][1]]) for r in range(world)] for k in range(chunks)]
+    lo0 = shards[rank][0]
+    chunk_views = [(a - lo0, b - lo0) for a, b in per_rank[rank]]
+    return FusePlan(view_offsets, host, rank, world, num_views_total, chunk_views, chunk_rows)
+
+
+def exchange_rows(tensors: Sequence[torch.Tensor], rows: Sequence[tuple], group=None, dst: Optional[int] = None, base: int = 0) -> list:
+    """In-place all-gatherv of row ranges of pre-allocated GLOBAL tensors: rank r owns rows ``rows[r] = (lo, hi)`` of
+    every tensor (already written), and receives every other rank's rows straight into place.  ONE grouped batch of
+    sends and receives (``ncclGroupStart .. ncclSend/ncclRecv .. ncclGroupEnd`` on RCCL: one xGMI link per peer, all
+    driven at once); nothing is staged or copied locally.  ``dst``: only that rank receives (gather-to-owner); a pure
+    sender may then hold just its own rows, ``base`` = the global row of its tensors' row 0.
+    Returns the outstanding work handles (``wait_all`` them before reading the rows on another stream)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if len(rows) != world:
+        raise ValueError("rows must have one (lo, hi) per rank")
+    if world == 1:
+        return []
+    glob = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
+    mine = rows[rank]
+    if base and (dst is None or rank == dst):
+        raise ValueError("base is for pure senders of a gather-to-owner exchange")
+    if os.environ.get("DD_ALLGATHERV", "p2p") == "broadcast" and dst is None:
+        return [dist.broadcast(t[rows[r][0]:rows[r][1]], src=glob(r), group=group, async_op=True)
+                for r in range(world) if rows[r][1] > rows[r][0] for t in tensors]
+    ops = []
+    for k in range(1, world):                          # peer order staggered per rank: no hot receiver
+        to, frm = (rank + k) % world, (rank - k) % world
+        for t in tensors:
+            if mine[1] > mine[0] and (dst is None or to == dst):
+                ops.append(dist.P2POp(dist.isend, t[mine[0] - base:mine[1] - base], glob(to), group))
+            if rows[frm][1] > rows[frm][0] and (dst is None or rank == dst):
+                ops.append(dist.P2POp(dist.irecv, t[rows[frm][0]:rows[frm][1]], glob(frm), group))
+    return list(dist.batch_isend_irecv(ops)) if ops else []
+
+
+def wait_all(work: Sequence) -> None:
+    for w in work:
+        w.wait()
+
+
+def fuse_replicated(batch, num_views_total: int, *, normals: bool = True, colors: bool = True, pixel_index: bool = False,
+                    view_index: bool = False, record: str = "rows", chunks: int = 4, group=None, dst: Optional[int] = None,
+                    buffers: Optional[dict] = None, counts: Optional[torch.Tensor] = None, plan: Optional[FusePlan] = None):
+    """Densify this rank's shard of views and fuse all shards into ONE cloud held by every rank (or by ``dst``):
+    ``scripts/test.py:203-244`` per view and the fuse of ``:238-240, 262-266`` across GPUs.
+
+    ``batch``: the ``ViewBatch`` of this rank's views (``shard_views`` order; ``view_index_base`` = its first global
+    view).  Every point is written exactly once, by the kernel, at its final global row; the exchange of chunk k
+    overlaps the kernel of chunk k+1.  ``record``: ``"rows"`` = xyz / normals / colours arrays (27 B per point with all
+    three), ``"xyz_rgba"`` = one 16-byte record (what the model writer needs).  ``buffers``: global tensors to reuse
+    (keys as ``CloudBuilder.FIELDS``).  Returns ``(FusedCloud, FusePlan)``; rows of other ranks are valid on the
+    current stream when this returns (on ranks that receive)."""
+    from .densify import CloudBuilder, FusedCloud, count_valid
+
+    if record not in ("rows", "xyz_rgba"):
+        raise ValueError("record must be 'rows' or 'xyz_rgba'")
+    if plan is None:
+        plan = plan_fuse(count_valid(batch) if counts is None else counts, num_views_total, chunks, group)
+    total = plan.total_points
+    receives = dst is None or plan.rank == dst
+    own_lo, own_hi = plan.rank_rows[plan.rank]
+    base = 0 if receives else own_lo                                   # a pure sender holds only its own rows
+    cap = total if receives else own_hi - own_lo
+    rows = record == "rows"
+    builder = CloudBuilder(cap, points=rows, normals=normals and rows, colors=colors and rows, pixel_index=pixel_index,
+                           view_index=view_index, packed=not rows, buffers=buffers, start=own_lo - base, device=batch.device)
+    moved = [t for t in (builder.xyz, builder.normal, builder.rgb, builder.pix, builder.view, builder.packed) if t is not None]
+    work = []
+    for (lo, hi), ranges in zip(plan.chunk_views, plan.chunk_rows):
+        builder.append(batch.slice(lo, hi))                             # kernel of this chunk on the current stream ...
+        work += exchange_rows(moved, ranges, group, dst, base)          # ... its exchange waits for it, then runs on RCCL's stream
+    wait_all(work)
+    end = builder.check()
+    if end != own_hi - base:
+        raise RuntimeError(f"rank {plan.rank}: kernel wrote up to row {end + base}, plan says {own_hi}")
+    cut = lambda t: None if t is None else t[:cap]
+    if rows:
+        cloud = FusedCloud(points=cut(builder.xyz), colors=cut(builder.rgb), normals=cut(builder.normal), pixel_index=cut(builder.pix),
+                           view_index=cut(builder.view), view_offsets=plan.view_offsets)
+    else:
+        cloud = FusedCloud.from_packed(cut(builder.packed), plan.view_offsets, pixel_index=cut(builder.pix), view_index=cut(builder.view))
+    return cloud, plan
+
+
+def fuse_filtered(local_cloud, votes: torch.Tensor, vote_threshold: int, num_views_total: int, *, record: str = "xyz_rgba",
+                  dst: Optional[int] = None, group=None):
+    """Fuse the per-GPU clouds AFTER the floater filter (``scripts/test.py:330-332`` then ``:355-358`` needs points and
+    colours in one place): every rank announces its kept rows per view, the global cloud is laid out, each rank
+    compacts its kept rows straight into its slice (``dd_compact_cloud`` -> final rows, no intermediate local cloud) and
+    the slices are exchanged in place.  ``record="xyz_rgba"``: 16 bytes per point on the wire; ``"rows"``: points, colours
+    and normals arrays.  ``dst``: only that rank receives.  Returns ``(FusedCloud or None on a pure sender, FusePlan)``."""
+    from .densify import CloudBuilder, FusedCloud
+    from .filtering import compact_into, kept_per_view
+
+    if os.environ.get("DD_ALLGATHERV", "p2p") == "broadcast":
+        dst = None                                           # rehearsal backends without send/recv replicate
+    plan = plan_fuse(kept_per_view(local_cloud, votes, vote_threshold), num_views_total, 1, group)
+    dev = local_cloud.points.device
+    receives = dst is None or plan.rank == dst
+    own_lo, own_hi = plan.rank_rows[plan.rank]
+    base = 0 if receives else own_lo
+    cap = plan.total_points if receives else own_hi - own_lo
+    names = ["packed"] if record == "xyz_rgba" else [k for k, t in (("points", local_cloud.points), ("colors", local_cloud.colors),
+                                                                    ("normals", local_cloud.normals)) if t is not None]
+    bufs = {k: torch.empty((max(cap, 1),) + CloudBuilder.FIELDS[k][0], dtype=CloudBuilder.FIELDS[k][1], device=dev) for k in names}
+    compact_into(local_cloud, votes, vote_threshold, bufs, own_lo - base, own_hi - own_lo)
+    wait_all(exchange_rows([bufs[k] for k in names], plan.chunk_rows[0], group, dst, base))
+    if not receives:
+        return None, plan
+    if record == "xyz_rgba":
+        return FusedCloud.from_packed(bufs["packed"][:cap], plan.view_offsets, local_cloud.name), plan
+    return FusedCloud(points=bufs["points"][:cap], colors=None if "colors" not in bufs else bufs["colors"][:cap],
+                      normals=None if "normals" not in bufs else bufs["normals"][:cap], pixel_index=None, view_index=None,
+                      view_offsets=plan.view_offsets, name=local_cloud.name), plan
 
 
 def allgather_views(local: torch.Tensor, num_views_total: int, group=None) -> torch.Tensor:

@@ -125,6 +125,44 @@ def compact_cloud(cloud: FusedCloud, votes: torch.Tensor, vote_threshold: int) -
                       view_offsets=new, name=cloud.name)
 
 
+def kept_per_view(cloud: FusedCloud, votes: torch.Tensor, vote_threshold: int) -> torch.Tensor:
+    """(V,) int64 device: rows of each view that pass ``votes < vote_threshold`` -- what a rank announces before a
+    filtered cloud is fused across GPUs (the rows themselves are compacted later, straight into the global cloud)."""
+    keep = (votes < int(vote_threshold)).to(torch.int64)
+    csum = torch.zeros(len(cloud) + 1, dtype=torch.int64, device=votes.device)
+    torch.cumsum(keep, 0, out=csum[1:])
+    at = csum[cloud.view_offsets - cloud.view_offsets[0]]
+    return at[1:] - at[:-1]
+
+
+def compact_into(cloud: FusedCloud, votes: torch.Tensor, vote_threshold: int, buffers: dict, row0: int, rows: int) -> None:
+    """``dd_compact_cloud`` writing the kept rows of ``cloud`` at rows ``[row0, row0 + rows)`` of caller-owned tensors
+    (keys ``points / normals / colors / pixel_index / view_index / packed``; ``packed`` = the 16-byte ``x, y, z, rgba``
+    record built from points + colours).  Asynchronous; kept rows beyond ``rows`` would be dropped (``rows`` is the
+    count announced by ``kept_per_view``)."""
+    n = len(cloud)
+    if n == 0 or rows == 0:
+        return
+    dev = cloud.points.device
+    ptr = lambda t: None if t is None else t.data_ptr()
+    at = lambda name: None if buffers.get(name) is None else buffers[name][row0:row0 + rows].data_ptr()
+    need = {"normals": cloud.normals, "colors": cloud.colors, "pixel_index": cloud.pixel_index, "view_index": cloud.view_index}
+    for name, srct in need.items():
+        if buffers.get(name) is not None and srct is None:
+            raise ValueError(f"buffer '{name}' given but the cloud has no such field")
+    src = DDCloudOut(xyz=ptr(cloud.points.contiguous()), normal=ptr(cloud.normals), rgb=ptr(cloud.colors),
+                     pixel_index=ptr(cloud.pixel_index), view_index=ptr(cloud.view_index), capacity=n)
+    dst = DDCloudOut(xyz=at("points"), normal=at("normals"), rgb=at("colors"), pixel_index=at("pixel_index"),
+                     view_index=at("view_index"), capacity=rows, xyz_rgba=at("packed"))
+    kept = torch.zeros(1, dtype=torch.int64, device=dev)
+    nb = int(lib.dd_compact_workspace_bytes(n))
+    ws = torch.empty(max(nb, 64), dtype=torch.uint8, device=dev)
+    rc = lib.dd_compact_cloud(C.byref(src), n, votes.data_ptr(), int(vote_threshold), C.byref(dst), kept.data_ptr(),
+                              None, None, 0, ws.data_ptr(), ws.numel(), _stream(dev))
+    if rc < 0:
+        raise DDCoreError(rc, lib.dd_filter_last_error().decode())
+
+
 def filter_floaters(cloud: FusedCloud, depth: ArrayLike, intrinsics: ArrayLike, cam_from_world: ArrayLike,
                     mask: Optional[ArrayLike] = None, config: Optional[FilteringConfig] = None):
     """``scripts/test.py:269-335``: returns ``(filtered_cloud, votes)``.  The reference filters points and

@@ -262,17 +262,22 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
     else:
         from .distributed import floater_votes_sharded
         votes = floater_votes_sharded(cloud, cached, num_views, config.filtering.depth_threshold)
-    kept = compact_cloud(cloud, votes, config.filtering.vote_threshold)        # :330-332
-    if ranks.world > 1:                 # fuse: all-gatherv of the per-GPU clouds, rank order = view order
+    if ranks.world == 1:
+        kept = compact_cloud(cloud, votes, config.filtering.vote_threshold)    # :330-332
+        n_kept = len(kept)
+    else:
+        # fuse: every rank compacts its kept rows straight into its slice of the global cloud (16-byte xyz + rgba
+        # records, all the model writer needs) and the slices travel to rank 0 only; rank order = view order
         from . import distributed as D
-        kept = D.gather_cloud(D.fuse_sharded(kept, num_views))
-    removed = n_before - len(kept)
+        kept, plan = D.fuse_filtered(cloud, votes, config.filtering.vote_threshold, num_views, record="xyz_rgba", dst=0)
+        n_kept = plan.total_points
+    removed = n_before - n_kept
     say(f"-> Filtering removed {removed} points ({removed / n_before * 100:.2f}%)")
     say(f"-> Filtering finished in {time.time() - t0:.2f}s.")
     stage["filter"] = time.time() - t0
 
     t0 = time.time()
-    report.update(dense_points=len(kept), removed=removed, total_points=rec.num_points3D() + len(kept))
+    report.update(dense_points=n_kept, removed=removed, total_points=rec.num_points3D() + n_kept)
     if ranks.rank == 0:
         if ranks.world > 1:
             # The reference rescales the camera of EVERY processed view in place (:172-173) before the model is

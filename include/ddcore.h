@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 6
+#define DD_ABI_VERSION 7
 
 enum {
     DD_OK = 0,
@@ -97,6 +97,10 @@ typedef struct DDCloudOut {
     int32_t *pixel_index; /* (capacity)  y*W + x inside the view */
     int32_t *view_index;  /* (capacity)  view_index_base + v */
     int64_t capacity;
+    uint32_t *xyz_rgba;   /* (capacity,4) dwords, 16-B aligned, or NULL: x, y, z as float32 bits and
+                             r | g<<8 | b<<16 | 255<<24 (0 colour without DDViewBatch.rgb) -- the compact 16-byte
+                             record of a point for the multi-GPU gather (SURVEY.md 8e ii: what the model writer
+                             of scripts/test.py:355-358 needs).  xyz may be NULL when this is given. */
 } DDCloudOut;
 
 int dd_abi_version(void);
@@ -180,8 +184,9 @@ int dd_floater_votes(const DDFilterViews *views, const float *xyz, const float *
 const char *dd_filter_last_error(void);
 
 /* Stable compaction of every per-point field by the vote test of scripts/test.py:330-332
- * (keep = votes < vote_threshold).  in / out: the field pointers of DDCloudOut (out->capacity >= n; NULL
- * output fields are skipped); kept_dev: (1) int64 out; old/new_view_offsets_dev: (V+1) int64 each or both
+ * (keep = votes < vote_threshold).  in / out: the field pointers of DDCloudOut (NULL output fields are
+ * skipped; kept rows at or beyond out->capacity are counted, not written; out->xyz_rgba packs xyz + colour
+ * into the 16-byte gather record); kept_dev: (1) int64 out; old/new_view_offsets_dev: (V+1) int64 each or both
  * NULL -- the new offsets are the kept rows before each old offset.  workspace:
  * dd_compact_workspace_bytes(n) bytes, 16-B aligned. */
 int64_t dd_compact_workspace_bytes(int64_t n);

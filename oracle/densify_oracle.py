@@ -143,6 +143,38 @@ def densify_view_script(depth: np.ndarray,
     return out
 
 
+def densify_view_script_literal(depth: np.ndarray, params, cam_from_world: np.ndarray, mask: np.ndarray,
+                                normal: np.ndarray, rgb: np.ndarray, stride: int = 1) -> dict:
+    """The densify block with the reference's OWN op sequence, for timing the reference's cost
+    (``bench.py`` ``cpu_baseline.reference_formulation``): in-place mask fold (``scripts/test.py:194``),
+    ``np.mgrid`` index grids (``:206``), fancy-index validity test (``:210``), boolean-mask gathers of the two
+    int64 grids (``:212``), fancy-index gathers of colours / normals / depths with int64 index pairs
+    (``:216, 220, 229``), ``np.stack`` of the pixel pairs (``:231``), ``unproject_points`` (``:79-90``:
+    three float64 temporaries + ``np.stack``) and the rigid inverse (``:233``).  Same results as
+    :func:`densify_view_script`, which reaches them with ``np.nonzero`` on a strided view (~20x faster).
+    """
+    refined = np.array(depth, copy=True)
+    refined[~np.asarray(mask, bool)] = 0
+    h, w = refined.shape
+    pixels_y, pixels_x = np.mgrid[0:h:stride, 0:w:stride]
+    with np.errstate(invalid="ignore"):
+        valid = refined[pixels_y, pixels_x] > 0
+    px, py = pixels_x[valid], pixels_y[valid]
+    colors = rgb[py, px]
+    normals = normal[py, px]
+    d = refined[py, px]
+    points2d = np.stack([px, py], axis=-1)
+    fx, fy, cx, cy = (float(p) for p in params)
+    u, v = points2d[:, 0], points2d[:, 1]
+    with np.errstate(invalid="ignore", over="ignore"):
+        x = (u - cx) / fx * d
+        y = (v - cy) / fy * d
+        z = d
+        cam = np.stack([x, y, z], axis=-1)
+        world = rigid_inverse_apply(cam_from_world, cam)
+    return {"points": world, "pixel_index": py * w + px, "colors": colors, "normals": normals}
+
+
 # --------------------------------------------------------------------------
 # package formulation (src/depthdensifier/visualizer.py)
 # --------------------------------------------------------------------------

@@ -66,6 +66,46 @@ def main():
     assert np.array_equal(fused.normals.numpy(), full.normals)
     assert np.array_equal(fused.pixel_index.numpy(), full.pixel_index.astype(np.int32))
     assert np.array_equal(fused.view_index.numpy(), full.view_index.astype(np.int32))
+    # ---- the replicated fuse IN PLACE: plan from the counts, own rows already at their final global rows, chunked
+    # grouped exchange straight into place (the kernel is played by the oracle part; GPU twin: tests/test_fuse_gpu.py)
+    want = {"points": full.points.astype(np.float32), "colors": full.colors, "normals": full.normals,
+            "pixel_index": full.pixel_index.astype(np.int32)}
+    mine = {"points": local.points, "colors": local.colors, "normals": local.normals, "pixel_index": local.pixel_index}
+    for chunks in (1, 3):
+        plan = D.plan_fuse(local.counts, V, chunks=chunks)
+        assert plan.offsets_host == full.view_offsets.tolist() and plan.total_points == len(full.points)
+        assert plan.rank_rows[a.rank] == (s0, s1)
+        assert [r for c in plan.chunk_views for r in c][0] == 0 and plan.chunk_views[-1][1] == hi - lo
+        N = plan.total_points
+        glob = {k: torch.zeros((N,) + tuple(v.shape[1:]), dtype=v.dtype) for k, v in mine.items()}
+        for k, v in mine.items():
+            glob[k][s0:s1] = v                                   # "the kernel wrote its rows at rank_offsets[rank]"
+        ptrs = {k: t.data_ptr() for k, t in glob.items()}
+        work = []
+        for ranges in plan.chunk_rows:
+            assert ranges[a.rank][0] >= s0 and ranges[a.rank][1] <= s1
+            work += D.exchange_rows(list(glob.values()), ranges)
+        D.wait_all(work)
+        for k, t in glob.items():
+            assert t.data_ptr() == ptrs[k]
+            assert np.array_equal(t.numpy(), want[k], equal_nan=t.dtype.is_floating_point), f"in-place fuse, chunks={chunks}, field {k}"
+    # gather-to-owner: only the last rank receives; the others hold just their own rows (base = their first global row)
+    owner = a.world - 1
+    plan = D.plan_fuse(local.counts, V, chunks=2)
+    if a.rank == owner:
+        glob = {k: torch.zeros((plan.total_points,) + tuple(v.shape[1:]), dtype=v.dtype) for k, v in mine.items()}
+        for k, v in mine.items():
+            glob[k][s0:s1] = v
+        tens, base = list(glob.values()), 0
+    else:
+        tens, base = [v.contiguous() for v in mine.values()], s0
+    work = []
+    for ranges in plan.chunk_rows:
+        work += D.exchange_rows(tens, ranges, dst=owner, base=base)
+    D.wait_all(work)
+    if a.rank == owner:
+        for k, t in glob.items():
+            assert np.array_equal(t.numpy(), want[k], equal_nan=t.dtype.is_floating_point), f"gather-to-owner, field {k}"
     # per-view stacks (what the sharded filter all-gathers): every rank ends with all views, in view order
     depth_all = D.allgather_views(torch.from_numpy(d["depth"][lo:hi].astype(np.float32)), V)
     assert np.array_equal(depth_all.numpy(), d["depth"].astype(np.float32), equal_nan=True)

@@ -1,0 +1,86 @@
+"""The in-place replicated fuse on real devices (``-m gpu``): RCCL world 1 in-process, two ranks sharing the box's GPU
+over gloo, and -- where the box has >= 2 GPUs -- two ranks over RCCL send/recv (the all-gatherv of the north star).
+CPU twin of the exchange logic: tests/test_distributed_cpu.py (gloo, world 2 and 3)."""
+
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+pytestmark = pytest.mark.gpu
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _torchrun(nproc, env_extra, timeout=300):
+    env = dict(os.environ, **env_extra)
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+                           "--master-port", str(_port()), str(ROOT / "tests" / "fuse_worker.py")], capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_rccl_world1_in_process():
+    """backend nccl (= RCCL) with a single rank: count exchange, plan, the fused call writing at the planned rows into
+    the global buffers, sharded fuse -- everything but the wire."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.distributed as dist
+    import depthdensifier_amd as dd
+    from depthdensifier_amd import distributed as D
+    from synth import make_views
+
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_port()}", rank=0, world_size=1, device_id=dev)
+    try:
+        V, H, W = 5, 96, 176
+        d = make_views(9, V, H, W, rho=0.8)
+        params = np.tile([140.0, 141.0, 88.0, 48.0], (V, 1))
+        kw = dict(mask=d["mask"], normal=d["normal"], rgb=d["rgb"])
+        full = dd.unproject_views(d["depth"], params, d["cam_from_world"], **kw)
+        batch = dd.ViewBatch(d["depth"], params, d["cam_from_world"], device=dev, **kw)
+        counts = dd.count_valid(batch)
+        assert counts.is_cuda and torch.equal(D.exchange_counts(counts, V), counts)
+        sharded = D.fuse_sharded(full, V)
+        assert sharded.view_offsets.is_cuda and sharded.global_slots == (0, len(full)) and sharded.rank_rows == [0, len(full)]
+        assert D.gather_cloud(sharded).points.data_ptr() != 0
+        for chunks in (1, 4):
+            cloud, plan = D.fuse_replicated(batch, V, pixel_index=True, chunks=chunks)
+            assert plan.total_points == len(full) and len(plan.chunk_rows) == chunks
+            for name in ("points", "colors", "normals", "pixel_index"):
+                assert torch.equal(getattr(cloud, name), getattr(full, name)), name
+        bufs = {"packed": torch.empty((len(full) + 7, 4), dtype=torch.float32, device=dev)}
+        cloud, _ = D.fuse_replicated(batch, V, record="xyz_rgba", chunks=3, buffers=bufs)
+        assert cloud.packed.data_ptr() == bufs["packed"].data_ptr()                  # written in place, no copy
+        assert torch.equal(cloud.points.contiguous(), full.points) and torch.equal(cloud.colors.contiguous(), full.colors)
+        assert int(cloud.packed.view(torch.int32)[:, 3].bitwise_right_shift(24).bitwise_and(255).min()) == 255
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_sharing_the_gpu_over_gloo():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    r = _torchrun(2, dict(DD_DIST_BACKEND="gloo", DD_ALLGATHERV="broadcast", DD_SHARE_GPU="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count(": ok,") == 2
+
+
+def test_two_ranks_over_rccl():
+    """The wire itself: grouped ncclSend/ncclRecv straight from / into the final rows.  Needs two GPUs."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (the driver's multi-GPU box)")
+    n = min(torch.cuda.device_count(), 4)
+    r = _torchrun(n, dict(DD_DIST_BACKEND="nccl", DD_FUSE_VIEWS="11"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count(": ok,") == n

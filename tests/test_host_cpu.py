@@ -33,7 +33,7 @@ def test_header_symbols_are_exported(libmod):
 def test_struct_layout_matches_header(libmod):
     # DDViewParams is 32 floats; DDViewBatch / DDCloudOut sizes for the LP64 layout in the header
     assert C.sizeof(libmod.DDViewBatch) == 4 * 4 + 6 * 8 + 6 * 4
-    assert C.sizeof(libmod.DDCloudOut) == 5 * 8 + 8
+    assert C.sizeof(libmod.DDCloudOut) == 5 * 8 + 8 + 8
 
 
 def _batch(libmod, **kw):
@@ -84,8 +84,14 @@ def test_neighbour_entry_points_validate_before_launching(libmod):
     assert L.dd_compact_cloud(C.byref(src), 10, 0x40, 5, C.byref(dst), 0x50, None, None, 0, 0x1000, 1 << 20, None) == -1
     assert b"no input field" in L.dd_filter_last_error()
     dst.normal = None
-    assert L.dd_compact_cloud(C.byref(src), 11, 0x40, 5, C.byref(dst), 0x50, None, None, 0, 0x1000, 1 << 20, None) == -1
+    dst.capacity = -1
+    assert L.dd_compact_cloud(C.byref(src), 10, 0x40, 5, C.byref(dst), 0x50, None, None, 0, 0x1000, 1 << 20, None) == -1
     assert b"capacity" in L.dd_filter_last_error()
+    dst.capacity = 10
+    dst.xyz_rgba = 0x208                                                                    # the 16-byte record must be 16-byte aligned
+    assert L.dd_compact_cloud(C.byref(src), 10, 0x40, 5, C.byref(dst), 0x50, None, None, 0, 0x1000, 1 << 20, None) == -1
+    assert b"xyz_rgba" in L.dd_filter_last_error()
+    dst.xyz_rgba = None
     assert L.dd_compact_cloud(C.byref(src), 10, 0x40, 5, C.byref(dst), 0x50, 0x60, None, 3, 0x1000, 1 << 20, None) == -1
     assert L.dd_compact_cloud(C.byref(src), 10, 0x40, 5, C.byref(dst), 0x50, None, None, 0, None, 0, None) == -3        # DD_ERR_WORKSPACE
     assert L.dd_compact_cloud(C.byref(src), 10, 0x40, 5, C.byref(dst), 0x50, None, None, 0, 0x1008, 1 << 20, None) == -3   # mis-aligned

@@ -11,6 +11,6 @@ mkdir -p "$OUT"
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --pmc $c --kernel-include-regex "compact_lean|count_lean|scan_view|compact_generic" --kernel-trace --output-format csv -d "$OUT/$c" -- \
-      python3 "$R/bench.py" --steps 3 --warmup 1 --cpu-seconds 0 "$@" > "$OUT/$c.log" 2>&1
+      python3 "$R/bench.py" --steps 3 --warmup 1 --cpu-seconds 0 --strong-views 0 "$@" > "$OUT/$c.log" 2>&1
   echo "$c rc=$?"
 done

@@ -11,7 +11,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   timeout -k 10 400 rocprofv3 --pmc $set --kernel-include-regex "compact_lean|count_lean" --kernel-trace --output-format csv -d "$OUT/set$i" -- \
-      python3 "$R/bench.py" --steps 2 --warmup 1 --cpu-seconds 0 "$@" > "$OUT/set$i.log" 2>&1 || echo "set$i failed"
+      python3 "$R/bench.py" --steps 2 --warmup 1 --cpu-seconds 0 --strong-views 0 "$@" > "$OUT/set$i.log" 2>&1 || echo "set$i failed"
 done
 python3 - "$OUT" <<'PY'
 import csv, sys, json
