@@ -262,11 +262,17 @@ class Reconstruction:
         _, table, order, sorted_ids = cache
         ids = np.asarray(ids)
         if table is not None:
-            rows = table[ids.astype(np.int64)]
+            idx = ids.astype(np.int64)
+            if len(idx) and (idx.min() < 0 or idx.max() >= len(table)):
+                raise KeyError("xyz_of: unknown point3D id")
+            rows = table[idx]
             if len(rows) and rows.min() < 0:
                 raise KeyError("xyz_of: unknown point3D id")
             return self.point_xyz[rows]
-        pos = np.searchsorted(sorted_ids, ids.astype(np.uint64))
+        want = ids.astype(np.uint64)
+        pos = np.minimum(np.searchsorted(sorted_ids, want), max(len(sorted_ids) - 1, 0))
+        if len(want) and (len(sorted_ids) == 0 or np.any(sorted_ids[pos] != want)):
+            raise KeyError("xyz_of: unknown point3D id")
         return self.point_xyz[order[pos]]
 
     # -- reading ------------------------------------------------------------------------

@@ -15,8 +15,11 @@ def rot_to_qvec(R):
     return np.array([w, x, y, z])
 
 
-def make_scan(root: Path, name: str, V=5, H=96, W=128, seed=0, floaters=0.02, second_size=None):
-    """``second_size=(H2, W2)``: odd-numbered views use a second camera of that size (mixed resolutions in one scan)."""
+def make_scan(root: Path, name: str, V=5, H=96, W=128, seed=0, floaters=0.02, second_size=None, image_scale=1, second_tail=0):
+    """``second_size=(H2, W2)``: odd-numbered views use a second camera of that size (mixed resolutions in one scan);
+    with ``second_tail=k`` only the LAST k views use it (a camera no early view touches).  ``image_scale=f``: the image
+    files and the sparse model's cameras / 2-D observations are f times larger than the cached maps, i.e. a scan meant
+    to be run with ``pipeline_downsample_factor=f`` (``scripts/test.py:145-152, 172-173``)."""
     from PIL import Image as PILImage
     rng = np.random.default_rng(seed)
     scan = Path(root) / name
@@ -27,11 +30,12 @@ def make_scan(root: Path, name: str, V=5, H=96, W=128, seed=0, floaters=0.02, se
     rec = Reconstruction()
     sizes = [(H, W)] + ([tuple(second_size)] if second_size else [])
     for k, (h, w) in enumerate(sizes):
-        rec.cameras[k + 1] = Camera(k + 1, 1, w, h, np.array([0.9 * w, 0.9 * w, w / 2.0, h / 2.0]))
+        f = image_scale
+        rec.cameras[k + 1] = Camera(k + 1, 1, w * f, h * f, np.array([0.9 * w * f, 0.9 * w * f, w * f / 2.0, h * f / 2.0]))
     ids, xyz, rgbs, next_id = [], [], [], 1
     truth = []
     for v in range(V):
-        cam_id = 1 + (v % len(sizes))
+        cam_id = (2 if v >= V - second_tail else 1) if (second_tail and len(sizes) > 1) else 1 + (v % len(sizes))
         H, W = sizes[cam_id - 1]
         fx = fy = 0.9 * W
         cx, cy = W / 2.0, H / 2.0
@@ -56,7 +60,11 @@ def make_scan(root: Path, name: str, V=5, H=96, W=128, seed=0, floaters=0.02, se
         normal = np.tile(np.array([0.0, -1.0, 0.0]) @ R.T, (H, W, 1)).astype(np.float32)   # plane normal in the camera frame
         img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
         stem = f"img_{v:03d}"
-        PILImage.fromarray(img).save(scan / "images" / f"{stem}.png")
+        if image_scale > 1:          # a smooth full-resolution picture (so that LANCZOS down-sampling is not pure noise)
+            big = np.asarray(PILImage.fromarray(img).resize((W * image_scale, H * image_scale), PILImage.Resampling.BICUBIC))
+            PILImage.fromarray(big).save(scan / "images" / f"{stem}.png")
+        else:
+            PILImage.fromarray(img).save(scan / "images" / f"{stem}.png")
         np.savez(cache / f"{stem}.npz", depth=mono_f, mask=mask, normal=normal)
         # sparse observations on the plane
         n_obs = 300
@@ -68,7 +76,7 @@ def make_scan(root: Path, name: str, V=5, H=96, W=128, seed=0, floaters=0.02, se
         world = (cam - t) @ R
         pid = np.arange(next_id, next_id + len(world)); next_id += len(world)
         ids.append(pid); xyz.append(world); rgbs.append(np.full((len(world), 3), 200, np.uint8))
-        xys = np.stack([np.floor(pu), np.floor(pv)], -1)
+        xys = np.stack([np.floor(pu), np.floor(pv)], -1) * image_scale
         rec.images[v + 1] = Image(v + 1, rot_to_qvec(R), t, cam_id, f"{stem}.png", xys, pid.astype(np.int64))
         truth.append(dict(R=R, t=t, depth_true=depth_true, mono=mono_f, mask=mask, normal=normal, rgb=img))
     rec.point_ids = np.concatenate(ids).astype(np.uint64)

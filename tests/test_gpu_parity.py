@@ -477,6 +477,93 @@ def test_offsets_beyond_32_bits(dd, orc):
     assert torch.equal(fused.view_index, cloud.view_index)
 
 
+@pytest.mark.parametrize("conf_dtype", ("float32", "float16"))
+def test_full_size_1080p_confidence_cull(dd, orc, conf_dtype):
+    """BASELINE configs[3] shape (the per-GPU share of the 7 Mip-NeRF 360 scenes): 1920x1080, mask AND conf > 0.5, all four
+    fields, float32 and float16 confidence maps.  Properties on all 6 views, the oracle on two; every kernel variant
+    gives the same bits."""
+    import torch
+    V, H, W = 6, 1080, 1920
+    depth, mask, normal, rgb = _device_stack(V, H, W, 4321)
+    g = torch.Generator(device="cuda").manual_seed(77)
+    conf = torch.rand((V, H, W), device="cuda", generator=g).to(getattr(torch, conf_dtype))
+    depth.view(-1)[::100003] = float("nan")                       # a few culled by depth > 0 as well
+    params = np.tile([0.8 * W, 0.8 * W, W / 2, H / 2], (V, 1))
+    E = _ring_poses(V)
+    kw = dict(mask=mask, conf=conf, conf_threshold=0.5, normal=normal, rgb=rgb, view_index=True)
+    cloud = dd.unproject_views(depth, params, E, capacity="max", **kw)
+    thr = torch.tensor(0.5, dtype=conf.dtype, device="cuda")    # NEP 50: the threshold is rounded to the map's dtype
+    keep = mask & (conf > thr) & (depth > 0)
+    assert np.array_equal(cloud.counts.cpu().numpy(), keep.sum(dim=(1, 2)).cpu().numpy())
+    assert 0.35 < len(cloud) / (V * H * W) < 0.45
+    offs = cloud.view_offsets.cpu().numpy()
+    pix = cloud.pixel_index.cpu().numpy()
+    for v in range(V):
+        assert np.array_equal(pix[offs[v]:offs[v + 1]], np.nonzero(keep[v].reshape(-1).cpu().numpy())[0])   # sorted, exactly the kept set
+    for tuning in (4, 1):                                       # two-pass lean, scalar kernels: bit-identical
+        again = dd.unproject_views(depth, params, E, capacity="max", tuning=tuning, **kw)
+        for name in ("points", "colors", "normals", "view_offsets", "pixel_index", "view_index"):
+            assert torch.equal(getattr(again, name), getattr(cloud, name)), (tuning, name)
+    exact = dd.unproject_views(depth, params, E, **kw)          # exact allocation (count pass with the conf rule)
+    assert len(exact) == len(cloud) and torch.equal(exact.points, cloud.points)
+    dn, mn, nn, cn, fn = (t.cpu().numpy() for t in (depth, mask, normal, rgb, conf))
+    rad = scene_radius(E, np.array([8.0]))
+    for v in (1, 4):
+        ref = orc.densify_view_script(dn[v], params[v], E[v], mask=mn[v], normal=nn[v], rgb=cn[v], conf=fn[v], conf_threshold=0.5)
+        sl = slice(offs[v], offs[v + 1])
+        assert np.array_equal(pix[sl], ref["pixel_index"])
+        assert_xyz(cloud.points[sl].double().cpu().numpy(), ref["points"], rad)
+        assert np.array_equal(cloud.colors[sl].cpu().numpy(), ref["colors"])
+        assert np.array_equal(cloud.normals[sl].cpu().numpy(), ref["normals"])
+
+
+def test_per_gpu_share_of_the_2000_view_scene_with_normals(dd, orc):
+    """BASELINE configs[2], what ONE of 8 GPUs holds: 250 views x 1080p with depth + mask + normal + rgb (10.4 GB in,
+    ~11 GB out), one fused call.  Counts, order and ranges on all views; first, middle and LAST view against the oracle
+    (rows beyond the 4 GiB byte offset carry normals here, unlike test_offsets_beyond_32_bits)."""
+    import torch
+    V, H, W = 250, 1080, 1920
+    g = torch.Generator(device="cuda").manual_seed(250)
+    depth = torch.empty((V, H, W), device="cuda")
+    mask = torch.empty((V, H, W), dtype=torch.bool, device="cuda")
+    normal = torch.empty((V, H, W, 3), device="cuda")
+    rgb = torch.empty((V, H, W, 3), dtype=torch.uint8, device="cuda")
+    for v in range(V):                      # per-view generation keeps the temporaries small
+        depth[v].uniform_(0.5, 8.0, generator=g)
+        mask[v] = torch.rand((H, W), device="cuda", generator=g) < 0.8
+        normal[v] = torch.nn.functional.normalize(torch.randn((H, W, 3), device="cuda", generator=g), dim=-1)
+        rgb[v] = torch.randint(0, 256, (H, W, 3), device="cuda", generator=g, dtype=torch.uint8)
+    params = np.tile([0.8 * W, 0.8 * W, W / 2, H / 2], (V, 1))
+    E = _ring_poses(V)
+    cloud = dd.unproject_views(depth, params, E, mask=mask, normal=normal, rgb=rgb, view_index=True, capacity="max")
+    offs = cloud.view_offsets.cpu().numpy()
+    assert len(cloud) * 12 > 2 ** 32                                          # byte offsets of the xyz / normal rows pass 4 GiB
+    assert np.array_equal(np.diff(offs), mask.sum(dim=(1, 2)).cpu().numpy())
+    vi = cloud.view_index
+    assert int(vi[0]) == 0 and int(vi[-1]) == V - 1 and bool(torch.all(vi[1:] >= vi[:-1]))
+    inc = cloud.pixel_index[1:] > cloud.pixel_index[:-1]                      # sorted inside every view
+    assert bool(torch.all(inc | (vi[1:] != vi[:-1])))
+    nn_ = torch.linalg.vector_norm(cloud.normals, dim=1)
+    assert float((nn_ - 1).abs().max()) < 1e-5                                # pass-through unit normals, no stray rows
+    rad = scene_radius(E, np.array([8.0]))
+    for v in (0, 125, V - 1):
+        sl = slice(int(offs[v]), int(offs[v + 1]))
+        ref = orc.densify_view_script(depth[v].cpu().numpy(), params[v], E[v], mask=mask[v].cpu().numpy(), normal=normal[v].cpu().numpy(),
+                                      rgb=rgb[v].cpu().numpy())
+        assert np.array_equal(cloud.pixel_index[sl].cpu().numpy().astype(np.int64), ref["pixel_index"])
+        assert np.array_equal(cloud.colors[sl].cpu().numpy(), ref["colors"])
+        assert np.array_equal(cloud.normals[sl].cpu().numpy(), ref["normals"])
+        assert_xyz(cloud.points[sl].double().cpu().numpy(), ref["points"], rad)
+    # the 16-byte record of the compact gather holds the same xyz bits and colours
+    del cloud
+    torch.cuda.empty_cache()
+    packed = dd.unproject_views(depth, params, E, mask=mask, rgb=rgb, record="xyz_rgba", pixel_index=False, capacity="max")
+    rows = dd.unproject_views(depth, params, E, mask=mask, rgb=rgb, pixel_index=False, capacity="max")
+    assert torch.equal(packed.view_offsets, rows.view_offsets)
+    assert torch.equal(packed.packed[:, :3], rows.points)
+    assert torch.equal(packed.colors, rows.colors)
+
+
 def test_c_abi_client_without_python(tmp_path):
     """A C++/HIP program linking libddcore.so (no torch, no Python in the loop) drives dd_plan + dd_scatter and
     the fused call and checks them against its own float64 loop (tests/c_client/abi_client.cpp)."""

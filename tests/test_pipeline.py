@@ -148,6 +148,101 @@ def test_pipeline_end_to_end_on_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_pipeline_downsample_factor_two_on_gpu(tmp_path):
+    """``pipeline_downsample_factor = 2`` (``scripts/test.py:145-152, 172-173``): the image FILES and the sparse model's
+    cameras are twice the size of the maps; the pipeline must LANCZOS-resize the picture, rescale the camera in place,
+    size the cloud from the files -- and write the rescaled cameras.  Checked stage by stage like the f = 1 test."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from PIL import Image as PILImage
+    import run_batch
+    import depthdensifier_amd as dd
+    from depthdensifier_amd.colmap_io import Reconstruction
+    from oracle import filter_oracle as forc
+    from scan_factory import make_scan
+
+    H, W = 96, 128
+    scan, cache, truth = make_scan(tmp_path / "scans", "plane2x", V=5, H=H, W=W, floaters=0.03, image_scale=2)
+    src = Reconstruction(scan / "sparse" / "0")
+    assert (src.cameras[1].width, src.cameras[1].height) == (2 * W, 2 * H)
+    n_sparse = src.num_points3D()
+    cfg = run_batch.BatchConfig(tmp_path / "scans", tmp_path / "out")
+    cfg.config.moge.cache_dir = cache
+    cfg.config.processing.pipeline_downsample_factor = 2
+    cfg.config.processing.downsample_density = 1
+    cfg.config.refiner.use_fp16 = False
+    cfg.config.refiner.adaptive_correspondences = False
+    cfg.config.filtering.vote_threshold = 2
+    rep = run_batch.main(cfg)
+    assert len(rep) == 1 and isinstance(rep[0][1], float), rep
+    out = Reconstruction(tmp_path / "out" / "plane2x" / "sparse" / "0")
+    cam = out.cameras[1]                                                 # :172-173 rescaled in place, then written (:363)
+    assert (cam.width, cam.height) == (W, H)
+    assert cam.params.tolist() == [0.9 * W, 0.9 * W, W / 2.0, H / 2.0]  # exact: the scale is a power of two
+    dense = out.point_xyz[n_sparse:]
+    assert len(dense) > 5000 and np.median(np.abs(dense[:, 1])) < 0.05
+    # stage by stage: PIL's LANCZOS picture, the rescaled camera, our refiner + densify, the ORACLE filter
+    K = np.array([[0.9 * W, 0, W / 2.0], [0, 0.9 * W, H / 2.0], [0, 0, 1.0]])
+    refiner = dd.DepthRefiner(use_fp16=False, adaptive_correspondences=False)
+    depths, Es, rgbs = [], [], []
+    for i in sorted(src.images):
+        im = src.images[i]; tr = truth[i - 1]
+        E = im.cam_from_world().matrix()
+        pic = PILImage.open(scan / "images" / im.name).convert("RGB")
+        assert pic.size == (2 * W, 2 * H)
+        rgbs.append(np.array(pic.resize((W, H), PILImage.Resampling.LANCZOS)))
+        r = refiner.refine_depth(tr["mono"], tr["normal"], src.xyz_of(im.observed_point3D_ids()), E, K, tr["mask"])
+        depths.append(r["refined_depth"]); Es.append(E)
+    depths = np.stack(depths); masks = np.stack([t["mask"] for t in truth]); Es = np.stack(Es)
+    Ks = np.stack([K] * len(Es))
+    c = dd.unproject_views(depths, Ks, Es, mask=masks, normal=np.stack([t["normal"] for t in truth]), rgb=np.stack(rgbs)).numpy()
+    culled = np.where(masks, depths, 0).astype(np.float32)
+    ep, ec, _, votes = forc.filter_floaters(c["points"].astype(np.float32), c["colors"], c["normals"], culled, Ks, Es,
+                                            vote_threshold=2, depth_threshold=0.7)
+    assert (votes >= 2).sum() > 20
+    assert len(dense) == len(ep)
+    assert np.array_equal(dense.astype(np.float32), ep) and np.array_equal(out.point_rgb[n_sparse:], ec)
+
+
+@pytest.mark.gpu
+def test_view_sharded_scan_with_downsample_factor_and_a_late_camera(tmp_path):
+    """Two ranks, ``pipeline_downsample_factor = 2``, and a second camera that only the LAST views use (all of them in
+    rank 1's shard): rank 0 writes the model, so it has to rescale that camera too (``scripts/test.py:172-173`` does it
+    for every processed view).  ``cameras.bin`` / ``images.bin`` / ``points3D.bin`` equal the one-process model byte
+    for byte."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from scan_factory import make_scan
+    scan, cache, _ = make_scan(tmp_path / "scans", "plane2x", V=7, seed=4, floaters=0.03, second_size=(72, 104), image_scale=2, second_tail=2)
+    root = Path(__file__).resolve().parent.parent
+    args = ["--paths.recon-path", str(scan / "sparse" / "0"), "--paths.image-dir", str(scan / "images"),
+            "--moge.cache-dir", str(cache), "--processing.downsample-density", "1", "--processing.pipeline-downsample-factor", "2",
+            "--refiner.no-use-fp16", "--refiner.no-adaptive-correspondences", "--filtering.vote-threshold", "2", "--refiner.verbose", "0"]
+    one = subprocess.run([sys.executable, str(root / "scripts" / "test.py"), *args, "--paths.output-model-dir", str(tmp_path / "one")],
+                         capture_output=True, text=True, timeout=240)
+    assert one.returncode == 0, one.stdout + one.stderr
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, DD_DIST_BACKEND="gloo", DD_ALLGATHERV="broadcast")      # gloo has no CUDA send/recv
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), str(root / "scripts" / "test.py"), *args, "--paths.output-model-dir", str(tmp_path / "two")],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert two.returncode == 0, two.stdout + two.stderr
+    from depthdensifier_amd.colmap_io import Reconstruction
+    m = Reconstruction(tmp_path / "two")
+    assert (m.cameras[2].width, m.cameras[2].height) == (104, 72) and (m.cameras[1].width, m.cameras[1].height) == (128, 96)
+    for name in ("cameras.bin", "images.bin", "points3D.bin"):
+        assert (tmp_path / "one" / name).read_bytes() == (tmp_path / "two" / name).read_bytes(), name
+
+
+@pytest.mark.gpu
 def test_view_sharded_scan_matches_single_gpu(tmp_path):
     """``scripts/test.py`` under torchrun: 2 ranks (sharing this box's one GPU, gloo collectives) shard the views, filter
     sharded by points, all-gatherv the surviving clouds; the model written by rank 0 equals the one-process model
