@@ -44,6 +44,8 @@ EXPORTS = (
     "dd_compact_cloud",
     "dd_refine_apply",
     "dd_refine_last_error",
+    "dd_allgatherv",
+    "dd_comm_last_error",
 )
 
 
@@ -140,6 +142,10 @@ def _load() -> C.CDLL:
                                     C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.dd_refine_last_error.restype = C.c_char_p
     lib.dd_refine_last_error.argtypes = []
+    lib.dd_allgatherv.restype = C.c_int
+    lib.dd_allgatherv.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(DDCloudOut), C.POINTER(C.c_int64), C.c_int32, C.c_void_p]
+    lib.dd_comm_last_error.restype = C.c_char_p
+    lib.dd_comm_last_error.argtypes = []
     got = lib.dd_abi_version()
     if got != DD_ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI version {got}, binding expects {DD_ABI_VERSION}; rebuild the library")

@@ -157,6 +157,29 @@ int dd_unproject_compact(const DDViewBatch *batch, const DDCloudOut *out,
                          void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Multi-GPU fuse: what scripts/test.py:262-266 (np.concatenate of the per-view arrays)
+ * becomes when the views are sharded over the GPUs of a node, one process per GPU.
+ *
+ * In-place all-gatherv of the per-GPU compacted clouds over an RCCL communicator the CALLER owns.  Rank r has
+ * already written its rows [rank_rows[r], rank_rows[r+1]) of every non-NULL field of `cloud` -- the GLOBAL buffers,
+ * capacity >= rank_rows[world_size] -- e.g. by dd_unproject_compact with *cursor_dev = rank_rows[r].  The call posts
+ * ONE ncclGroupStart .. ncclSend/ncclRecv .. ncclGroupEnd on `stream`: its rows to every peer, every peer's rows
+ * straight into place (xGMI is point-to-point: one link per peer, all driven at once; nothing is staged or copied
+ * locally).  Chain it per chunk of views on a second stream to overlap the exchange with the next chunk's kernel.
+ *
+ *  comm        ncclComm_t of the caller (as void*); unused when world_size == 1.
+ *  rank_rows   (world_size+1) int64 on the HOST: first global row of each rank's slice, [world_size] = total.
+ *  dst         -1: every rank receives (replicated cloud); r: gather-to-owner, only rank r receives and a pure
+ *              sender's buffers hold just its own rows (their row 0 is global row rank_rows[rank]).
+ * libddcore.so does not link RCCL: the entry points are resolved at first use from the RCCL runtime already loaded in
+ * the process.  Returns DD_ERR_UNSUPPORTED when none can be found, DD_ERR_LAUNCH on an RCCL error
+ * (dd_comm_last_error() has the RCCL message).
+ * ------------------------------------------------------------------------------------------- */
+int dd_allgatherv(void *comm, int32_t rank, int32_t world_size, const DDCloudOut *cloud, const int64_t *rank_rows,
+                  int32_t dst, void *stream);
+const char *dd_comm_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
  * multi-view floater votes, scripts/test.py:269-335 (+ project_points :58-76).
  * ------------------------------------------------------------------------------------------- */
 

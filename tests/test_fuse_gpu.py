@@ -84,3 +84,48 @@ def test_two_ranks_over_rccl():
     r = _torchrun(n, dict(DD_DIST_BACKEND="nccl", DD_FUSE_VIEWS="11"))
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count(": ok,") == n
+
+
+def _build_allgatherv_client(tmp_path):
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = tmp_path / "abi_allgatherv"
+    lib_dir = ROOT / "depthdensifier_amd"
+    build = subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", f"-I{ROOT / 'include'}",
+                            str(ROOT / "tests" / "c_client" / "abi_allgatherv.cpp"), f"-L{lib_dir}", "-lddcore", "-L/opt/rocm/lib", "-lrccl",
+                            f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-2000:]
+    return exe
+
+
+def _run_allgatherv_client(exe, world, tmp_path):
+    idfile = tmp_path / f"nccl_id_{world}"
+    procs = [subprocess.Popen([str(exe), str(r), str(world), str(idfile)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=240)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "C ABI all-gatherv OK" in out, f"rank {r}:\n{out}"
+
+
+def test_c_abi_allgatherv_world1(tmp_path):
+    """dd_allgatherv through the C ABI alone (tests/c_client/abi_allgatherv.cpp), one rank: RCCL communicator of the
+    caller, counts all-gather, the fused call writing at rank_rows[rank] of the global buffers, error conventions."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _run_allgatherv_client(_build_allgatherv_client(tmp_path), 1, tmp_path)
+
+
+def test_c_abi_allgatherv_over_rccl(tmp_path):
+    """The same client, one process per GPU: grouped ncclSend / ncclRecv in place, replicated and gather-to-owner."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (the driver's multi-GPU box)")
+    _run_allgatherv_client(_build_allgatherv_client(tmp_path), min(torch.cuda.device_count(), 4), tmp_path)
