@@ -40,6 +40,7 @@ EXPORTS = (
     "dd_unproject_compact",
     "dd_floater_votes",
     "dd_filter_last_error",
+    "dd_votes_workspace_bytes",
     "dd_compact_workspace_bytes",
     "dd_compact_cloud",
     "dd_refine_apply",
@@ -94,6 +95,10 @@ class DDFilterViews(C.Structure):
         ("grazing_cos", C.c_double),
         ("depth_threshold", C.c_float),
         ("reserved2", C.c_float),
+        ("workspace", C.c_void_p),
+        ("workspace_bytes", C.c_int64),
+        ("mode", C.c_int32),
+        ("reserved3", C.c_int32),
     ]
 
 
@@ -130,6 +135,8 @@ def _load() -> C.CDLL:
     ]
     lib.dd_floater_votes.restype = C.c_int
     lib.dd_floater_votes.argtypes = [C.POINTER(DDFilterViews), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.dd_votes_workspace_bytes.restype = C.c_int64
+    lib.dd_votes_workspace_bytes.argtypes = [C.c_int32, C.c_int64]
     lib.dd_filter_last_error.restype = C.c_char_p
     lib.dd_filter_last_error.argtypes = []
     lib.dd_compact_workspace_bytes.restype = C.c_int64

@@ -52,12 +52,24 @@ def filter_cameras(intrinsics: ArrayLike, cam_from_world: ArrayLike) -> np.ndarr
     return cams
 
 
+VOTE_MODES = {"float64": 1, "float32_first": 0, "verify": 2}
+
+
 def floater_votes(points: torch.Tensor, normals: torch.Tensor, depth: ArrayLike, intrinsics: ArrayLike,
                   cam_from_world: ArrayLike, mask: Optional[ArrayLike] = None, depth_threshold: float = 0.7,
-                  votes: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  votes: Optional[torch.Tensor] = None, mode: str = "float64", stats: Optional[dict] = None) -> torch.Tensor:
     """(N,) int32 votes of ``scripts/test.py:273-328``.  ``depth`` (V,H,W) float32 is the refined depth
     of the cached views (``:197-201``); with ``mask`` given, masked-out pixels read as 0 (``:194``).
-    Pass ``votes`` to accumulate over several calls (views in chunks)."""
+    Pass ``votes`` to accumulate over several calls (views in chunks).
+
+    ``mode``: ``"float64"`` (default) = every decision in float64, the fastest form on MI355X (335 Gpairs/s);
+    ``"float32_first"`` = a float32 first pass with rigorous error bounds whose undecided pairs (~1 %) are resolved in
+    float64 -- the same votes bit for bit, but measured SLOWER here (240-280 Gpairs/s: the float64 kernel's time is mostly
+    cheap early exits, not float64 arithmetic), kept as a checked experiment; ``"verify"`` = that first
+    pass with every confident decision cross-checked in float64.  ``stats`` (a dict) receives ``pairs``,
+    ``resolved_in_float64`` and, in verify mode, ``mismatches`` (one host synchronisation)."""
+    if mode not in VOTE_MODES:
+        raise ValueError(f"mode must be one of {sorted(VOTE_MODES)}")
     dev = _require_gpu(points.device if isinstance(points, torch.Tensor) and points.is_cuda else None)
     pts = _gpu(points, dev, torch.float32)
     nrm = _gpu(normals, dev, torch.float32)
@@ -85,12 +97,17 @@ def floater_votes(points: torch.Tensor, normals: torch.Tensor, depth: ArrayLike,
     if votes is None:
         votes = torch.empty(pts.shape[0], dtype=torch.int32, device=dev)
     V, H, W = d.shape
+    ws = torch.empty(int(lib.dd_votes_workspace_bytes(V, pts.shape[0])) if mode != "float64" else 16, dtype=torch.uint8, device=dev)
     fv = DDFilterViews(num_views=V, height=H, width=W, depth=d.data_ptr(), mask=None if m is None else m.data_ptr(),
-                       cams=cams.data_ptr(), grazing_cos=GRAZING_COS, depth_threshold=float(depth_threshold))
+                       cams=cams.data_ptr(), grazing_cos=GRAZING_COS, depth_threshold=float(depth_threshold),
+                       workspace=ws.data_ptr(), workspace_bytes=ws.numel(), mode=VOTE_MODES[mode])
     rc = lib.dd_floater_votes(C.byref(fv), pts.data_ptr(), nrm.data_ptr(), pts.shape[0], votes.data_ptr(),
                               1 if accumulate else 0, _stream(dev))
     if rc < 0:
         raise DDCoreError(rc, lib.dd_filter_last_error().decode())
+    if stats is not None:
+        w = [0, 0] if mode == "float64" else ws[:64 * 128].view(torch.int64).view(64, 16)[:, :2].sum(dim=0).tolist()   # 64 shards, a line each
+        stats.update(pairs=int(pts.shape[0]) * V, resolved_in_float64=int(w[0]), mismatches=int(w[1]), mode=mode)
     # asynchronous: temporaries freed here are only reused by later work on the same stream
     return votes
 

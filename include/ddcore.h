@@ -188,7 +188,7 @@ typedef struct DDFilterViews {
     int32_t num_views;
     int32_t height;
     int32_t width;
-    int32_t reserved;
+    int32_t reserved;       /* 0 (timing experiments of the float32 pass: 1 no gather, 2 / 4 stop after the bounds / sign test) */
     const float *depth;     /* (V,H,W) refined depth */
     const uint8_t *mask;    /* (V,H,W) or NULL; mask == 0 reads as depth 0 (scripts/test.py:194) */
     const double *cams;     /* (V,24) float64 per view: cam_from_world 3x4 row-major [0..11]
@@ -197,6 +197,16 @@ typedef struct DDFilterViews {
     double grazing_cos;     /* 0.087, scripts/test.py:295 */
     float depth_threshold;  /* FilteringConfig.depth_threshold = 0.7, scripts/test.py:45-46, 320 */
     float reserved2;
+    void *workspace;        /* NULL (default: every decision in float64, the fastest form measured on MI355X), or device scratch
+                               of dd_votes_workspace_bytes(num_views, n) bytes (less is accepted: more rounds of views), 16-B
+                               aligned, for the EXPERIMENTAL float32 first pass: float32 evaluation with rigorous error bounds,
+                               undecided pairs (~1 %) resolved in float64 through a queue -- the same votes bit for bit, measured
+                               0.7-0.8x the float64 kernel's rate.  After the stream has drained the first
+                               8 KiB hold 64 shards of 16 uint64: [0] pairs left undecided, [1] verify disagreements. */
+    int64_t workspace_bytes;
+    int32_t mode;           /* with a workspace: 0 = float32 first pass; 1 = float64 throughout; 2 = verify: every decision of
+                               the float32 pass is also taken in float64 and disagreements are counted (must be 0) */
+    int32_t reserved3;
 } DDFilterViews;
 
 /* votes_dev[i] (= or +=, by `accumulate`) the number of views in which point i is a floater
@@ -204,6 +214,7 @@ typedef struct DDFilterViews {
  * in float64 exactly as NumPy promotes them.  The caller then keeps votes < vote_threshold (:330). */
 int dd_floater_votes(const DDFilterViews *views, const float *xyz, const float *normal, int64_t n,
                      int32_t *votes_dev, int32_t accumulate, void *stream);
+int64_t dd_votes_workspace_bytes(int32_t num_views, int64_t n_points);
 const char *dd_filter_last_error(void);
 
 /* Stable compaction of every per-point field by the vote test of scripts/test.py:330-332

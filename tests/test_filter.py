@@ -205,3 +205,52 @@ def test_gpu_compact_cloud(n, fields):
                                                                torch.bincount(view[keep].long(), minlength=4).cumsum(0).cpu()]))
     # keep everything / drop everything
     assert len(dd.compact_cloud(cloud, votes, 100)) == n and len(dd.compact_cloud(cloud, votes, 0)) == 0
+
+
+@pytest.mark.gpu
+def test_float32_first_pass_gives_the_float64_votes():
+    """The optional float32 first pass (rigorous error bounds, undecided pairs resolved in float64): votes equal the
+    float64 kernel's bit for bit, and in verify mode not one confident float32 decision disagrees with float64 -- on a
+    ring scene, on points that reproject exactly onto pixel centres / image borders / the camera centre, on huge and
+    non-finite coordinates, and with the queue squeezed into a small workspace (several rounds, overflow -> redo)."""
+    import ctypes as C
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import depthdensifier_amd as dd
+    from depthdensifier_amd import _lib
+    from depthdensifier_amd.filtering import filter_cameras
+
+    d = _scene(11, 9, 96, 128)
+    K = dd.intrinsics_matrix(d["params"])
+    E = d["cam_from_world"]
+    depth_in = np.where(np.isfinite(d["depth"]), d["depth"], 0).astype(np.float32)
+    cloud = dd.unproject_views(depth_in, d["params"], E, mask=d["mask"], normal=d["normal"])      # points ON pixel centres of their own view
+    pts, nrm = cloud.points.clone(), cloud.normals.clone()
+    n = len(pts)
+    rng = np.random.default_rng(0)
+    centres = torch.as_tensor(np.stack([-E[v, :, :3].T @ E[v, :, 3] for v in range(9)]), dtype=torch.float32, device="cuda")
+    pts[:9] = centres                                                          # exactly at a camera centre
+    pts[100:110] = float("nan"); pts[110:120] = float("inf"); pts[120:130] = 3e30; nrm[130:140] = float("nan")
+    pts[140:150] *= 1e-30                                                      # underflow territory
+    st64, st32, stv = {}, {}, {}
+    v64 = dd.floater_votes(pts, nrm, depth_in, K, E, mask=d["mask"], mode="float64", stats=st64)
+    v32 = dd.floater_votes(pts, nrm, depth_in, K, E, mask=d["mask"], mode="float32_first", stats=st32)
+    vv = dd.floater_votes(pts, nrm, depth_in, K, E, mask=d["mask"], mode="verify", stats=stv)
+    assert torch.equal(v32, v64) and torch.equal(vv, v64)
+    assert stv["mismatches"] == 0
+    assert 0 < st32["resolved_in_float64"] < 0.2 * st32["pairs"]              # own-view pairs sit on integers: undecided by design
+    assert int(v64.max()) >= 3
+    # a workspace with room for only a few hundred queue entries per shard: rounds of views + redo cells, same votes
+    V, H, W = depth_in.shape
+    cams = torch.from_numpy(filter_cameras(K, E)).cuda()
+    dz = torch.where(torch.as_tensor(d["mask"]).cuda(), torch.as_tensor(depth_in).cuda(), torch.zeros((), device="cuda")).contiguous()
+    blocks = (n + 255) // 256
+    small = 2 * 64 * 128 + V * 128 + ((blocks + 31) // 32 * 4 + 15) // 16 * 16 + 8 * 4096 * 64 + 4096
+    ws = torch.zeros(small, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    fv = _lib.DDFilterViews(num_views=V, height=H, width=W, depth=dz.data_ptr(), mask=None, cams=cams.data_ptr(), grazing_cos=0.087,
+                            depth_threshold=0.7, workspace=ws.data_ptr(), workspace_bytes=ws.numel(), mode=0)
+    rc = _lib.lib.dd_floater_votes(C.byref(fv), pts.data_ptr(), nrm.data_ptr(), n, out.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, _lib.lib.dd_filter_last_error()
+    assert torch.equal(out, v64)

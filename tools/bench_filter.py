@@ -7,7 +7,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 import bench, depthdensifier_amd as dd
 
-ap = argparse.ArgumentParser(); ap.add_argument("--views", type=int, default=32); 
+ap = argparse.ArgumentParser(); ap.add_argument("--views", type=int, default=32); ap.add_argument("--verify", action="store_true")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 cfg = dict(bench.WORKLOADS["garden185"]); cfg["V"] = a.views
@@ -19,13 +19,20 @@ E = bench.ring_poses(ids, a.views)
 cloud = dd.unproject_views(scene["depth"], params, E, mask=scene["mask"], normal=scene["normal"], rgb=scene["rgb"])
 K = dd.intrinsics_matrix(params)
 torch.cuda.synchronize()
-for _ in range(2):
+pairs = len(cloud) * a.views
+sums = {}
+for mode in ("float64", "float32_first", "float64", "float32_first") + (("verify",) if a.verify else ()):
+    st = {}
+    dd.floater_votes(cloud.points, cloud.normals, scene["depth"], K, E, mask=scene["mask"], mode=mode)   # warm-up (allocations)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    votes = dd.floater_votes(cloud.points, cloud.normals, scene["depth"], K, E, mask=scene["mask"])
+    votes = dd.floater_votes(cloud.points, cloud.normals, scene["depth"], K, E, mask=scene["mask"], mode=mode, stats=st)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-pairs = len(cloud) * a.views
-print(f"points {len(cloud)/1e6:.1f} M x views {a.views} = {pairs/1e9:.2f} G pairs in {dt*1e3:.1f} ms -> {pairs/dt/1e9:.1f} Gpairs/s; "
-      f"votes>=5: {(votes >= 5).float().mean().item()*100:.2f} %  max {int(votes.max())}")
-print("votes checksum", int(votes.long().sum()), int((votes.long() * (torch.arange(len(votes), device=votes.device) % 1000003)).sum()))
+    sums[mode] = (int(votes.long().sum()), int((votes.long() * (torch.arange(len(votes), device=votes.device) % 1000003)).sum()))
+    print(f"[{mode:13s}] points {len(cloud)/1e6:.1f} M x views {a.views} = {pairs/1e9:.2f} G pairs in {dt*1e3:.1f} ms -> {pairs/dt/1e9:.1f} Gpairs/s; "
+          f"votes>=5: {(votes >= 5).float().mean().item()*100:.2f} %  max {int(votes.max())}; resolved in float64 {st['resolved_in_float64']} "
+          f"({st['resolved_in_float64']/pairs*100:.3f} % of pairs); mismatches {st['mismatches']}; checksum {sums[mode]}")
+assert len(set(sums.values())) == 1, f"votes differ between modes: {sums}"
+print("votes identical in every mode")
 # the NumPy baseline of this stage is timed by tests/time_filter_oracle.py (the oracle is test infrastructure)
