@@ -45,6 +45,8 @@ EXPORTS = (
     "dd_compact_cloud",
     "dd_refine_apply",
     "dd_refine_last_error",
+    "dd_refine_fit",
+    "dd_sort_knots",
     "dd_allgatherv",
     "dd_comm_last_error",
 )
@@ -149,6 +151,11 @@ def _load() -> C.CDLL:
                                     C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.dd_refine_last_error.restype = C.c_char_p
     lib.dd_refine_last_error.argtypes = []
+    lib.dd_refine_fit.restype = C.c_int
+    lib.dd_refine_fit.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.dd_sort_knots.restype = C.c_int
+    lib.dd_sort_knots.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.dd_allgatherv.restype = C.c_int
     lib.dd_allgatherv.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(DDCloudOut), C.POINTER(C.c_int64), C.c_int32, C.c_void_p]
     lib.dd_comm_last_error.restype = C.c_char_p

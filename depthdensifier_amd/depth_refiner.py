@@ -134,8 +134,16 @@ class DepthRefiner:
         """The same per-pixel work as ``_apply_curve`` in one hand-written kernel (``dd_refine_apply``,
         ``csrc/ddrefine.hip``): the view is read once and written once.  Always float32 arithmetic."""
         from ._lib import DD_F16, DD_F32, DDCoreError, lib
-        order = torch.argsort(x.float())
-        kx, ky = x.float()[order].contiguous(), y.float()[order].contiguous()
+        xf, yf = x.float().contiguous(), y.float().contiguous()
+        if xf.numel() <= 4096:                                # one launch instead of argsort + two gathers
+            kx, ky = torch.empty_like(xf), torch.empty_like(yf)
+            rc = lib.dd_sort_knots(xf.data_ptr(), yf.data_ptr(), xf.numel(), kx.data_ptr(), ky.data_ptr(),
+                                   torch.cuda.current_stream(xf.device).cuda_stream)
+            if rc < 0:
+                raise DDCoreError(rc, lib.dd_refine_last_error().decode())
+        else:
+            order = torch.argsort(xf)
+            kx, ky = xf[order].contiguous(), yf[order].contiguous()
         d = depth if depth.dtype in (torch.float16, torch.float32) else depth.float()
         d = d.contiguous()
         m = None if mask is None else mask.contiguous().view(torch.uint8)
@@ -160,6 +168,34 @@ class DepthRefiner:
         out[~mask] = 0
         return out
 
+    def _fit_hip(self, depth: torch.Tensor, points3D: ArrayLike, cam_from_world: ArrayLike, K: ArrayLike):
+        """The correspondence half (``depth_refiner.py:244-299``) as ONE kernel launch + one small device->host read
+        (``dd_refine_fit``, ``csrc/ddrefine.hip``) instead of ~25 tensor launches and several synchronisations.
+        Returns ``(z_mono, z_metric, in_bounds, positive, kept, removed, scale)``.  In the reference's FP16 mode
+        (``:85-86``) the inputs and the correspondences are quantised to half like there; the arithmetic in between is
+        float32 (no golden exists for that mode, and this is at least as close to the FP32 result)."""
+        import ctypes as C
+        from ._lib import DD_F16, DD_F32, DDCoreError, lib
+        half = self.dtype == torch.float16
+        q = (lambda a: np.asarray(a, dtype=np.float64).astype(np.float16).astype(np.float32)) if half else (lambda a: np.asarray(a, dtype=np.float32))
+        E = q(cam_from_world.cpu().numpy() if isinstance(cam_from_world, torch.Tensor) else cam_from_world)[:3, :4].reshape(-1)
+        Kq = q(K.cpu().numpy() if isinstance(K, torch.Tensor) else K)[:2, :3].reshape(-1)
+        pts = (torch.from_numpy(np.ascontiguousarray(points3D, dtype=np.float32)) if isinstance(points3D, np.ndarray) else points3D.float()).to(self.device).contiguous()
+        n = int(pts.shape[0])
+        buf = torch.empty((3, max(n, 1)), dtype=torch.float32, device=self.device)
+        meta = torch.zeros(8, dtype=torch.int32, device=self.device)
+        d = depth.contiguous()
+        rc = lib.dd_refine_fit(pts.data_ptr(), n, (C.c_float * 12)(*E.tolist()), (C.c_float * 6)(*Kq.tolist()), d.data_ptr(),
+                               DD_F16 if d.dtype == torch.float16 else DD_F32, d.shape[0], d.shape[1], int(self.edge_margin),
+                               1 if self.robust else 0, float(self.outlier_threshold), 1 if half else 0,
+                               buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), meta.data_ptr(),
+                               torch.cuda.current_stream(self.device).cuda_stream)
+        if rc < 0:
+            raise DDCoreError(rc, lib.dd_refine_last_error().decode())
+        inb, pos, kept, removed, scale_bits = meta[:5].tolist()                 # the one synchronisation of the fit
+        scale = float(np.array([scale_bits], dtype=np.int32).view(np.float32)[0])
+        return buf[0][:kept], buf[1][:kept], inb, pos, kept, removed, scale
+
     # ---- API --------------------------------------------------------------------------
     def refine_depth(self, depth_map: ArrayLike, normal_map: Optional[ArrayLike], points3D: ArrayLike,
                      cam_from_world: ArrayLike, K: ArrayLike, mask: Optional[ArrayLike] = None,
@@ -172,15 +208,39 @@ class DepthRefiner:
             print(f"[DepthRefiner] Input depth shape: {tuple(depth_map.shape)}")
             print(f"[DepthRefiner] COLMAP points: {len(points3D)}")
         depth = self._to(depth_map)
-        pts = self._to(points3D)
-        E = self._to(cam_from_world)
-        Kt = self._to(K)
         m = self._to(mask, torch.bool) if mask is not None else depth > 0
 
         def unchanged(n, why):
             if self.verbose > 0:
                 print(f"[DepthRefiner] {why}")
             return {"refined_depth": depth_map, "num_correspondences": n, "scale_factor": 1.0}
+
+        if depth.is_cuda and depth.dim() == 2 and min(depth.shape) >= 2:
+            # GPU: the whole correspondence half is one hand-written kernel
+            z_mono, z_metric, inb, pos, kept, removed, scale = self._fit_hip(depth, points3D, cam_from_world, K)
+            if inb == 0:
+                return unchanged(0, "No valid correspondences found")
+            if pos == 0:
+                return unchanged(0, "No valid depth correspondences")
+            if kept < self.min_correspondences:
+                return unchanged(kept, f"Too few correspondences ({kept} < {self.min_correspondences})")
+            if self.adaptive_correspondences and kept > 500:
+                pick = torch.randperm(kept, device=self.device, generator=generator)[:500]
+                z_mono, z_metric = z_mono[pick], z_metric[pick]
+                scale = float(torch.median(z_metric / (z_mono + 1e-6)).cpu())
+            refined = self._apply_curve(depth, m, z_mono, z_metric)
+            n_corr = int(z_mono.numel())
+            if self.verbose > 0:
+                print(f"[DepthRefiner] Refined using {n_corr} correspondences")
+                if removed > 0:
+                    print(f"[DepthRefiner] Removed {removed} outliers")
+                print(f"[DepthRefiner] Effective scale: {scale:.3f}")
+            out = refined.float() if return_tensor else refined.cpu().numpy().astype(np.float32)
+            return {"refined_depth": out, "num_correspondences": n_corr, "outliers_removed": removed, "scale_factor": scale}
+
+        pts = self._to(points3D)
+        E = self._to(cam_from_world)
+        Kt = self._to(K)
 
         uv, z = self._project_sparse(pts, E, Kt)
         h, w = depth.shape

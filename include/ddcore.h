@@ -241,6 +241,21 @@ int dd_refine_apply(const void *depth, int32_t depth_dtype, const uint8_t *mask,
                     float *refined_out, void *stream);
 const char *dd_refine_last_error(void);
 
+/* The correspondence half of DepthRefiner.refine_depth, src/depthdensifier/depth_refiner.py:244-299, in ONE launch:
+ * project the n sparse points (:92-115; cam_from_world = 12 floats [R|t] row-major, calibration = rows 0 and 1 of K, 6
+ * floats, both on the HOST), keep projections inside the image minus edge_margin with positive depth (:247-254), sample
+ * the depth map bilinearly there (grid_sample, zero padding, align_corners=True, :260-272), keep positive samples
+ * (:281-288), and -- if robust and more than 10 remain -- drop ratio outliers by outlier_threshold x IQR (:117-139).
+ * z_mono_out / z_metric_out: (n) float32 device, the kept correspondences in the reference's order; scratch: (n) float32
+ * device; meta_out: (8) int32 device: [0] projections in bounds, [1] positive samples, [2] kept, [3] outliers removed,
+ * [4] float32 bits of the effective scale median(z_metric / (z_mono + 1e-6)) (:315).  float32 arithmetic;
+ * half_precision_io != 0 mirrors the reference's FP16 mode (:85-86): points and correspondences are quantised to half. */
+int dd_refine_fit(const float *points, int32_t n, const float *cam_from_world, const float *calibration, const void *depth,
+                  int32_t depth_dtype, int32_t height, int32_t width, int32_t edge_margin, int32_t robust, float outlier_threshold,
+                  int32_t half_precision_io, float *z_mono_out, float *z_metric_out, float *scratch, int32_t *meta_out, void *stream);
+/* The knots sorted by x (torch.argsort, :149-151), n <= 4096, one launch. */
+int dd_sort_knots(const float *x, const float *y, int32_t n, float *x_sorted, float *y_sorted, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,23 @@ def pinhole_K(params):
     return np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
 
 
+def refiner_case(seed, H=96, W=128, n_pts=900):
+    """Mono depth = distorted true depth; sparse points = true-depth unprojections + noise + outliers."""
+    rng = np.random.default_rng(seed)
+    ys, xs = np.mgrid[0:H, 0:W]
+    true_depth = 3.0 + 1.2 * np.sin(xs / 17.0) + 0.8 * np.cos(ys / 11.0)
+    mono = (0.35 * true_depth ** 1.15 + 0.1).astype(np.float32)        # unknown monotone distortion
+    mask = rng.uniform(size=(H, W)) < 0.9
+    fx, fy, cx, cy = 110.0, 112.0, W / 2.0, H / 2.0
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+    E = random_pose(rng)
+    u = rng.uniform(2, W - 3, n_pts); v = rng.uniform(2, H - 3, n_pts)
+    d = true_depth[v.astype(int), u.astype(int)] * (1 + 0.01 * rng.standard_normal(n_pts))
+    d[: n_pts // 20] *= rng.uniform(1.5, 3.0, n_pts // 20)            # outliers
+    cam = np.stack([(u - cx) / fx * d, (v - cy) / fy * d, d], axis=-1)
+    world = (cam - E[:, 3]) @ E[:, :3]                                 # R^T (p - t)
+    behind = rng.standard_normal((40, 3)) * 0.2 - E[:, :3].T @ E[:, 3] - 3.0 * E[2, :3]
+    return dict(depth=mono, mask=mask, points3D=np.vstack([world, behind]), cam_from_world=E, K=K)
 
 
 def sha(a) -> str:

@@ -137,3 +137,101 @@ def test_hip_apply_kernel_equals_tensor_path(shape, skip, with_mask):
         pytest.skip("fewer than 4 masked pixels: the tensor path takes its own branch")
     want = cpu._apply_curve(depth.clone(), m_cpu, x, y)
     assert torch.equal(got, want)
+
+
+def _tensor_fit_cpu(r, depth, pts, E, K):
+    """The correspondence half as the tensor formulation evaluates it on the CPU (= the reference's op sequence, which
+    the CPU golden test pins): returns z_mono, z_metric (kept, in order), counts and the scale."""
+    import torch.nn.functional as F
+    cpu = type(r).__new__(type(r))
+    cpu.__dict__.update(r.__dict__); cpu.device = torch.device("cpu"); cpu.dtype = torch.float32
+    d = torch.as_tensor(depth, dtype=torch.float32)
+    uv, z = cpu._project_sparse(torch.as_tensor(pts, dtype=torch.float32), torch.as_tensor(E, dtype=torch.float32), torch.as_tensor(K, dtype=torch.float32))
+    h, w = d.shape
+    e = cpu.edge_margin
+    ok = (uv[:, 0] >= e) & (uv[:, 0] < w - e) & (uv[:, 1] >= e) & (uv[:, 1] < h - e) & (z > 0)
+    uv, z = uv[ok], z[ok]
+    grid = torch.stack([uv[:, 0] / (w - 1) * 2 - 1, uv[:, 1] / (h - 1) * 2 - 1], dim=-1)[None, None]
+    sampled = F.grid_sample(d[None, None], grid, mode="bilinear", padding_mode="zeros", align_corners=True).reshape(-1)
+    has = sampled > 0
+    z_mono, z_metric = sampled[has], z[has]
+    pos, removed = int(has.sum()), 0
+    if cpu.robust and len(z_mono) > 10:
+        z_metric, z_mono, removed = cpu._iqr_inliers(z_metric, z_mono)
+    scale = float(torch.median(z_metric / (z_mono + 1e-6))) if len(z_mono) else 1.0
+    return z_mono, z_metric, int(ok.sum()), pos, removed, scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ("default", "notrobust", "nomask"))
+def test_hip_fit_kernel_equals_tensor_path_on_the_golden_inputs(g, name):
+    """dd_refine_fit (one launch) against the tensor formulation on the CPU, on the inputs of the reference goldens: same
+    correspondences in the same order (counts identical, values to float32 rounding), same outlier count, same scale."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    r = _refiner(**VARIANTS[name])
+    depth, pts = g[f"{name}_in_depth"], g[f"{name}_in_points3D"]
+    E, K = g[f"{name}_in_cam_from_world"][:3], g[f"{name}_in_K"]
+    zm, zt, inb, pos, kept, removed, scale = r._fit_hip(torch.as_tensor(depth).cuda(), pts, E, K)
+    em, et, e_inb, e_pos, e_removed, e_scale = _tensor_fit_cpu(r, depth, pts, E, K)
+    assert (inb, pos, kept, removed) == (e_inb, e_pos, len(em), e_removed)
+    assert np.allclose(zm.cpu().numpy(), em.numpy(), rtol=2e-6, atol=0) and np.allclose(zt.cpu().numpy(), et.numpy(), rtol=2e-6, atol=0)
+    assert abs(scale - e_scale) <= 2e-6 * abs(e_scale)
+    assert kept == int(g[f"{name}_exp_num_correspondences__refine_depth"])
+    assert removed == int(g[f"{name}_exp_outliers_removed__refine_depth"])
+    assert abs(scale - float(g[f"{name}_exp_scale_factor__refine_depth"])) <= 2e-6 * abs(scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("holes", (False, True))
+@pytest.mark.parametrize("seed, n, shape", [(1, 7000, (270, 480)), (2, 40000, (1080, 1920)), (3, 9, (64, 64)), (4, 1, (16, 16)), (5, 300, (2, 2000))])
+def test_hip_fit_kernel_random_scenes(seed, n, shape, holes):
+    """Larger / odd cases: tens of thousands of points (chunked stable compaction, radix select over > 4096 values), very
+    few points (no IQR below 11), points behind the camera and outside the image, zeros in the depth map."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from synth import refiner_case                 # tests/golden/synth.py: own synthetic scene builder
+    H, W = shape
+    try:
+        c = refiner_case(seed, H=H, W=W, n_pts=n) if min(H, W) > 8 else None
+    except Exception:
+        c = None
+    rng = np.random.default_rng(seed)
+    if c is None:
+        c = dict(depth=rng.uniform(0.5, 3.0, (H, W)).astype(np.float32), points3D=rng.standard_normal((n, 3)) * 2 + [0, 0, 3],
+                 cam_from_world=np.hstack([np.eye(3), np.zeros((3, 1))]), K=np.array([[0.9 * W, 0, W / 2.0], [0, 0.9 * W, H / 2.0], [0, 0, 1.0]]))
+    c["depth"] = np.array(c["depth"], copy=True)
+    if holes:
+        c["depth"][rng.uniform(size=c["depth"].shape) < 0.05] = 0.0
+    r = _refiner(edge_margin=3 if min(H, W) < 30 else 10)
+    if min(H, W) <= 6:
+        r.edge_margin = 0
+    zm, zt, inb, pos, kept, removed, scale = r._fit_hip(torch.as_tensor(c["depth"]).cuda(), c["points3D"], c["cam_from_world"][:3], c["K"])
+    em, et, e_inb, e_pos, e_removed, e_scale = _tensor_fit_cpu(r, c["depth"], c["points3D"], c["cam_from_world"][:3], c["K"])
+    # a projection within float32 rounding of a bound, or a ratio within rounding of the IQR threshold, may fall either way
+    assert abs(inb - e_inb) <= 2 and abs(pos - e_pos) <= 2 and abs(kept - len(em)) <= 3 + 2e-3 * len(em)
+    if kept == len(em) and kept:
+        # A projected coordinate differs by an ulp between two float32 evaluations (1.2e-4 px at u ~ 1500).  On a smooth map
+        # that moves the sample by ~1e-7; next to a hole the sample is (weight x one neighbour) and the weight u - floor(u)
+        # inherits the whole ulp: relative differences up to ~1e-3 there, in either implementation, against float64.
+        rel_m = np.abs(zm.cpu().numpy() - em.numpy()) / np.abs(em.numpy())
+        rel_t = np.abs(zt.cpu().numpy() - et.numpy()) / np.abs(et.numpy())
+        assert rel_t.max() <= 1e-5
+        assert rel_m.max() <= (5e-3 if holes else 2e-5) and np.median(rel_m) <= 1e-6
+        assert abs(scale - e_scale) <= (1e-4 if holes else 1e-5) * abs(e_scale)
+
+
+@pytest.mark.gpu
+def test_sort_knots_kernel():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from depthdensifier_amd._lib import lib
+    for n in (1, 2, 3, 500, 777, 4096):
+        gen = torch.Generator().manual_seed(n)
+        x = torch.rand(n, generator=gen).cuda() * 5
+        y = torch.rand(n, generator=gen).cuda()
+        xs, ys = torch.empty_like(x), torch.empty_like(y)
+        assert lib.dd_sort_knots(x.data_ptr(), y.data_ptr(), n, xs.data_ptr(), ys.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+        order = torch.argsort(x)
+        assert torch.equal(xs, x[order]) and torch.equal(ys, y[order])
+    assert lib.dd_sort_knots(x.data_ptr(), y.data_ptr(), 5000, xs.data_ptr(), ys.data_ptr(), None) == -1
