@@ -28,6 +28,7 @@ DD_VALID_DEPTH_POSITIVE = 0x1
 DD_VALID_MASK = 0x2
 DD_VALID_CONF = 0x4
 DD_ROTATE_NORMALS = 0x8
+DD_REFINE = 0x10
 
 #: every symbol include/ddcore.h declares
 EXPORTS = (
@@ -70,6 +71,7 @@ class DDViewBatch(C.Structure):
         ("flags", C.c_uint32),
         ("view_index_base", C.c_int32),
         ("tuning", C.c_uint32),
+        ("refined_out", C.c_void_p),
     ]
 
 

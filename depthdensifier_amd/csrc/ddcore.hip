@@ -28,6 +28,7 @@
 #include <string.h>
 
 #include "ddcore.h"
+#include "ddrefine_math.h"
 
 namespace {
 
@@ -64,6 +65,8 @@ struct KArgs {
     uint8_t *out_rgb;
     int32_t *out_pix;
     int32_t *out_view;
+    float *refined_out;           // DD_REFINE: (V,H,W) refined map or NULL
+    int raw_f16;                  // DD_REFINE: the raw depth is float16 (the kernel's own depth type is float32 then)
     uint32_t *out_packed;         // (capacity,4) dwords: x, y, z (float bits), r | g<<8 | b<<16 | 255<<24 -- the 16-byte gather record
     long long capacity;
     long long *view_offsets;
@@ -611,13 +614,19 @@ __device__ __forceinline__ long long lookback13(unsigned long long *state, unsig
 
 // NW = waves per workgroup: 4 (4096-pixel tiles) for the two-pass scatter; the single-pass variant uses 12
 // (12288-pixel tiles, 2 workgroups x 12 waves per CU) so that one look-back is amortised over three times the work.
-template <typename DepthT, bool HAS_MASK, bool SINGLE_PASS, bool HAS_NORMAL, bool HAS_RGB, int NW>
+constexpr int REFINE_MAX_KNOTS = 512;
+
+template <typename DepthT, bool HAS_MASK, bool SINGLE_PASS, bool HAS_NORMAL, bool HAS_RGB, int NW, bool REFINE = false>
 __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs a) {
     constexpr int BT = 64 * NW;             // threads per workgroup
     constexpr int LT = NW * L_WSPAN;        // pixels per tile
     constexpr int VEC = 16 / (int)sizeof(DepthT), CH = L_PXT / VEC, CSPAN = 64 * VEC;
-    __shared__ float s_d[LT];              // 16 KiB
-    __shared__ unsigned short s_q[LT];     //  8 KiB
+    // the point list: depth (float) + 16-bit pixel per listed point.  One raw block, because the fused refine stage uses
+    // the same bytes, BEFORE the list exists, for the transformed values of the tile and its halo (up to LT*6/4 floats)
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[LT * 6];
+    float *const s_d = reinterpret_cast<float *>(s_raw);                              // 4 B per pixel
+    unsigned short *const s_q = reinterpret_cast<unsigned short *>(s_raw + LT * 4);  // 2 B per pixel
+    __shared__ float s_knots[REFINE ? 2 * REFINE_MAX_KNOTS : 1];
     __shared__ unsigned s_tot[NW];
     __shared__ long long s_excl;
     __shared__ unsigned s_ticket;
@@ -656,7 +665,72 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
 
     uint4 d[CH];
     unsigned bits[CH];
-    lean_load_test<DepthT, HAS_MASK, true>(a, vbase, qw, lane, d, bits);
+    if constexpr (REFINE) {
+        static_assert(sizeof(DepthT) == 4 && SINGLE_PASS, "the fused refine stage runs in the float32 single-pass instantiation");
+        // ---- src/depthdensifier/depth_refiner.py:180-205 on this tile, from the RAW depth (scripts/test.py:179-194 fused in) ----
+        const DDViewParams *vp = a.params + v;
+        const int nk = vp->n_knots;                                   // wave-uniform
+        float *const s_kx = s_knots, *const s_ky = s_knots + REFINE_MAX_KNOTS;
+        for (int i = tid; i < nk; i += BT) { s_kx[i] = vp->knots_x[i]; s_ky[i] = vp->knots_y[i]; }
+        // transformed values of the tile plus W + 1 pixels either side (a 3x3 window of a pixel of the tile reaches one
+        // row up and down); replicate padding = clamped coordinates, so nothing outside the view is ever needed
+        float *const s_val = reinterpret_cast<float *>(s_raw);
+        const unsigned Wd = (unsigned)a.W, Hd = (unsigned)a.H;
+        const unsigned lo = q0 > Wd + 1u ? q0 - (Wd + 1u) : 0u;
+        const unsigned hi = (q0 + (unsigned)LT + Wd + 1u) < a.P ? (q0 + (unsigned)LT + Wd + 1u) : a.P;
+        __syncthreads();
+        for (unsigned e = lo + (unsigned)tid; e < hi; e += (unsigned)BT) {
+            const long long p = vbase + e;
+            const float raw = a.raw_f16 ? (float)reinterpret_cast<const _Float16 *>(a.depth)[p] : reinterpret_cast<const float *>(a.depth)[p];
+            const bool mk = a.mask ? (a.mask[p] != 0) : (raw > 0.0f);         // depth_refiner.py:238-241
+            s_val[e - lo] = mk ? ddmath::lut(s_kx, s_ky, nk, raw) : 0.0f;     // :185-191
+        }
+        __syncthreads();
+        const bool smooth = vp->skip_smoothing == 0;
+        float ref[CH][VEC];
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) {
+            const unsigned qb = qw + (unsigned)(ch * 64 + lane) * VEC;
+            unsigned y = qb / Wd, x = qb - y * Wd;
+            unsigned b = 0;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const unsigned q = qb + (unsigned)k;
+                float r = 0.0f;
+                if (q < a.P) {
+                    const float c = s_val[q - lo];
+                    r = c;
+                    if (smooth) {                                             // :194-200
+                        const unsigned ym = y ? y - 1u : 0u, yp = y + 1u < Hd ? y + 1u : Hd - 1u;
+                        const unsigned xm = x ? x - 1u : 0u, xp = x + 1u < Wd ? x + 1u : Wd - 1u;
+                        float w9[9];
+                        w9[0] = s_val[ym * Wd + xm - lo]; w9[1] = s_val[ym * Wd + x - lo]; w9[2] = s_val[ym * Wd + xp - lo];
+                        w9[3] = s_val[y * Wd + xm - lo];  w9[4] = c;                        w9[5] = s_val[y * Wd + xp - lo];
+                        w9[6] = s_val[yp * Wd + xm - lo]; w9[7] = s_val[yp * Wd + x - lo]; w9[8] = s_val[yp * Wd + xp - lo];
+                        r = ddmath::median9(w9);
+                    }
+                    r = (c != 0.0f) ? r : 0.0f;      // :203 zero outside the mask (a masked pixel's value is >= 1e-3 or NaN, never 0)
+                    if (r > 0.0f) b |= 1u << k;       // scripts/test.py:194 + :210: mask AND refined depth > 0
+                }
+                ref[ch][k] = r;
+                if (++x == Wd) { x = 0; ++y; }
+            }
+            bits[ch] = b;
+            d[ch].x = __float_as_uint(ref[ch][0]); d[ch].y = __float_as_uint(ref[ch][1]);
+            d[ch].z = __float_as_uint(ref[ch][2]); d[ch].w = __float_as_uint(ref[ch][3]);
+            if (a.refined_out) {                       // the filter's cache (scripts/test.py:197-201)
+                float *o = a.refined_out + vbase + qb;
+                if (qb + (unsigned)VEC <= a.P && ((vbase + qb) & 3) == 0) *reinterpret_cast<uint4 *>(o) = d[ch];
+                else {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) if (qb + (unsigned)k < a.P) o[k] = ref[ch][k];
+                }
+            }
+        }
+        __syncthreads();                               // s_val is dead from here: the point list takes its place
+    } else {
+        lean_load_test<DepthT, HAS_MASK, true>(a, vbase, qw, lane, d, bits);
+    }
 
     int lane_pre[CH], tot[CH], m = 0;
 #pragma unroll
@@ -1020,6 +1094,7 @@ constexpr unsigned TUNE_TWO_PASS = 4u;        // dd_unproject_compact: plan + sc
 constexpr unsigned TUNE_SINGLE_PASS = 8u;     // dd_unproject_compact: ticket + decoupled look-back (default on the lean path)
 
 struct Plan {
+    bool refine;    // DD_REFINE: the fused refine stage (single-pass lean kernel, float32)
     bool f16;
     bool lean;      // stride-1 maps (any size >= one vector) -> lean kernels; otherwise the generic scalar kernels
     bool single;    // dd_unproject_compact runs the single-pass kernel
@@ -1054,10 +1129,23 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
     a.view_base = b->view_index_base;
 
     p.f16 = (b->depth_dtype == DD_F16);
+    p.refine = (b->flags & DD_REFINE) != 0;
+    if (p.refine) {
+        // the fused refine stage: float32 single-pass lean kernel, raw depth read element by element
+        if (b->stride != 1) return fail(DD_ERR_UNSUPPORTED, "DD_REFINE needs stride 1 (at a coarser density refine with dd_refine_apply first)");
+        if (b->flags & DD_VALID_CONF) return fail(DD_ERR_UNSUPPORTED, "DD_REFINE does not combine with DD_VALID_CONF");
+        if (b->width > 3071 || hw < 4) return fail(DD_ERR_UNSUPPORTED, "DD_REFINE handles widths up to 3071 (tile + halo must fit the LDS)");
+        if (b->tuning & (TUNE_FORCE_GENERIC | TUNE_TWO_PASS)) return fail(DD_ERR_UNSUPPORTED, "DD_REFINE runs in the single-pass kernel only");
+        if ((b->flags & DD_VALID_MASK) && !b->mask) return fail(DD_ERR_INVALID_ARG, "DD_VALID_MASK set but mask is NULL");
+        a.refined_out = b->refined_out;
+        a.raw_f16 = p.f16;
+        if (!(b->flags & DD_VALID_MASK)) a.mask = nullptr;      // mask = raw depth > 0 (depth_refiner.py:241)
+        p.f16 = false;
+    }
     const int vec = p.f16 ? 8 : 4;
     // lean kernels: stride 1, any view size of at least one vector; pointers need element alignment only (views of
     // H*W % vec != 0 pixels start off the 16-byte grid anyway; the wide loads are element-aligned)
-    bool aligned = (b->stride == 1) && (hw >= vec) && ((uintptr_t)b->depth % (p.f16 ? 2 : 4) == 0);
+    bool aligned = (b->stride == 1) && (hw >= vec) && (p.refine || (uintptr_t)b->depth % (p.f16 ? 2 : 4) == 0);
     if (b->flags & DD_VALID_CONF) aligned = aligned && ((uintptr_t)b->conf % (b->conf_dtype == DD_F16 ? 2 : 4) == 0);
     if (b->tuning & TUNE_FORCE_GENERIC) aligned = false;
     p.lean = aligned;
@@ -1120,8 +1208,21 @@ void launch_lean(const KArgs &a, hipStream_t s) {
     else launch_lean3<DepthT, SP, false, false>(a, s);
 }
 
+void launch_refine(const KArgs &a, hipStream_t s) {
+    const dim3 grid(a.num_tiles), block(64 * SP_WAVES);
+    const bool hn = a.out_normal != nullptr, hc = a.rgb && (a.out_rgb || a.out_packed);
+    if (hn && hc) hipLaunchKernelGGL((compact_lean<float, false, true, true, true, SP_WAVES, true>), grid, block, 0, s, a);
+    else if (hn) hipLaunchKernelGGL((compact_lean<float, false, true, true, false, SP_WAVES, true>), grid, block, 0, s, a);
+    else if (hc) hipLaunchKernelGGL((compact_lean<float, false, true, false, true, SP_WAVES, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((compact_lean<float, false, true, false, false, SP_WAVES, true>), grid, block, 0, s, a);
+}
+
 template <bool SP>
 void launch_scatter(const Plan &p, const KArgs &a, hipStream_t s) {
+    if (p.refine) {
+        launch_refine(a, s);
+        return;
+    }
     if (p.lean) {
         if (p.f16) launch_lean<_Float16, SP>(a, s); else launch_lean<float, SP>(a, s);
     } else {
@@ -1184,6 +1285,7 @@ int dd_count_valid(const DDViewBatch *batch, int64_t *counts_dev, void *stream) 
     int rc = make_plan(batch, a, p);
     if (rc != DD_OK) return rc;
     if (!counts_dev) return fail(DD_ERR_INVALID_ARG, "counts_dev is NULL");
+    if (p.refine) return fail(DD_ERR_UNSUPPORTED, "DD_REFINE is handled by dd_unproject_compact only");
     hipStream_t s = (hipStream_t)stream;
     a.counts = reinterpret_cast<unsigned long long *>(counts_dev);
     if (hipMemsetAsync(counts_dev, 0, sizeof(int64_t) * (size_t)a.V, s) != hipSuccess)
@@ -1205,6 +1307,7 @@ int dd_plan(const DDViewBatch *batch, const int64_t *cursor_dev, int64_t *view_o
     int rc = make_plan(batch, a, p);
     if (rc != DD_OK) return rc;
     if (!view_offsets_dev || !cursor_dev) return fail(DD_ERR_INVALID_ARG, "view_offsets_dev / cursor_dev is NULL");
+    if (p.refine) return fail(DD_ERR_UNSUPPORTED, "DD_REFINE is handled by dd_unproject_compact only");
     if ((rc = bind_workspace(a, workspace, workspace_bytes)) != DD_OK) return rc;
     a.view_offsets = reinterpret_cast<long long *>(view_offsets_dev);
     a.cursor = reinterpret_cast<const long long *>(cursor_dev);
@@ -1218,6 +1321,7 @@ int dd_scatter(const DDViewBatch *batch, const DDCloudOut *out, const int64_t *v
     if (rc != DD_OK) return rc;
     if ((rc = bind_output(a, batch, out)) != DD_OK) return rc;
     if (!view_offsets_dev) return fail(DD_ERR_INVALID_ARG, "view_offsets_dev is NULL");
+    if (p.refine) return fail(DD_ERR_UNSUPPORTED, "DD_REFINE is handled by dd_unproject_compact only");
     if ((rc = bind_workspace(a, workspace, workspace_bytes)) != DD_OK) return rc;
     a.view_offsets = const_cast<long long *>(reinterpret_cast<const long long *>(view_offsets_dev));
     launch_scatter<false>(p, a, (hipStream_t)stream);

@@ -13,6 +13,7 @@
 #include <stdio.h>
 
 #include "ddcore.h"
+#include "ddrefine_math.h"
 
 namespace {
 
@@ -32,25 +33,7 @@ __device__ __forceinline__ float read_depth(const RArgs &a, int idx) {
     return a.f16 ? (float)reinterpret_cast<const _Float16 *>(a.depth)[idx] : reinterpret_cast<const float *>(a.depth)[idx];
 }
 
-// torch.searchsorted(xs, d, right=False) clamped to [1, n-1], then the linear blend of :160-176
-__device__ __forceinline__ float lut(const float *kx, const float *ky, int n, float d) {
-#pragma clang fp contract(off)   // the reference rounds after the multiply (separate tensor ops): no FMA here
-    if (d != d) return d;                   // torch.clamp / torch.maximum propagate a NaN depth (:168-176): the pixel later fails depth > 0
-    int lo = 0, hi = n;                     // first index with kx[i] >= d
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (kx[mid] < d) lo = mid + 1; else hi = mid;
-    }
-    int i = lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
-    const float x0 = kx[i - 1], x1 = kx[i], y0 = ky[i - 1], y1 = ky[i];
-    float dx = x1 - x0;
-    if (dx == 0.0f) dx = 1e-6f;
-    float t = (d - x0) / dx;
-    t = fminf(fmaxf(t, 0.0f), 1.0f);
-    return fmaxf(y0 + t * (y1 - y0), 1e-3f);
-}
-
-#define CSWAP(a, b) { const float lo_ = fminf(v[a], v[b]), hi_ = fmaxf(v[a], v[b]); v[a] = lo_; v[b] = hi_; }
+using ddmath::lut;
 
 __global__ __launch_bounds__(256) void refine_apply_kernel(const RArgs a) {
     __shared__ float s_val[HH_][HW_ + 1];
@@ -83,14 +66,11 @@ __global__ __launch_bounds__(256) void refine_apply_kernel(const RArgs a) {
             r = s_val[ly + 1][lx + 1];
         } else {                                                       // median of the 3x3 window (:194-200)
             float v[9];
-            bool has_nan = false;                                      // torch.median of a window holding a NaN is NaN
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) { v[dy * 3 + dx] = s_val[ly + dy][lx + dx]; has_nan |= v[dy * 3 + dx] != v[dy * 3 + dx]; }
-            CSWAP(1, 2) CSWAP(4, 5) CSWAP(7, 8) CSWAP(0, 1) CSWAP(3, 4) CSWAP(6, 7) CSWAP(1, 2) CSWAP(4, 5) CSWAP(7, 8)
-            CSWAP(0, 3) CSWAP(5, 8) CSWAP(4, 7) CSWAP(3, 6) CSWAP(1, 4) CSWAP(2, 5) CSWAP(4, 7) CSWAP(4, 2) CSWAP(6, 4) CSWAP(4, 2)
-            r = has_nan ? __builtin_nanf("") : v[4];
+                for (int dx = 0; dx < 3; ++dx) v[dy * 3 + dx] = s_val[ly + dy][lx + dx];
+            r = ddmath::median9(v);
         }
         const int idx = gy * a.W + gx;
         const bool m = a.mask ? (a.mask[idx] != 0) : (read_depth(a, idx) > 0.0f);

@@ -158,7 +158,12 @@ class ViewBatch:
                  conf_threshold: Optional[float] = None, normal: Optional[ArrayLike] = None,
                  rgb: Optional[ArrayLike] = None, stride: int = 1, semantics: str = "script",
                  rotate_normals: Optional[bool] = None, view_index_base: int = 0, device=None,
-                 tuning: int = 0, depth_positive_on_mask: bool = False):
+                 tuning: int = 0, depth_positive_on_mask: bool = False, refine=None, refined_out=None):
+        """``refine``: per view ``(knots_x, knots_y, skip_smoothing)`` (or one tuple for a single view), sorted float32 device
+        knots of the refiner's transfer curve: ``depth`` is then the RAW monocular map and the densify kernel refines it on
+        the fly (``DD_REFINE``: ``depth_refiner.py:180-205`` fused with ``scripts/test.py:194-233``; stride 1, width <= 3071,
+        2..512 knots).  ``refined_out``: ``True`` or a (V,H,W) float32 tensor to receive the refined, mask-zeroed map (the
+        filter's cache, ``scripts/test.py:197-201``); available as ``self.refined`` afterwards."""
         if semantics not in SEMANTICS:
             raise ValueError(f"semantics must be one of {SEMANTICS}")
         dev = _require_gpu(device)
@@ -207,6 +212,35 @@ class ViewBatch:
         blocks = camera_blocks(intrinsics, cam_from_world)
         if blocks.shape[0] != V:
             raise ValueError(f"{blocks.shape[0]} cameras for {V} views")
+        self._knots = None
+        self.refined = None
+        if refine is not None:
+            curves = [refine] if (isinstance(refine, tuple) and len(refine) == 3 and not isinstance(refine[0], tuple)) else list(refine)
+            if len(curves) != V:
+                raise ValueError(f"{len(curves)} transfer curves for {V} views")
+            if semantics != "script" or conf is not None or stride != 1 or W > 3071:
+                raise ValueError("refine= needs script semantics, stride 1, no confidence map and width <= 3071")
+            i32, u64 = blocks.view(np.int32), blocks.view(np.uint64)       # DDViewParams: n_knots / skip at floats 21, 22; pointers at bytes 96, 104
+            keep = []
+            for v, (kx, ky, skip) in enumerate(curves):
+                kx = _gpu(kx, dev, torch.float32)
+                ky = _gpu(ky, dev, torch.float32)
+                if kx.dim() != 1 or kx.shape != ky.shape or not 2 <= kx.numel() <= 512:
+                    raise ValueError("a transfer curve needs 2..512 knots, knots_x and knots_y of equal length")
+                keep.append((kx, ky))
+                i32[v, 21], i32[v, 22] = kx.numel(), 1 if skip else 0
+                u64[v, 12], u64[v, 13] = kx.data_ptr(), ky.data_ptr()
+            self._knots = keep
+            if refined_out is True:
+                refined_out = torch.empty((V, H, W), dtype=torch.float32, device=dev)
+            if refined_out is not None:
+                if refined_out.dim() == 2:
+                    refined_out = refined_out[None]
+                if tuple(refined_out.shape) != (V, H, W) or refined_out.dtype != torch.float32 or not refined_out.is_contiguous() or refined_out.device != dev:
+                    raise ValueError("refined_out must be a contiguous float32 (V,H,W) tensor on the batch's device")
+                self.refined = refined_out
+        elif refined_out is not None:
+            raise ValueError("refined_out needs refine=")
         self.params = torch.from_numpy(blocks).to(dev)
         self.view_index_base = int(view_index_base)
         self.tuning = int(tuning)
@@ -232,6 +266,8 @@ class ViewBatch:
         self.rotate_normals = rot_default if rotate_normals is None else bool(rotate_normals)
         if self.rotate_normals:
             flags |= _lib.DD_ROTATE_NORMALS
+        if self._knots is not None:
+            flags |= _lib.DD_REFINE | _lib.DD_VALID_DEPTH_POSITIVE
         self.flags = flags
         self.device = dev
 
@@ -243,7 +279,8 @@ class ViewBatch:
         sub = object.__new__(ViewBatch)
         sub.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("_cstruct", "_ws_bytes")})
         cut = lambda t: None if t is None else t[lo:hi]
-        sub.depth, sub.mask, sub.conf, sub.normal, sub.rgb, sub.params = (cut(t) for t in (self.depth, self.mask, self.conf, self.normal, self.rgb, self.params))
+        sub.depth, sub.mask, sub.conf, sub.normal, sub.rgb, sub.params, sub.refined = (
+            cut(t) for t in (self.depth, self.mask, self.conf, self.normal, self.rgb, self.params, self.refined))
         sub.view_index_base = self.view_index_base + lo
         return sub
 
@@ -289,7 +326,7 @@ class ViewBatch:
             depth_dtype=_lib.DD_F16 if self.depth.dtype == torch.float16 else _lib.DD_F32,
             conf_dtype=_lib.DD_F16 if (self.conf is not None and self.conf.dtype == torch.float16) else _lib.DD_F32,
             conf_threshold=self.conf_threshold, flags=self.flags,
-            view_index_base=self.view_index_base, tuning=self.tuning,
+            view_index_base=self.view_index_base, tuning=self.tuning, refined_out=ptr(self.refined),
         )
 
 

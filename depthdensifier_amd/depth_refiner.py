@@ -130,10 +130,9 @@ class DepthRefiner:
         out = y0 + t * (y1 - y0)
         return torch.maximum(out, torch.tensor(1e-3, device=self.device, dtype=self.dtype))
 
-    def _apply_curve_hip(self, depth: torch.Tensor, mask: Optional[torch.Tensor], x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
-        """The same per-pixel work as ``_apply_curve`` in one hand-written kernel (``dd_refine_apply``,
-        ``csrc/ddrefine.hip``): the view is read once and written once.  Always float32 arithmetic."""
-        from ._lib import DD_F16, DD_F32, DDCoreError, lib
+    def _sorted_knots(self, x: torch.Tensor, y: torch.Tensor):
+        """The knots ordered by x (``torch.argsort``, ``depth_refiner.py:149-151``), float32, on the device."""
+        from ._lib import DDCoreError, lib
         xf, yf = x.float().contiguous(), y.float().contiguous()
         if xf.numel() <= 4096:                                # one launch instead of argsort + two gathers
             kx, ky = torch.empty_like(xf), torch.empty_like(yf)
@@ -141,9 +140,15 @@ class DepthRefiner:
                                    torch.cuda.current_stream(xf.device).cuda_stream)
             if rc < 0:
                 raise DDCoreError(rc, lib.dd_refine_last_error().decode())
-        else:
-            order = torch.argsort(xf)
-            kx, ky = xf[order].contiguous(), yf[order].contiguous()
+            return kx, ky
+        order = torch.argsort(xf)
+        return xf[order].contiguous(), yf[order].contiguous()
+
+    def _apply_curve_hip(self, depth: torch.Tensor, mask: Optional[torch.Tensor], x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        """The same per-pixel work as ``_apply_curve`` in one hand-written kernel (``dd_refine_apply``,
+        ``csrc/ddrefine.hip``): the view is read once and written once.  Always float32 arithmetic."""
+        from ._lib import DD_F16, DD_F32, DDCoreError, lib
+        kx, ky = self._sorted_knots(x, y)
         d = depth if depth.dtype in (torch.float16, torch.float32) else depth.float()
         d = d.contiguous()
         m = None if mask is None else mask.contiguous().view(torch.uint8)
@@ -199,11 +204,15 @@ class DepthRefiner:
     # ---- API --------------------------------------------------------------------------
     def refine_depth(self, depth_map: ArrayLike, normal_map: Optional[ArrayLike], points3D: ArrayLike,
                      cam_from_world: ArrayLike, K: ArrayLike, mask: Optional[ArrayLike] = None,
-                     return_tensor: bool = False, generator: Optional[torch.Generator] = None,
+                     return_tensor: bool = False, generator: Optional[torch.Generator] = None, fit_only: bool = False,
                      **kwargs) -> dict[str, Any]:
         """Same contract as the reference (``depth_refiner.py:207-328``).  Extras: ``return_tensor=True``
         leaves ``refined_depth`` on the device (float32 tensor) for the densify kernels;
-        ``generator`` seeds the 500-correspondence subsample (the reference's is unseeded, ``:304``)."""
+        ``generator`` seeds the 500-correspondence subsample (the reference's is unseeded, ``:304``);
+        ``fit_only=True`` (GPU) stops after the correspondence fit and returns ``curve = (knots_x, knots_y,
+        skip_smoothing)`` with ``refined_depth = None`` when the curve can be applied inside the densify kernel
+        (``ViewBatch(refine=...)``; ``raw_depth`` is the map in the refiner's working precision, which is what the curve
+        must be applied to) -- early exits and unusual curves still return a map."""
         if self.verbose > 1:
             print(f"[DepthRefiner] Input depth shape: {tuple(depth_map.shape)}")
             print(f"[DepthRefiner] COLMAP points: {len(points3D)}")
@@ -228,8 +237,16 @@ class DepthRefiner:
                 pick = torch.randperm(kept, device=self.device, generator=generator)[:500]
                 z_mono, z_metric = z_mono[pick], z_metric[pick]
                 scale = float(torch.median(z_metric / (z_mono + 1e-6)).cpu())
-            refined = self._apply_curve(depth, m, z_mono, z_metric)
             n_corr = int(z_mono.numel())
+            if fit_only:
+                # hand the curve out instead of applying it: the densify kernel refines on the fly (ViewBatch(refine=...)).
+                # Only where dd_refine_apply would have been taken (>= 4 masked pixels, see _apply_curve) and the curve fits
+                # the kernel's LDS table; otherwise the caller gets the refined map as usual.
+                if 2 <= n_corr <= 512 and int(m.sum().item()) >= 4:
+                    kx, ky = self._sorted_knots(z_mono, z_metric)
+                    return {"refined_depth": None, "curve": (kx, ky, bool(self.skip_smoothing)), "raw_depth": depth,
+                            "num_correspondences": n_corr, "outliers_removed": removed, "scale_factor": scale}
+            refined = self._apply_curve(depth, m, z_mono, z_metric)
             if self.verbose > 0:
                 print(f"[DepthRefiner] Refined using {n_corr} correspondences")
                 if removed > 0:

@@ -225,16 +225,24 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
         normal = maps["normal"]
         if normal is None:
             normal = torch.zeros((new_h, new_w, 3), dtype=torch.float32, device=device)
+        fuse = s == 1 and new_w <= 3071          # full density: the densify kernel applies the transfer curve itself
         res = refiner.refine_depth(depth_map=maps["depth"], normal_map=normal, points3D=pts_world, cam_from_world=E, K=K,
-                                   mask=maps["mask"], return_tensor=True)        # :179-186
+                                   mask=maps["mask"], return_tensor=True, fit_only=fuse)   # :179-186
         refined = res["refined_depth"]
         t4 = clock()
-        refined = refined if isinstance(refined, torch.Tensor) else torch.as_tensor(refined, device=device)
-        refined = refined.float()
         # :194 "refined_depth[~moge_mask] = 0" is the kernels' validity rule (mask AND depth > 0);
         # :203-240 densify + append
-        batch = ViewBatch(refined, camera.pinhole_params()[None], E[None], mask=maps["mask"], normal=normal, rgb=rgb,
-                          stride=s, view_index_base=lo + len(cached), device=device)
+        if refined is None:
+            # raw depth -> LUT + 3x3 median -> validity -> unprojection in ONE kernel; the refined map it writes on the way
+            # is the filter's cache (:197-201).  Same bits as dd_refine_apply followed by the plain densify call.
+            batch = ViewBatch(res["raw_depth"], camera.pinhole_params()[None], E[None], mask=maps["mask"], normal=normal, rgb=rgb,
+                              stride=s, view_index_base=lo + len(cached), device=device, refine=res["curve"], refined_out=True)
+            refined = batch.refined[0]
+        else:
+            refined = refined if isinstance(refined, torch.Tensor) else torch.as_tensor(refined, device=device)
+            refined = refined.float()
+            batch = ViewBatch(refined, camera.pinhole_params()[None], E[None], mask=maps["mask"], normal=normal, rgb=rgb,
+                              stride=s, view_index_base=lo + len(cached), device=device)
         builder.append(batch)
         cached.append(dict(depth=refined, mask=maps["mask"], K=K, E=E))         # :197-201
         t5 = clock()

@@ -42,6 +42,10 @@ enum { DD_F32 = 0, DD_F16 = 1 };
 #define DD_VALID_MASK           0x2u /* mask  != 0           scripts/test.py:194, visualizer.py:312 */
 #define DD_VALID_CONF           0x4u /* conf  > threshold    (build-defined)          */
 #define DD_ROTATE_NORMALS       0x8u /* n_w = R^T n / (|R^T n| + 1e-8)   visualizer.py:363-374      */
+#define DD_REFINE               0x10u /* depth is the RAW map; refine it per DDViewParams.knots_* inside the densify kernel
+                                        (src/depthdensifier/depth_refiner.py:180-205 fused with scripts/test.py:194-233).
+                                        dd_unproject_compact only, stride 1, width <= 3071, no DD_VALID_CONF; the validity
+                                        rule is the script's: mask (or raw depth > 0 without one) AND refined depth > 0 */
 
 /*
  * Per-view camera block, 32 floats (128 B), device memory, built on the host in
@@ -56,7 +60,15 @@ typedef struct DDViewParams {
     float ray_to_world[9];
     float centre[3];
     float rot[9];
-    float reserved[11];
+    /* Optional depth->depth transfer curve of this view (DD_REFINE, see DDViewBatch.flags): the kernel then reads the RAW
+     * monocular depth and refines it on the fly exactly like dd_refine_apply -- sorted look-up table with linear
+     * interpolation (depth_refiner.py:141-178), 3x3 median (:194-200), zero outside the mask (:203). */
+    int32_t n_knots;          /* 2..512 */
+    int32_t skip_smoothing;
+    int32_t reserved0;
+    const float *knots_x;     /* (n_knots) device, ascending */
+    const float *knots_y;     /* (n_knots) device */
+    float reserved[4];
 } DDViewParams;
 
 /*
@@ -82,6 +94,8 @@ typedef struct DDViewBatch {
     int32_t view_index_base;  /* added to the per-point view index (global view id of view 0) */
     uint32_t tuning;          /* 0 = default; 1 = force the scalar kernels; 4 / 8 = dd_unproject_compact as
                                  plan + scatter / as the single-pass look-back kernel (default on stride-1 maps) */
+    float *refined_out;       /* DD_REFINE: NULL, or (V,H,W) float32 receiving the refined, mask-zeroed depth -- the map the
+                                 reference caches for the multi-view filter (scripts/test.py:194, 197-201) */
 } DDViewBatch;
 
 /*

@@ -235,3 +235,52 @@ def test_sort_knots_kernel():
         order = torch.argsort(x)
         assert torch.equal(xs, x[order]) and torch.equal(ys, y[order])
     assert lib.dd_sort_knots(x.data_ptr(), y.data_ptr(), 5000, xs.data_ptr(), ys.data_ptr(), None) == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("skip", (False, True))
+@pytest.mark.parametrize("dtype", ("float32", "float16"))
+@pytest.mark.parametrize("shape, with_mask", [((96, 128), True), ((37, 53), True), ((200, 333), False), ((540, 960), True), ((5, 3000), True)])
+def test_fused_refine_densify_equals_apply_then_densify(shape, with_mask, dtype, skip):
+    """DD_REFINE: the densify kernel applying the transfer curve to the RAW depth itself (LUT + 3x3 median over a halo held
+    in LDS + mask) must give, bit for bit, what dd_refine_apply followed by the plain densify call gives -- cloud AND the
+    refined map it writes for the filter cache.  Several tiles per view, ragged sizes, NaN / inf / zero raw depths, holes."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import depthdensifier_amd as dd
+    from depthdensifier_amd.depth_refiner import DepthRefiner
+    H, W = shape
+    V = 3
+    g = torch.Generator().manual_seed(H * 7 + W)
+    raw = (torch.rand((V, H, W), generator=g) * 4 + 0.2)
+    raw[torch.rand((V, H, W), generator=g) < 0.05] = 0.0
+    flat = raw.view(-1)
+    flat[::997] = float("nan"); flat[5::1013] = float("inf"); flat[7::1019] = -1.0
+    raw = raw.to(getattr(torch, dtype)).cuda()
+    mask = (torch.rand((V, H, W), generator=g) < 0.85).cuda() if with_mask else None
+    normal = torch.nn.functional.normalize(torch.randn((V, H, W, 3), generator=g), dim=-1).cuda()
+    rgb = torch.randint(0, 256, (V, H, W, 3), generator=g, dtype=torch.uint8).cuda()
+    params = np.tile([0.9 * W, 0.9 * W, W / 2.0, H / 2.0], (V, 1))
+    from synth import random_pose
+    rng = np.random.default_rng(H + W)
+    E = np.stack([random_pose(rng) for _ in range(V)])
+    r = DepthRefiner(use_fp16=False, skip_smoothing=skip)
+    curves, refined = [], []
+    for v in range(V):
+        n = 120 + 130 * v
+        x = torch.rand(n, generator=g) * 3 + 0.5
+        y = 2.0 * x + 0.3 * torch.rand(n, generator=g)
+        kx, ky = r._sorted_knots(x.cuda(), y.cuda())
+        curves.append((kx, ky, skip))
+        m = mask[v] if mask is not None else raw[v] > 0
+        refined.append(r._apply_curve_hip(raw[v], m if mask is not None else None, x.cuda(), y.cuda()))
+    refined = torch.stack(refined)
+    want = dd.unproject_views(refined, params, E, mask=mask, normal=normal, rgb=rgb, view_index=True, capacity="max")
+    batch = dd.ViewBatch(raw, params, E, mask=mask, normal=normal, rgb=rgb, refine=curves, refined_out=True)
+    b = dd.CloudBuilder(batch.max_points, normals=True, colors=True, pixel_index=True, view_index=True)
+    b.append(batch)
+    got = b.finish()
+    assert torch.equal(got.view_offsets, want.view_offsets)
+    for name in ("points", "colors", "normals", "pixel_index", "view_index"):
+        assert torch.equal(getattr(got, name), getattr(want, name)), name
+    assert torch.equal(batch.refined.view(torch.int32), refined.view(torch.int32))          # NaNs included, bit for bit

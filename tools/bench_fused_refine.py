@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Raw MoGe depth -> points: dd_refine_apply + densify (two kernels, refined map written and re-read) against the fused
+DD_REFINE kernel (LUT + 3x3 median + validity + unprojection in one pass; the refined map is still written once for the
+filter cache).  GPU box only.   python tools/bench_fused_refine.py [--views 64]"""
+import argparse, sys
+from pathlib import Path
+import numpy as np, torch
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import bench, depthdensifier_amd as dd
+from depthdensifier_amd.depth_refiner import DepthRefiner
+
+ap = argparse.ArgumentParser(); ap.add_argument("--views", type=int, default=64); a = ap.parse_args()
+dev = torch.device("cuda", 0)
+cfg = dict(bench.WORKLOADS["garden185"]); cfg["V"] = a.views
+ids = np.arange(a.views)
+scene = bench.make_scene(cfg, ids, dev)
+H, W = cfg["H"], cfg["W"]
+V = a.views
+params = np.tile([0.8 * W, 0.8 * W, W / 2.0, H / 2.0], (V, 1))
+E = bench.ring_poses(ids, V)
+r = DepthRefiner(use_fp16=False)
+g = torch.Generator(device=dev).manual_seed(0)
+x = torch.rand(500, device=dev, generator=g) * 7 + 1
+kx, ky = r._sorted_knots(x, 1.1 * x + 0.05 * torch.rand(500, device=dev, generator=g))
+refined = torch.empty((V, H, W), dtype=torch.float32, device=dev)
+
+def unfused():
+    for v in range(V):
+        refined[v] = r._apply_curve_hip(scene["depth"][v], scene["mask"][v], kx, ky)      # (sorts the sorted knots again: one tiny launch)
+    batch = dd.ViewBatch(refined, params, E, mask=scene["mask"], normal=scene["normal"], rgb=scene["rgb"], device=dev)
+    b.reset(); b.append(batch)
+
+fused_batch = dd.ViewBatch(scene["depth"], params, E, mask=scene["mask"], normal=scene["normal"], rgb=scene["rgb"], device=dev,
+                           refine=[(kx, ky, False)] * V, refined_out=True)
+def fused():
+    b.reset(); b.append(fused_batch)
+
+b = dd.CloudBuilder(fused_batch.max_points, normals=True, colors=True, pixel_index=False, device=dev)
+res = {}
+for name, fn in (("unfused", unfused), ("fused", fused), ("unfused", unfused), ("fused", fused)):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5): fn()
+    e1.record(); torch.cuda.synchronize()
+    n = b.check()
+    res[name] = e0.elapsed_time(e1) / 5
+    print(f"{name:8s} {res[name]:8.3f} ms per {V} views = {res[name] / V * 1e3:7.1f} us per 1080p view, {n} points")
+pix = V * H * W
+rho = n / pix
+print(f"bytes per pixel by the model: unfused {5 + 4 + 5 + rho * 42:.1f} (refine 5 r + 4 w, densify 5 r + rho 42), fused {5 + 4 + rho * 42:.1f} "
+      f"(5 r + 4 w for the filter cache + rho 42); rho = {rho:.3f}")
