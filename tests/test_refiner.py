@@ -63,11 +63,14 @@ def test_constructor_overrides_and_config():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ("default", "nomask"))
+@pytest.mark.parametrize("name", ("default", "nosmooth", "notrobust", "nomask"))
 def test_gpu_fp32_matches_golden_and_stays_on_device(g, name):
+    """GPU / FP32 (dd_refine_fit + dd_refine_apply) against the outputs of the reference's own class: the same
+    correspondences, the same outliers, the same scale, the refined map to 2e-4 of its range (measured 3e-5 .. 9e-5: the
+    bilinear samples differ from the CPU's in the last bit and the steep segments of the transfer curve amplify that)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    r = _refiner()
+    r = _refiner(**VARIANTS[name])
     assert r.device.type == "cuda"
     mask = g.get(f"{name}_in_mask")
     out = r.refine_depth(g[f"{name}_in_depth"], None, g[f"{name}_in_points3D"], g[f"{name}_in_cam_from_world"][:3],
@@ -75,9 +78,12 @@ def test_gpu_fp32_matches_golden_and_stays_on_device(g, name):
     t = out["refined_depth"]
     assert isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32
     exp = g[f"{name}_exp_refined_depth__refine_depth"]
-    # GPU matmul / grid_sample round differently from the CPU: a correspondence on the IQR edge may flip
+    assert out["num_correspondences"] == int(g[f"{name}_exp_num_correspondences__refine_depth"])
+    assert out["outliers_removed"] == int(g[f"{name}_exp_outliers_removed__refine_depth"])
+    assert abs(out["scale_factor"] - float(g[f"{name}_exp_scale_factor__refine_depth"])) <= 1e-6 * abs(out["scale_factor"])
     diff = np.abs(t.cpu().numpy() - exp)
-    assert np.median(diff) <= 1e-5 and np.quantile(diff, 0.999) <= 2e-2 * exp.max()
+    assert np.array_equal(t.cpu().numpy() > 0, exp > 0)
+    assert diff.max() <= 2e-4 * exp.max() and np.median(diff) <= 1e-6
 
 
 @pytest.mark.gpu
