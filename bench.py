@@ -260,7 +260,13 @@ def strong_scaling_record(args, dd, D, dist, use_dist, rank, world, device, fenc
                 b.append(batch.slice(clo, chi))
             return b.check(), counts
 
-        dt, _ = timed(replicated, args.strong_steps)
+        try:
+            dt, _ = timed(replicated, args.strong_steps)
+        except Exception as e:      # noqa: BLE001  (one leg failing must not cost the others)
+            rec[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            del bufs
+            torch.cuda.empty_cache()
+            continue
         recv = (n_total - n_own) * rec_bytes
         rec[key] = {"ms": round(dt * 1e3, 3), "mpixels_per_s": round(pixels / dt / 1e6, 1), "mpoints_per_s": round(n_total / dt / 1e6, 1),
                     "record_bytes": rec_bytes, "cloud_bytes": need, "bytes_received_per_rank": recv,
