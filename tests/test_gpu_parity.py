@@ -564,6 +564,49 @@ def test_per_gpu_share_of_the_2000_view_scene_with_normals(dd, orc):
     assert torch.equal(packed.colors, rows.colors)
 
 
+@pytest.mark.parametrize("rho", (0.05, 0.5, 0.97))
+def test_every_row_alignment_of_the_first_row(dd, rho):
+    """The lean kernel shifts its sweeps so that wave runs start on 128-byte lines of the outputs (32-row period); the
+    shift depends on the tile's first row.  Start the cloud at every row 0..40 (all 32 phases), with sparse / medium /
+    nearly dense tiles (lists shorter than one sweep, a few sweeps, almost full), all fields, and with the capacity cutting
+    the cloud at an odd row: the rows written are always the same rows, shifted."""
+    import torch
+    V, H, W = 3, 211, 307                          # ~65 k pixels per view: 5-6 tiles, ragged end
+    g = torch.Generator(device="cuda").manual_seed(int(rho * 100))
+    depth = torch.empty((V, H, W), device="cuda").uniform_(0.5, 8.0, generator=g)
+    mask = torch.rand((V, H, W), device="cuda", generator=g) < rho
+    normal = torch.nn.functional.normalize(torch.randn((V, H, W, 3), device="cuda", generator=g), dim=-1)
+    rgb = torch.randint(0, 256, (V, H, W, 3), device="cuda", generator=g, dtype=torch.uint8)
+    params = np.tile([0.8 * W, 0.8 * W, W / 2, H / 2], (V, 1))
+    E = _ring_poses(V)
+    batch = dd.ViewBatch(depth, params, E, mask=mask, normal=normal, rgb=rgb)
+    ref = dd.CloudBuilder(batch.max_points, normals=True, colors=True, pixel_index=True, view_index=True, packed=True)
+    ref.append(batch)
+    want = ref.finish()
+    n = len(want)
+    assert n == int(mask.sum())
+    fields = ("points", "normals", "colors", "pixel_index", "view_index", "packed")
+    for start in list(range(0, 41)) + [95, 127, 1000003]:
+        for cut in (0, 777):                       # capacity = everything, or 777 rows short
+            cap = start + n - cut
+            b = dd.CloudBuilder(cap, normals=True, colors=True, pixel_index=True, view_index=True, packed=True, start=start)
+            for t in (b.xyz, b.normal, b.packed):
+                t.fill_(-7.0)
+            b.rgb.fill_(201); b.pix.fill_(-7); b.view.fill_(-7)
+            b.append(batch)
+            torch.cuda.synchronize()
+            assert int(b.cursor.item()) == start + n                      # counted even where not written
+            kept = n - cut
+            got = dict(points=b.xyz, normals=b.normal, colors=b.rgb, pixel_index=b.pix, view_index=b.view, packed=b.packed)
+            for name in fields:
+                w = getattr(want, name)[:kept]
+                t = got[name]
+                assert torch.equal(t[start:start + kept].view(torch.uint8), w.contiguous().view(torch.uint8)), (start, cut, name)
+                if start:                                                  # nothing before the first row was touched
+                    head = t[:start]
+                    assert bool((head == (201 if name == "colors" else -7)).all()), (start, cut, name, "rows before the start")
+
+
 def test_c_abi_client_without_python(tmp_path):
     """A C++/HIP program linking libddcore.so (no torch, no Python in the loop) drives dd_plan + dd_scatter and
     the fused call and checks them against its own float64 loop (tests/c_client/abi_client.cpp)."""
