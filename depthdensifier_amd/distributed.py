@@ -229,12 +229,22 @@ def plan_fuse(local_counts: torch.Tensor, num_views_total: int, chunks: int = 1,
     counts = exchange_counts(local_counts, num_views_total, group)
     view_offsets = offsets_from_counts(counts)
     host = view_offsets.tolist()
+    chunk_views, chunk_rows = layout_chunks(host, world, rank, chunks)
+    return FusePlan(view_offsets, host, rank, world, num_views_total, chunk_views, chunk_rows)
+
+
+def layout_chunks(offsets_host: Sequence[int], world: int, rank: int, chunks: int):
+    """Pure layout of the fused cloud from the global view offsets (``len = V_total + 1``): rank r's contiguous shard of
+    views is cut into ``chunks`` contiguous pieces; returns ``(chunk_views, chunk_rows)`` -- this rank's LOCAL view range
+    per chunk and, per chunk, every rank's global row range.  Rows of (rank, chunk) cells tile ``[0, total)`` in
+    (rank, chunk) order, i.e. in view order."""
+    num_views_total = len(offsets_host) - 1
     shards = [shard_views(num_views_total, world, r) for r in range(world)]
     per_rank = [_chunk_bounds(lo, hi, chunks) for lo, hi in shards]
-    chunk_rows = [[(host[per_rank[r][k][0]], host[per_rank[r][k][1]]) for r in range(world)] for k in range(chunks)]
+    chunk_rows = [[(offsets_host[per_rank[r][k][0]], offsets_host[per_rank[r][k][1]]) for r in range(world)] for k in range(chunks)]
     lo0 = shards[rank][0]
     chunk_views = [(a - lo0, b - lo0) for a, b in per_rank[rank]]
-    return FusePlan(view_offsets, host, rank, world, num_views_total, chunk_views, chunk_rows)
+    return chunk_views, chunk_rows
 
 
 def exchange_rows(tensors: Sequence[torch.Tensor], rows: Sequence[tuple], group=None, dst: Optional[int] = None, base: int = 0) -> list:

@@ -50,6 +50,33 @@ def test_shard_views_partition():
         shard_views(10, 2, 2)
 
 
+def test_fuse_layout_tiles_the_cloud_in_view_order():
+    """layout_chunks (what plan_fuse derives from the exchanged counts): for every world size / chunk count the
+    (rank, chunk) cells are contiguous, in view order, cover [0, total) exactly, agree between ranks, and a rank's local
+    view ranges cover its shard."""
+    import numpy as np
+    from depthdensifier_amd.distributed import layout_chunks, shard_views
+    rng = np.random.default_rng(0)
+    for V in (0, 1, 7, 185, 2000):
+        counts = rng.integers(0, 5000, V)
+        if V > 3:
+            counts[2] = 0
+        offs = [0] + np.cumsum(counts).tolist()
+        for R in (1, 2, 3, 8):
+            for C in (1, 3, 5, 20):
+                views0, rows0 = layout_chunks(offs, R, 0, C)
+                for r in range(R):
+                    views, rows = layout_chunks(offs, R, r, C)
+                    assert rows == rows0 and len(rows) == C and all(len(c) == R for c in rows)
+                    lo, hi = shard_views(V, R, r)
+                    assert views[0][0] == 0 and views[-1][1] == hi - lo and all(a[1] == b[0] for a, b in zip(views, views[1:]))
+                    for k, (a, b) in enumerate(views):               # the chunk's rows are the rows of its views
+                        assert rows[k][r] == (offs[lo + a], offs[lo + b])
+                cells = [rows0[k][r] for r in range(R) for k in range(C)]          # rank-major, chunk-minor = view order
+                assert cells[0][0] == 0 and cells[-1][1] == offs[-1]
+                assert all(a[1] == b[0] and a[0] <= a[1] for a, b in zip(cells, cells[1:]))
+
+
 def test_balanced_contiguous_split():
     from depthdensifier_amd.distributed import shard_views_balanced
     costs = [1920 * 1080] * 100 + [4032 * 3024] * 20 + [640 * 480] * 300        # mixed resolutions, in view order
