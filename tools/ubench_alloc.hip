@@ -84,14 +84,15 @@ int main() {
         void *x; CK(hipMalloc(&x, (size_t)(r + 1) * 700 * 1000 * 1000)); ballast.push_back(x);     // perturb the next placement
     }
     for (void *x : ballast) CK(hipFree(x));
-    for (size_t chunk : {(size_t)0, (size_t)2 << 20, (size_t)1 << 30}) {
-        for (int r = 0; r < 3; ++r) {
+    for (size_t chunk : {(size_t)0, (size_t)64 << 10, (size_t)512 << 10, (size_t)2 << 20, (size_t)8 << 20, (size_t)32 << 20, (size_t)128 << 20, (size_t)1 << 30}) {
+        for (int r = 0; r < 4; ++r) {
             std::vector<hipMemGenericAllocationHandle_t> ha, hb, hm;
             const size_t ca = chunk ? chunk : BYTES, cm = chunk ? chunk : MIXB;
             void *a = vmm_alloc(BYTES, ca, ha), *b = vmm_alloc(BYTES, ca, hb), *m = vmm_alloc(MIXB, cm, hm);
             CK(hipMemset(a, 1, BYTES)); CK(hipMemset(m, 0, MIXB));
-            printf("VMM handle size %s round %d: copy %7.1f GB/s   mixed %7.1f GB/s\n", chunk == 0 ? "whole buffer" : chunk == ((size_t)2 << 20) ? "2 MiB" : "1 GiB", r,
-                   time_copy(a, b, BYTES), time_mixed((char *)m, NMIX));
+            char nm[32]; if (chunk == 0) snprintf(nm, sizeof nm, "whole buffer"); else snprintf(nm, sizeof nm, "%zu KiB", chunk >> 10);
+            printf("VMM handle size %-12s round %d: copy %7.1f GB/s   mixed %7.1f GB/s\n", nm, r, time_copy(a, b, BYTES), time_mixed((char *)m, NMIX));
+            fflush(stdout);
             vmm_free(a, BYTES, ca, ha); vmm_free(b, BYTES, ca, hb); vmm_free(m, MIXB, cm, hm);
         }
     }
