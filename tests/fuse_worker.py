@@ -68,9 +68,14 @@ def main():
             s0, s1 = plan.rank_rows[rank]
             same(cloud.packed, full_packed.packed[s0:s1], "a sender keeps just its own rows")
     # the count-only (sharded) fuse and the gather of an already compacted local cloud (what the pipeline does after the filter)
-    part = dd.unproject_views(cut(d["depth"]), cut(params), cut(d["cam_from_world"]), view_index=True, mask=cut(d["mask"]),
-                              normal=cut(d["normal"]), rgb=cut(d["rgb"])) if hi > lo else None
-    if part is not None and world > 0:
+    if hi > lo:
+        part = dd.unproject_views(cut(d["depth"]), cut(params), cut(d["cam_from_world"]), view_index=True, mask=cut(d["mask"]),
+                                  normal=cut(d["normal"]), rgb=cut(d["rgb"]))
+    else:                                   # a rank without views still takes part in every collective, with an empty cloud
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        part = dd.FusedCloud(points=z((0, 3), torch.float32), colors=z((0, 3), torch.uint8), normals=z((0, 3), torch.float32),
+                             pixel_index=z((0,), torch.int32), view_index=z((0,), torch.int32), view_offsets=z((1,), torch.int64))
+    if True:
         sharded = D.fuse_sharded(part, V)
         assert torch.equal(sharded.view_offsets, full.view_offsets)
         fused = D.gather_cloud(sharded)

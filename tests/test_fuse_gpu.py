@@ -21,7 +21,7 @@ def _port():
         return s.getsockname()[1]
 
 
-def _torchrun(nproc, env_extra, timeout=300):
+def _torchrun(nproc, env_extra, timeout=150):
     env = dict(os.environ, **env_extra)
     return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
                            "--master-port", str(_port()), str(ROOT / "tests" / "fuse_worker.py")], capture_output=True, text=True, timeout=timeout, env=env)
@@ -66,13 +66,15 @@ def test_rccl_world1_in_process():
         dist.destroy_process_group()
 
 
-def test_two_ranks_sharing_the_gpu_over_gloo():
+@pytest.mark.parametrize("ranks, views", [(2, 9), (3, 4), (3, 2)])
+def test_ranks_sharing_the_gpu_over_gloo(ranks, views):
+    """Even shards, uneven shards (2 + 1 + 1 views) and a rank that owns NO view at all (3 ranks, 2 views)."""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    r = _torchrun(2, dict(DD_DIST_BACKEND="gloo", DD_ALLGATHERV="broadcast", DD_SHARE_GPU="1"))
+    r = _torchrun(ranks, dict(DD_DIST_BACKEND="gloo", DD_ALLGATHERV="broadcast", DD_SHARE_GPU="1", DD_FUSE_VIEWS=str(views)))
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count(": ok,") == 2
+    assert r.stdout.count(": ok,") == ranks
 
 
 def test_two_ranks_over_rccl():
