@@ -43,9 +43,14 @@ WORKLOADS = {
     "scene2000": dict(V=2000, H=1080, W=1920, depth="float32", mask=True, normal=True, rgb=True, rho=0.8,
                       note="BASELINE configs[2]: 2000-view synthetic scene (strong scaling: V is the total)"),
     "mip360conf": dict(V=232, H=1080, W=1920, depth="float32", mask=True, normal=True, rgb=True, rho=0.85, conf=0.5,
-                       scenes=[194, 292, 240, 185, 279, 311, 125],
-                       note="BASELINE configs[3]: the 7 Mip-NeRF 360 scene sizes back to back (1626 views, synthetic "
-                            "stand-ins), mask AND conf > 0.5; V is the per-GPU share at 7..8 GPUs, use --views to change"),
+                       note="BASELINE configs[3], one GPU's share as ONE batch: 232 = 1626 / 7 views of the Mip-NeRF 360 set "
+                            "(synthetic stand-ins), mask AND conf > 0.5; use --views to change"),
+    "mip360x7": dict(V=1626, H=1080, W=1920, depth="float32", mask=True, normal=True, rgb=True, rho=0.85, conf=0.5,
+                     scenes=[("bicycle", 194), ("bonsai", 292), ("counter", 240), ("garden", 185), ("kitchen", 279),
+                             ("room", 311), ("stump", 125)],
+                     note="BASELINE configs[3]: the 7 Mip-NeRF 360 scenes back to back (1626 views, synthetic stand-ins at 1080p), "
+                          "mask AND conf > 0.5; whole scenes dealt to the ranks most expensive first (no data-path collective), "
+                          "every scene gets a fresh cloud and a host read of its point count (V is the total: strong scaling)"),
     "roofline12mp": dict(V=500, H=3024, W=4032, depth="float16", mask=False, normal=False, rgb=False, rho=1.0,
                          note="BASELINE configs[4]: 500 views 12 MP, f16 depth in / f32 xyz out, dense"),
 }
@@ -109,7 +114,7 @@ def make_scene(cfg: dict, view_ids: np.ndarray, device) -> dict:
 
 # ------------------------------------------------------------------------------ byte model
 
-def algorithmic_bytes(cfg: dict, V: int, n_valid: int, pixel_index: bool) -> int:
+def algorithmic_bytes(cfg: dict, V: int, n_valid: int, pixel_index: bool, reads_only: bool = False) -> int:
     """SURVEY.md 8d: read P*(b_depth+b_mask) + N*(12[normal]+3[rgb]) + 64 B params per view;
     write N*(12 + 12[normal] + 3[rgb] + 4[pixel_index]) + 8 B offset per view.  Attributes are
     charged only for surviving pixels; nothing is credited for re-reads."""
@@ -118,6 +123,8 @@ def algorithmic_bytes(cfg: dict, V: int, n_valid: int, pixel_index: bool) -> int
     per_px = b_depth + (1 if cfg["mask"] else 0) + (4 if cfg.get("conf") else 0)
     per_pt_r = (12 if cfg["normal"] else 0) + (3 if cfg["rgb"] else 0)
     per_pt_w = 12 + (12 if cfg["normal"] else 0) + (3 if cfg["rgb"] else 0) + (4 if pixel_index else 0)
+    if reads_only:
+        return V * P * per_px + n_valid * per_pt_r + V * 64
     return V * P * per_px + n_valid * (per_pt_r + per_pt_w) + V * (64 + 8)
 
 
@@ -334,6 +341,16 @@ def cpu_baseline_all_cores(cfg: dict, scene: dict, params: np.ndarray, E: np.nda
                       f"slowest worker {wall:.1f} s; a courtesy upper bound, the reference itself is one process"}
 
 
+def deal_scenes(sizes, world: int):
+    """Owner rank of every scene: largest first to the least loaded rank (what batch.assign_scans does with scan
+    folders); a pure function of the sizes, identical on every rank."""
+    load, owner = [0] * world, [0] * len(sizes)
+    for k in sorted(range(len(sizes)), key=lambda k: (-sizes[k], k)):
+        r = min(range(world), key=lambda r: (load[r], r))
+        owner[k], load[r] = r, load[r] + sizes[k]
+    return owner
+
+
 # ------------------------------------------------------------------------------ main
 
 _GUARD_SRC = r"""
@@ -436,9 +453,21 @@ def main() -> None:
     cfg = dict(WORKLOADS[args.workload])
     cfg["mask_kind"] = args.mask_kind
     strong = args.workload == "scene2000"
+    multi = "scenes" in cfg                          # whole scenes back to back, dealt to the ranks
     if args.views:
+        if multi:                                    # scale every scene (quick runs)
+            cfg["scenes"] = [(n, max(1, round(v * args.views / cfg["V"]))) for n, v in cfg["scenes"]]
         cfg["V"] = args.views
-    if strong:
+    scene_sets = None
+    if multi:
+        names, sizes = zip(*cfg["scenes"])
+        owner = deal_scenes(sizes, world)
+        starts = np.concatenate([[0], np.cumsum(sizes)])
+        total_views = int(starts[-1])
+        scene_sets = [(names[k], np.arange(starts[k], starts[k + 1])) for k in range(len(sizes)) if owner[k] == rank]
+        lo, hi = (int(scene_sets[0][1][0]), int(scene_sets[0][1][-1]) + 1) if scene_sets else (0, 0)
+        scaling = "strong"
+    elif strong:
         total_views = cfg["V"]
         lo, hi = D.shard_views(total_views, world, rank)
         scaling = "strong"
@@ -466,22 +495,55 @@ def main() -> None:
                 E[j] = im.cam_from_world().matrix()
                 params[j] = cam.pinhole_params() * [W / cam.width, H / cam.height, W / cam.width, H / cam.height]
             poses_from = str(args.colmap_path)
-    batch = dd.ViewBatch(scene["depth"], params, E, mask=scene["mask"], normal=scene["normal"], rgb=scene["rgb"],
-                         conf=scene["conf"], conf_threshold=cfg.get("conf"),
-                         view_index_base=int(lo), device=device, tuning=args.tuning)
-    # capacity = every visited pixel: no sizing pass exists anywhere, timed or not (SURVEY.md 8d defines the metric over
-    # count + scan + unproject + compact, which the fused kernel does in its one pass)
-    builder = dd.CloudBuilder(batch.max_points, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index,
-                              device=device)
+    def view_batch(sc, pr, Ek, base):
+        return dd.ViewBatch(sc["depth"], pr, Ek, mask=sc["mask"], normal=sc["normal"], rgb=sc["rgb"], conf=sc["conf"],
+                            conf_threshold=cfg.get("conf"), view_index_base=int(base), device=device, tuning=args.tuning)
+
+    if multi:       # this rank's scenes, each its own ring of cameras and its own batch; `scene` stays the first (CPU baseline)
+        batches = []
+        for k, (_, ids) in enumerate(scene_sets):
+            sc = scene if k == 0 else make_scene(cfg, ids, device)
+            batches.append(view_batch(sc, np.tile(params[:1], (len(ids), 1)), ring_poses(np.arange(len(ids)), len(ids)), 0))
+        if scene_sets:
+            E = ring_poses(np.arange(V), V)
+        V = sum(len(ids) for _, ids in scene_sets)
+        batch = builder = None
+    else:
+        batch = view_batch(scene, params, E, lo)
+        # capacity = every visited pixel: no sizing pass exists anywhere, timed or not (SURVEY.md 8d defines the metric over
+        # count + scan + unproject + compact, which the fused kernel does in its one pass)
+        builder = dd.CloudBuilder(batch.max_points, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index,
+                                  device=device)
 
     ev = []
     state = {"plan": None}
     single_pass = not args.two_pass
 
+    def step_scenes(record: bool):
+        """mip360x7: this rank's scenes back to back -- per scene a fresh cloud sized for every visited pixel (torch's
+        caching allocator), the fused call, and the host read of the point count and the error word that writing the
+        scene's model needs.  The events bracket the whole sequence, host gaps included."""
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if record else None
+        if record:
+            e[0].record()
+        n = 0
+        for b in batches:
+            cloud = dd.CloudBuilder(b.max_points, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index, device=device)
+            cloud.append(b)
+            n += cloud.check()
+            del cloud
+        if record:
+            e[1].record(); e[2].record()
+            ev.append(e)
+        state["n_local"] = n
+        return None
+
     def step(record: bool):
         """One pass of the hot path.  Default: the fused call dd_unproject_compact (one kernel reads the
         inputs once: cull + unproject + transform + look-back scan + compaction + write).  --two-pass:
         dd_plan (count + scans) then dd_scatter.  Events bracket the kernels on the launch stream."""
+        if multi:
+            return step_scenes(record)
         builder.reset()
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if record else None
         if record:
@@ -523,8 +585,16 @@ def main() -> None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    n_local = builder.check()
-    n_total = int(goffs[-1].item())
+    if multi:
+        n_local = state["n_local"]
+        n_total = n_local
+        if use_dist:
+            nt = torch.tensor([n_local], dtype=torch.int64, device=device)
+            dist.all_reduce(nt)
+            n_total = int(nt.item())
+    else:
+        n_local = builder.check()
+        n_total = int(goffs[-1].item())
     if os.environ.get("DD_BENCH_TRACE_STEPS") and rank == 0:      # per-step kernel times (diagnostic)
         print("steps_ms", [round(e[0].elapsed_time(e[2]), 3) for e in ev], file=sys.stderr)
     plan_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
@@ -538,6 +608,7 @@ def main() -> None:
         ms_per_step = elapsed / args.steps * 1e3
         pixels = total_views * H * W
         alg = algorithmic_bytes(cfg, V, n_local, args.pixel_index)
+        alg_r = algorithmic_bytes(cfg, V, n_local, args.pixel_index, reads_only=True)
         achieved = alg / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_source = None, None
         tfile = ROOT / "profiles" / "traffic.json"
@@ -548,6 +619,8 @@ def main() -> None:
                 traffic = int(rec["hbm_bytes_per_launch"] * V / rec["views"])
                 traffic_source = (f"profiles/traffic.json[{tkey}]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this kernel on this workload, "
                                   "collected in separate profiling runs (tools/pmc_traffic.sh) -- NOT measured in this run")
+        if multi:
+            cfg_scenes = {"scenes": [f"{n}:{len(i)}" for n, i in scene_sets], "scenes_total": len(cfg["scenes"])}
         line = {
             "metric": "Mpixels/s unprojected+fused",
             "value": round(pixels / (elapsed / args.steps) / 1e6, 1),
@@ -565,13 +638,17 @@ def main() -> None:
                        "inputs": "+".join(k for k in ("depth", "mask", "conf", "normal", "rgb") if scene[k] is not None),
                        "outputs": "xyz f32" + (" + normal f32" if cfg["normal"] else "") + (" + rgb u8" if cfg["rgb"] else "")
                                   + (" + pixel_index i32" if args.pixel_index else ""),
-                       "fuse": "single GPU: one global scan, points written at final slots" if world == 1 else
+                       "fuse": "whole scenes per rank, one cloud per scene, no data-path collective" if multi else
+                               "single GPU: one global scan, points written at final slots" if world == 1 else
                                "sharded: contiguous view shards + RCCL all-gather of per-view counts (global offsets)"},
             "roofline": {"bound": "hbm",
                          "kernel": "compact_lean<single-pass> (dd_unproject_compact: cull+unproject+transform+scan+compact+write)"
                                    if single_pass else "compact_lean (dd_scatter: cull+unproject+transform+compact+write)",
                          "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "read_frac": round(alg_r / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                         "read_frac_note": "algorithmic READ bytes / kernel time / peak (the other "
+                                           f"{100 * (1 - alg_r / alg):.0f} % of the bytes are writes sharing the same interface)",
                          "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_over_algorithmic": None if traffic is None else round(traffic / alg, 4),
                          "algorithmic_bytes_per_launch": alg,
@@ -583,6 +660,9 @@ def main() -> None:
                          "pass1_note": "two-pass mode only: count_lean + scan kernels re-read depth+mask (not credited)",
                          "whole_step_frac": round(alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
         }
+        if multi:
+            line["config"]["rank0_scenes"] = cfg_scenes["scenes"]
+            line["roofline"]["kernel"] += f"; {len(batches)} launches, the events also bracket the per-scene allocation and host read"
         if args.cpu_seconds > 0 and world == 1:      # reported at N=1 only, on rank 0
             line["cpu_baseline"] = cpu_baseline(cfg, scene, params, E, args.cpu_seconds)
             procs = args.cpu_procs if args.cpu_procs >= 0 else min(len(os.sched_getaffinity(0)), 16)      # a GPU box's CPU share is 16 cores
@@ -605,6 +685,8 @@ def main() -> None:
         import threading
 
         del batch, builder, scene
+        if multi:
+            del batches
         torch.cuda.empty_cache()
 
         def bail():

@@ -36,6 +36,12 @@ def _case(seed):
         use_normal=bool(rng.uniform() < 0.6), use_rgb=bool(rng.uniform() < 0.6),
         viz=bool(rng.uniform() < 0.25), tuning=int(rng.choice([0, 0, 1, 4, 5, 9])),
     )
+    # options added in round 2, drawn from their own stream so that a seed keeps the configuration it always had
+    rng2 = np.random.default_rng(20_000 + seed)
+    opts["record"] = str(rng2.choice(["rows", "rows", "xyz_rgba", "both"]))
+    opts["capacity"] = [None, "max"][int(rng2.integers(0, 2))]
+    if rng2.uniform() < 0.3:
+        opts["tuning"] |= 32                      # wave runs NOT aligned to 128-byte lines: same bits out
     return d, opts
 
 
@@ -64,7 +70,18 @@ def test_random_configuration(seed):
     conf = d["conf"].astype(o["conf_dtype"]) if o["use_conf"] else None
     thr = 0.37 if o["use_conf"] else None
     cloud = dd.unproject_views(d["depth"], d["params"], d["cam_from_world"], mask=mask, normal=normal, rgb=rgb, conf=conf,
-                               conf_threshold=thr, downsample_density=o["stride"], view_index=True, tuning=o["tuning"])
+                               conf_threshold=thr, downsample_density=o["stride"], view_index=True, tuning=o["tuning"],
+                               record=o["record"], capacity=o["capacity"])
     ref = orc.densify_scene_script(d["depth"], d["params"], d["cam_from_world"], mask=mask, normal=normal, rgb=rgb,
                                    stride=o["stride"], conf=conf, conf_threshold=thr)
     assert_cloud(cloud, ref, rad)
+    if o["record"] != "rows":                     # the 16-byte record: x, y, z bits + r | g<<8 | b<<16 | 255<<24
+        rec = cloud.packed.cpu().numpy().view(np.uint32)
+        assert rec.shape == (len(ref.points), 4)
+        want = np.full(len(rec), 255 << 24, dtype=np.uint32)
+        if rgb is not None:
+            c = ref.colors.astype(np.uint32)
+            want |= c[:, 0] | (c[:, 1] << 8) | (c[:, 2] << 16)
+        assert np.array_equal(rec[:, 3], want)
+        if o["record"] == "both":                 # rows and record written by the same lanes: identical xyz bits
+            assert np.array_equal(rec[:, :3], cloud.points.cpu().numpy().view(np.uint32))
