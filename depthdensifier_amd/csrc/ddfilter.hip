@@ -282,10 +282,137 @@ __global__ __launch_bounds__(256) void floater_votes_kernel(const FArgs a) {
 }
 
 // ==================================================================================================
+// float64 kernel, second form (round 2): the image-bounds test WITHOUT the division, the grazing test second, and the
+// reciprocal only for the pairs that reach the depth lookup.  Stage times of the first form on the 96-view ring scene
+// (16.2 G pairs, DD_VOTES_STAGE builds): depth sign 5.3 ms, + projection and bounds 18.0 ms (every pair in front of the
+// camera paid xc, yc, a reciprocal with two Newton steps, six more FMAs and the integer guards before the four
+// comparisons), + grazing 10.4 ms (74 % of the pairs), + lookup 16.0 ms (34 %).
+//
+// With M = K [R|t] (rows 0 and 1; a per-view table built by votes_prepare64 in the caller's workspace) the reference's
+//   u = K00 xc/den + K01 yc/den + K02 zc/den,  0 <= u < W      (den = zc + 1e-8 > 0, scripts/test.py:71-75, 300-302)
+// is, in real arithmetic,  nu = M0 . (p, 1) >= 0  and  W den - nu > 0.  The float64 evaluation of nu and the reference's
+// own float64 evaluation of u both stay within ~20 eps64 A of the real values, A = sum of the magnitudes of every
+// product and intermediate sum involved <= coef S, with  coef = max_j (sum_i |K0i| |[R|t]_ij| + W |[R|t]_2j|)  (+ the
+// 1e-8 term) per view and S = |x| + |y| + |z| + 1 per point.  A comparison is accepted when the value is farther than
+// band = 1e-9 coef S from zero -- 4.5e5 times the rounding it could hide -- and the pair takes the exact formulation
+// (the reference's three divisions) otherwise; NaN / inf compare false on both sides and land there too.  The pixel
+// of a surviving pair is trunc(nu / den) by reciprocal + Newton unless within band / den of an integer (then exact).
+// Same votes as the first form on every test (oracle, the reference's vote-loop fixture, 16.2 G-pair checksums).
+// ==================================================================================================
+struct Cam2 {
+    f64x4 m0, m1, zr;           // M0, M1, [R|t] row z: fetched one view ahead into scalar registers
+    cam_double *rest;           // the 32-double table row: [0..23] the caller's block, [21] band coefficient
+};
+
+__global__ __launch_bounds__(64) void votes_prepare64(const double *cams, double *tab, int V, int H, int W) {
+    const int v = blockIdx.x * 64 + threadIdx.x;
+    if (v >= V) return;
+    const double *c = cams + (size_t)v * 24;
+    double *t = tab + (size_t)v * 32;
+    for (int k = 0; k < 24; ++k) t[k] = c[k];
+    double coef = 0.0;
+    for (int j = 0; j < 4; ++j) {
+        t[24 + j] = c[12] * c[j] + c[13] * c[4 + j] + c[14] * c[8 + j];
+        t[28 + j] = c[15] * c[j] + c[16] * c[4 + j] + c[17] * c[8 + j];
+        const double a0 = fabs(c[12]) * fabs(c[j]) + fabs(c[13]) * fabs(c[4 + j]) + fabs(c[14]) * fabs(c[8 + j]);
+        const double a1 = fabs(c[15]) * fabs(c[j]) + fabs(c[16]) * fabs(c[4 + j]) + fabs(c[17]) * fabs(c[8 + j]);
+        const double az = fabs(c[8 + j]) + (j == 3 ? 1e-8 : 0.0);
+        coef = fmax(coef, fmax(a0 + (double)W * az, a1 + (double)H * az));
+    }
+    t[21] = 1.0000001e-9 * coef + 1e-300;      // NaN / inf camera entries make every band test fail -> exact formulation
+}
+
+__device__ __forceinline__ void exact_uw(cam_double *c, const double x, const double y, const double z, const double zc,
+                                         const double den, double &u, double &w) {
+    const double xc = c[0] * x + c[1] * y + c[2] * z + c[3];
+    const double yc = c[4] * x + c[5] * y + c[6] * z + c[7];
+    const double xn = xc / den, yn = yc / den, zn = zc / den;
+    u = c[12] * xn + c[13] * yn + c[14] * zn;
+    w = c[15] * xn + c[16] * yn + c[17] * zn;
+}
+
+__device__ __forceinline__ bool pair_votes2(const FArgs &a, const Cam2 &c, const int v, const double x, const double y,
+                                            const double z, const double nx, const double ny, const double nz, const double S,
+                                            const double wlim, const double hlim) {
+    const double zc = c.zr[0] * x + c.zr[1] * y + c.zr[2] * z + c.zr[3];
+    if (!(zc > 0.0)) return false;                           // :301 depths > 0
+    const double den = zc + 1e-8;
+    const double nu = c.m0[0] * x + c.m0[1] * y + c.m0[2] * z + c.m0[3];
+    const double nw = c.m1[0] * x + c.m1[1] * y + c.m1[2] * z + c.m1[3];
+    const double band = c.rest[21] * S;
+    const double ru = fma(wlim, den, -nu), rw = fma(hlim, den, -nw);
+    const double lo = fmin(fmin(nu, nw), fmin(ru, rw));      // NaN-free minimum is all that matters: NaN operands are caught below
+    bool exact = false;
+    double u = 0.0, w = 0.0;
+    if (!(nu > band && nw > band && ru > band && rw > band)) {
+        if (lo < -band) return false;                        // certainly outside the image
+        exact_uw(c.rest, x, y, z, zc, den, u, w);            // inside a band (or not finite): the reference's formulation decides
+        if (!(u >= 0.0 && u < wlim && w >= 0.0 && w < hlim)) return false;      // :300-302
+        exact = true;
+    }
+    // :284-295  grazing-angle test (the filtered form of the first kernel)
+    {
+        double dx = x - c.rest[18], dy = y - c.rest[19], dz = z - c.rest[20];
+        const double len2 = dx * dx + dy * dy + dz * dz;
+        const double t = -(nx * dx + ny * dy + nz * dz), g = a.grazing_cos;
+        const double s = t * t, q = g * g * len2;
+        if (g > 0.0 && t <= 0.0) return false;
+        if (g > 0.0 && fabs(s - q) > 2.5e-9 * (s + q) && s < 1e300) {
+            if (!(s > q)) return false;
+        } else {
+            const double len = sqrt(len2);
+            dx /= len; dy /= len; dz /= len;
+            const double facing = nx * -dx + ny * -dy + nz * -dz;
+            if (!(facing > a.grazing_cos)) return false;
+        }
+    }
+    if (!exact) {
+        double rden = __builtin_amdgcn_rcp(den);
+        rden = fma(fma(-den, rden, 1.0), rden, rden);
+        rden = fma(fma(-den, rden, 1.0), rden, rden);
+        u = nu * rden; w = nw * rden;
+        const double g = fma(band, rden, 1e-9);              // |u - u_reference| <= ~20 eps64 A / den, far inside band / den
+        if (!(fabs(u - rint(u)) > g && fabs(w - rint(w)) > g)) exact_uw(c.rest, x, y, z, zc, den, u, w);
+    }
+    // :308-312  truncating lookup of the view's (mask-zeroed) refined depth
+    const long long pix = (long long)v * a.hw + (long long)(int)w * a.W + (int)u;
+    float seen = a.depth[pix];
+    if (a.mask && a.mask[pix] == 0) seen = 0.0f;        // :194 refined_depth[~mask] = 0
+    if (!(seen > 0.0f)) return false;                        // :315
+    const float limit = a.depth_threshold * seen;        // :320 float32 product (NEP 50)
+    return zc < (double)limit;                           // :319-328
+}
+
+__global__ __launch_bounds__(256) void floater_votes_kernel2(const FArgs a, const double *tab) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const double wlim = (double)a.W, hlim = (double)a.H;
+    const double x = a.xyz[3 * i], y = a.xyz[3 * i + 1], z = a.xyz[3 * i + 2];
+    const double nx = a.normal[3 * i], ny = a.normal[3 * i + 1], nz = a.normal[3 * i + 2];
+    const double S = fabs(x) + fabs(y) + fabs(z) + 1.0;
+    int votes = a.accumulate ? a.votes[i] : 0;
+    auto fetch = [&](int v, Cam2 &c) {
+        cam_vec4 *p = (cam_vec4 *)(tab + (size_t)v * 32);
+        c.zr = p[2]; c.m0 = p[6]; c.m1 = p[7];
+        c.rest = (cam_double *)(tab + (size_t)v * 32);
+    };
+    Cam2 cur, nxt;
+    fetch(0, cur);
+    for (int v = 0; v < a.V; ++v) {
+        fetch(v + 1 < a.V ? v + 1 : v, nxt);
+        votes += pair_votes2(a, cur, v, x, y, z, nx, ny, nz, S, wlim, hlim) ? 1 : 0;
+        cur = nxt;
+    }
+    a.votes[i] = votes;
+}
+
+// ==================================================================================================
 // Float32 first pass with rigorous error bounds (default when the caller provides DDFilterViews.workspace).
 //
-// The float64 kernel above is VALU-bound at the float64 rate (16 lanes per clock per SIMD on gfx950, half the
-// float32 rate; ~75 instructions per wave and view).  Here every (point, view) pair is first evaluated in float32
+// The float64 kernel above is VALU-bound (~75 instructions per wave and view).  NOTE (measured after this pass was
+// built, tools/ubench_fma.hip): on gfx950 v_fma_f64 issues at 0.88x the rate of a scalar-per-lane v_fma_f32 -- only the
+// PACKED float32 form is twice as fast -- so a float32 evaluation that needs about twice the instructions for its error
+// bounds has no arithmetic advantage to collect; that is why this pass measures slower.  Every (point, view) pair is first evaluated in float32
 // together with an upper bound of the distance between each float32 quantity and the value the float64 formulation
 // computes; a comparison is accepted only when the float32 value is farther from its threshold than that bound --
 // then the float64 formulation takes the same branch.  Pairs with any comparison inside its band (about 1-2 % of
@@ -848,6 +975,11 @@ int dd_floater_votes(const DDFilterViews *views, const float *xyz, const float *
             hipLaunchKernelGGL(votes_resolve, dim3(resolve_blocks, V_SHARDS), dim3(256), 0, s, r, gq, entries, capacity);
             hipLaunchKernelGGL(votes_redo, dim3((unsigned)blocks), dim3(256), 0, s, r, v0, v1, redo, (int)chunks_total);
         }
+    } else if (views->mode == 1 && views->workspace && views->workspace_bytes >= (int64_t)V * 256) {
+        if (((uintptr_t)views->workspace % 32) != 0) return fail("workspace must be 32-byte aligned");
+        double *tab = reinterpret_cast<double *>(views->workspace);
+        hipLaunchKernelGGL(votes_prepare64, dim3((unsigned)((V + 63) / 64)), dim3(64), 0, s, views->cams, tab, V, views->height, views->width);
+        hipLaunchKernelGGL(floater_votes_kernel2, dim3((unsigned)blocks), dim3(256), 0, s, a, (const double *)tab);
     } else
     hipLaunchKernelGGL(floater_votes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     if (hipGetLastError() != hipSuccess) { snprintf(g_ferr, sizeof(g_ferr), "floater_votes launch failed"); return DD_ERR_LAUNCH; }

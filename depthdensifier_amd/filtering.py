@@ -52,7 +52,7 @@ def filter_cameras(intrinsics: ArrayLike, cam_from_world: ArrayLike) -> np.ndarr
     return cams
 
 
-VOTE_MODES = {"float64": 1, "float32_first": 0, "verify": 2}
+VOTE_MODES = {"float64": 1, "float64_classic": 1, "float32_first": 0, "verify": 2}
 
 
 def floater_votes(points: torch.Tensor, normals: torch.Tensor, depth: ArrayLike, intrinsics: ArrayLike,
@@ -62,7 +62,10 @@ def floater_votes(points: torch.Tensor, normals: torch.Tensor, depth: ArrayLike,
     of the cached views (``:197-201``); with ``mask`` given, masked-out pixels read as 0 (``:194``).
     Pass ``votes`` to accumulate over several calls (views in chunks).
 
-    ``mode``: ``"float64"`` (default) = every decision in float64, the fastest form on MI355X (335 Gpairs/s);
+    ``mode``: ``"float64"`` (default) = every decision in float64, the fastest form on MI355X (division-free image-bounds
+    test first, grazing second, reciprocal only for pairs that reach the lookup; a 256-byte table per view is built in a
+    scratch buffer); ``"float64_classic"`` = the round-1 kernel (projection with a reciprocal for every pair in front of
+    the camera; needs no scratch -- what a C caller gets with ``workspace = NULL``);
     ``"float32_first"`` = a float32 first pass with rigorous error bounds whose undecided pairs (~1 %) are resolved in
     float64 -- the same votes bit for bit, but measured SLOWER here (240-280 Gpairs/s: the float64 kernel's time is mostly
     cheap early exits, not float64 arithmetic), kept as a checked experiment; ``"verify"`` = that first
@@ -97,7 +100,8 @@ def floater_votes(points: torch.Tensor, normals: torch.Tensor, depth: ArrayLike,
     if votes is None:
         votes = torch.empty(pts.shape[0], dtype=torch.int32, device=dev)
     V, H, W = d.shape
-    ws = torch.empty(int(lib.dd_votes_workspace_bytes(V, pts.shape[0])) if mode != "float64" else 16, dtype=torch.uint8, device=dev)
+    ws_bytes = {"float64": 256 * V, "float64_classic": 16}.get(mode) or int(lib.dd_votes_workspace_bytes(V, pts.shape[0]))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     fv = DDFilterViews(num_views=V, height=H, width=W, depth=d.data_ptr(), mask=None if m is None else m.data_ptr(),
                        cams=cams.data_ptr(), grazing_cos=GRAZING_COS, depth_threshold=float(depth_threshold),
                        workspace=ws.data_ptr(), workspace_bytes=ws.numel(), mode=VOTE_MODES[mode])
@@ -106,7 +110,7 @@ def floater_votes(points: torch.Tensor, normals: torch.Tensor, depth: ArrayLike,
     if rc < 0:
         raise DDCoreError(rc, lib.dd_filter_last_error().decode())
     if stats is not None:
-        w = [0, 0] if mode == "float64" else ws[:64 * 128].view(torch.int64).view(64, 16)[:, :2].sum(dim=0).tolist()   # 64 shards, a line each
+        w = [0, 0] if mode.startswith("float64") else ws[:64 * 128].view(torch.int64).view(64, 16)[:, :2].sum(dim=0).tolist()   # 64 shards, a line each
         stats.update(pairs=int(pts.shape[0]) * V, resolved_in_float64=int(w[0]), mismatches=int(w[1]), mode=mode)
     # asynchronous: temporaries freed here are only reused by later work on the same stream
     return votes

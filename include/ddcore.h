@@ -211,7 +211,10 @@ typedef struct DDFilterViews {
     double grazing_cos;     /* 0.087, scripts/test.py:295 */
     float depth_threshold;  /* FilteringConfig.depth_threshold = 0.7, scripts/test.py:45-46, 320 */
     float reserved2;
-    void *workspace;        /* NULL (default: every decision in float64, the fastest form measured on MI355X), or device scratch
+    void *workspace;        /* NULL: the float64 kernel of round 1.  With mode = 1 and >= 256 * num_views bytes (32-B aligned):
+                               the float64 kernel builds a per-view table there (K [R|t] and a band coefficient) and tests the
+                               image bounds without the division -- same votes, 5-10 % faster on coherent normal maps.  With
+                               mode = 0 / 2: device scratch
                                of dd_votes_workspace_bytes(num_views, n) bytes (less is accepted: more rounds of views), 16-B
                                aligned, for the EXPERIMENTAL float32 first pass: float32 evaluation with rigorous error bounds,
                                undecided pairs (~1 %) resolved in float64 through a queue -- the same votes bit for bit, measured

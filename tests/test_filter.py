@@ -82,6 +82,8 @@ def test_gpu_votes_match_oracle(with_mask):
     ref = forc.floater_votes(pts[fin], cloud.normals.cpu().numpy()[fin], culled, K, d["cam_from_world"])
     assert ref.max() >= 3, "scene too tame to exercise the vote path"
     assert np.array_equal(votes[fin], ref)
+    classic = dd.floater_votes(cloud.points, cloud.normals, depth_in, K, d["cam_from_world"], mask=mask, mode="float64_classic")
+    assert np.array_equal(classic.cpu().numpy(), votes)             # the round-1 kernel (no scratch table): same votes
     # accumulate over view chunks == one call
     v2 = dd.floater_votes(cloud.points, cloud.normals, depth_in[:3], K[:3], d["cam_from_world"][:3], mask=None if mask is None else mask[:3])
     v2 = dd.floater_votes(cloud.points, cloud.normals, depth_in[3:], K[3:], d["cam_from_world"][3:], mask=None if mask is None else mask[3:], votes=v2)
@@ -107,6 +109,8 @@ def test_gpu_votes_random_scenes(seed):
     culled = np.where(d["mask"], depth, 0).astype(np.float32)
     ref = forc.floater_votes(cloud.points.cpu().numpy(), cloud.normals.cpu().numpy(), culled, K, d["cam_from_world"], depth_threshold=thr)
     assert np.array_equal(votes, ref)
+    classic = dd.floater_votes(cloud.points, cloud.normals, depth, K, d["cam_from_world"], mask=d["mask"], depth_threshold=thr, mode="float64_classic")
+    assert np.array_equal(classic.cpu().numpy(), ref)
 
 
 @pytest.mark.gpu
@@ -142,6 +146,8 @@ def test_gpu_votes_on_decision_boundaries():
     pts = np.concatenate(pts).astype(np.float32); nrm = np.concatenate(nrm).astype(np.float32)
     ref = forc.floater_votes(pts, nrm, depth, K, E)
     got = dd.floater_votes(torch.from_numpy(pts).cuda(), torch.from_numpy(nrm).cuda(), depth, K, E).cpu().numpy()
+    assert np.array_equal(got, ref)
+    got = dd.floater_votes(torch.from_numpy(pts).cuda(), torch.from_numpy(nrm).cuda(), depth, K, E, mode="float64_classic").cpu().numpy()
     assert np.array_equal(got, ref)
     assert 0 < (ref[-20000:] > 0).mean() < 1 and ref[:-20000].max() == 3 and ref[:-20000].min() == 0     # both outcomes occur
 
@@ -238,6 +244,12 @@ def test_float32_first_pass_gives_the_float64_votes():
     v32 = dd.floater_votes(pts, nrm, depth_in, K, E, mask=d["mask"], mode="float32_first", stats=st32)
     vv = dd.floater_votes(pts, nrm, depth_in, K, E, mask=d["mask"], mode="verify", stats=stv)
     assert torch.equal(v32, v64) and torch.equal(vv, v64)
+    vc = dd.floater_votes(pts, nrm, depth_in, K, E, mask=d["mask"], mode="float64_classic")
+    assert torch.equal(vc, v64)                                                # division-free bounds test vs the round-1 kernel
+    fin = torch.isfinite(pts).all(dim=1).cpu().numpy()                         # and the oracle on every finite point
+    culled = np.where(d["mask"], depth_in, 0).astype(np.float32)
+    ref = forc.floater_votes(pts.cpu().numpy()[fin], nrm.cpu().numpy()[fin], culled, K, E)
+    assert np.array_equal(v64.cpu().numpy()[fin], ref)
     assert stv["mismatches"] == 0
     assert 0 < st32["resolved_in_float64"] < 0.2 * st32["pairs"]              # own-view pairs sit on integers: undecided by design
     assert int(v64.max()) >= 3

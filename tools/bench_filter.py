@@ -8,12 +8,22 @@ sys.path.insert(0, str(ROOT))
 import bench, depthdensifier_amd as dd
 
 ap = argparse.ArgumentParser(); ap.add_argument("--views", type=int, default=32); ap.add_argument("--verify", action="store_true")
+ap.add_argument("--modes", default="float64,float32_first,float64,float32_first", help="comma-separated vote modes, timed in this order")
+ap.add_argument("--normals", default="random", choices=("random", "smooth"),
+                help="random: independent unit normals per pixel (bench.py's scene; the grazing test then differs lane by lane); "
+                     "smooth: a slowly varying field facing the camera, like a monocular normal map (coherent within a wave)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 cfg = dict(bench.WORKLOADS["garden185"]); cfg["V"] = a.views
 ids = np.arange(a.views)
 scene = bench.make_scene(cfg, ids, dev)
 H, W = cfg["H"], cfg["W"]
+if a.normals == "smooth":
+    ys = torch.linspace(0, 1, H, device=dev)[:, None].expand(H, W)
+    xs = torch.linspace(0, 1, W, device=dev)[None, :].expand(H, W)
+    for i in range(a.views):
+        n = torch.stack([0.6 * torch.sin(5.0 * xs + i), 0.6 * torch.cos(4.0 * ys + 0.5 * i), -torch.ones_like(xs)], dim=-1)
+        scene["normal"][i] = torch.nn.functional.normalize(n, dim=-1)
 params = np.tile([0.8 * W, 0.8 * W, W / 2.0, H / 2.0], (a.views, 1))
 E = bench.ring_poses(ids, a.views)
 cloud = dd.unproject_views(scene["depth"], params, E, mask=scene["mask"], normal=scene["normal"], rgb=scene["rgb"])
@@ -21,7 +31,7 @@ K = dd.intrinsics_matrix(params)
 torch.cuda.synchronize()
 pairs = len(cloud) * a.views
 sums = {}
-for mode in ("float64", "float32_first", "float64", "float32_first") + (("verify",) if a.verify else ()):
+for mode in tuple(a.modes.split(",")) + (("verify",) if a.verify else ()):
     st = {}
     dd.floater_votes(cloud.points, cloud.normals, scene["depth"], K, E, mask=scene["mask"], mode=mode)   # warm-up (allocations)
     torch.cuda.synchronize()
