@@ -21,7 +21,7 @@ import torch  # noqa: F401  (load order, see above)
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("DDCORE_LIB", _HERE / "libddcore.so"))
 
-DD_ABI_VERSION = 7
+DD_ABI_VERSION = 8
 DD_OK = 0
 DD_F32, DD_F16 = 0, 1
 DD_VALID_DEPTH_POSITIVE = 0x1
@@ -50,6 +50,8 @@ EXPORTS = (
     "dd_sort_knots",
     "dd_allgatherv",
     "dd_comm_last_error",
+    "dd_format_points3d",
+    "dd_model_last_error",
 )
 
 
@@ -162,6 +164,10 @@ def _load() -> C.CDLL:
     lib.dd_allgatherv.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(DDCloudOut), C.POINTER(C.c_int64), C.c_int32, C.c_void_p]
     lib.dd_comm_last_error.restype = C.c_char_p
     lib.dd_comm_last_error.argtypes = []
+    lib.dd_format_points3d.restype = C.c_int
+    lib.dd_format_points3d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.dd_model_last_error.restype = C.c_char_p
+    lib.dd_model_last_error.argtypes = []
     got = lib.dd_abi_version()
     if got != DD_ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI version {got}, binding expects {DD_ABI_VERSION}; rebuild the library")

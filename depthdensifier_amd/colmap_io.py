@@ -415,9 +415,18 @@ class Reconstruction:
         return new_ids
 
     # -- writing ------------------------------------------------------------------------
-    def write_binary(self, path: Union[str, Path]) -> None:
+    def write_binary(self, path: Union[str, Path], dense=None, dense_total: Optional[int] = None, chunk_points: Optional[int] = None) -> dict:
+        """``rec.write_binary(path)`` (``scripts/test.py:363``).  ``dense``: a DEVICE cloud (``FusedCloud``) whose points
+        are written behind this reconstruction's own, exactly as if ``add_points3D(dense.points, dense.colors)`` had
+        been called first -- but formatted on the GPU and streamed to the file chunk by chunk
+        (``model_writer.write_dense_records``), never materialised on the host.  ``dense_total``: the number of dense
+        records the file is announced to hold when this call writes only some (or none) of them -- the other ranks of a
+        multi-GPU run then write their slices with ``model_writer.write_dense_at`` at the returned offsets.
+        Returns ``{"dense_offset": byte offset of the first dense record, "first_dense_id": its id}``."""
         path = Path(path)
         path.mkdir(parents=True, exist_ok=True)
+        n_dense = 0 if dense is None else len(dense)
+        n_announced = n_dense if dense_total is None else int(dense_total)
         with open(path / "cameras.bin", "wb") as f:
             f.write(struct.pack("<Q", len(self.cameras)))
             for c in self.cameras.values():
@@ -438,7 +447,7 @@ class Reconstruction:
                 f.write(o.tobytes())
         with open(path / "points3D.bin", "wb") as f:
             n_old = len(self._track_len)                             # points that may carry tracks come first
-            f.write(struct.pack("<Q", len(self.point_ids)))
+            f.write(struct.pack("<Q", len(self.point_ids) + n_announced))
             if n_old:                                                # heads scattered, tracks poured into the gaps
                 H = _POINT_NO_TRACK.itemsize
                 head = np.empty(n_old, _POINT_NO_TRACK)
@@ -459,6 +468,15 @@ class Reconstruction:
                 rec["id"], rec["xyz"], rec["rgb"] = self.point_ids[n_old:], self.point_xyz[n_old:], self.point_rgb[n_old:]
                 rec["error"], rec["track"] = self.point_error[n_old:], 0
                 rec.tofile(f)
+            first_id = int(self.point_ids.max()) + 1 if len(self.point_ids) else 1
+            f.flush()
+            where = {"dense_offset": f.tell(), "first_dense_id": first_id}
+            if n_dense:
+                from .model_writer import DEFAULT_CHUNK_POINTS, write_dense_records
+                write_dense_records(f, dense, first_id, chunk_points or DEFAULT_CHUNK_POINTS)
+            if n_announced > n_dense:                                # room for the slices the other ranks write in place
+                f.truncate(where["dense_offset"] + n_announced * _POINT_NO_TRACK.itemsize)
+        return where
 
 
 def load_colmap_model(model_path: Union[str, Path]) -> Reconstruction:

@@ -58,6 +58,9 @@ class ProcessingConfig:
     shard_views: bool = True
     """Under torchrun (one process per GPU): shard this scan's views over the ranks.  The batch driver turns it
     off because it shards by scan."""
+    sharded_model_write: bool = True
+    """With sharded views: every rank writes its own slice of the dense points into points3D.bin (the clouds are never
+    gathered: N PCIe links and N writers).  Off: the kept clouds travel to rank 0 over xGMI, which writes alone."""
 
 
 @dataclass
@@ -270,9 +273,19 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
     else:
         from .distributed import floater_votes_sharded
         votes = floater_votes_sharded(cloud, cached, num_views, config.filtering.depth_threshold)
+    plan = None
+    sharded_write = ranks.world > 1 and config.processing.sharded_model_write
     if ranks.world == 1:
         kept = compact_cloud(cloud, votes, config.filtering.vote_threshold)    # :330-332
         n_kept = len(kept)
+    elif sharded_write:
+        # no gather at all: the ranks agree on the row range of every rank's kept points (one all-gather of per-view
+        # counts), each compacts its own cloud, and each writes its own slice of the model file (below)
+        from . import distributed as D
+        from .filtering import kept_per_view
+        plan = D.plan_fuse(kept_per_view(cloud, votes, config.filtering.vote_threshold), num_views, 1)
+        kept = compact_cloud(cloud, votes, config.filtering.vote_threshold)
+        n_kept = plan.total_points
     else:
         # fuse: every rank compacts its kept rows straight into its slice of the global cloud (16-byte xyz + rgba
         # records, all the model writer needs) and the slices travel to rank 0 only; rank order = view order
@@ -293,12 +306,24 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
             for im in todo[hi:]:
                 pw, ph = _processing_size(config.paths.image_dir / im.name, f)
                 rec.cameras[im.camera_id].rescale(new_width=pw, new_height=ph)
-        points = kept.points.cpu().numpy().astype(np.float64)
-        colors = kept.colors.cpu().numpy()
-        say(f"Adding {len(points)} new dense points...")
-        rec.add_points3D(points, colors)                                        # :355-358, bulk
+        say(f"Adding {n_kept} new dense points...")
         config.paths.output_model_dir.mkdir(parents=True, exist_ok=True)
-        rec.write_binary(config.paths.output_model_dir)                         # :363
+        # :355-358 + :363 -- the dense records are formatted on the GPU and streamed behind the sparse points
+        # (model_writer.py); nothing of the dense cloud is materialised on the host
+        # (sharded write: rank 0 lays the file out -- cameras, images, sparse points, room for every dense record --
+        # and then writes its slice like everybody else)
+        where = rec.write_binary(config.paths.output_model_dir, dense=None if sharded_write else kept, dense_total=n_kept)
+    if sharded_write:
+        import torch.distributed as dist
+        from .model_writer import RECORD_BYTES, write_dense_at
+        box = [where if ranks.rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)          # also orders the writes: the file exists at its full size from here on
+        own_lo = plan.rank_rows[ranks.rank][0]
+        if len(kept):
+            write_dense_at(config.paths.output_model_dir / "points3D.bin", box[0]["dense_offset"] + own_lo * RECORD_BYTES,
+                           kept, box[0]["first_dense_id"] + own_lo)
+        dist.barrier()
+    if ranks.rank == 0:
         say(f"COLMAP binary model saved to: {config.paths.output_model_dir}")
         say(f"-> COLMAP model written in {time.time() - t0:.2f}s.")
     stage["write_model"] = time.time() - t0

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 7
+#define DD_ABI_VERSION 8
 
 enum {
     DD_OK = 0,
@@ -272,6 +272,20 @@ int dd_refine_fit(const float *points, int32_t n, const float *cam_from_world, c
                   int32_t half_precision_io, float *z_mono_out, float *z_metric_out, float *scratch, int32_t *meta_out, void *stream);
 /* The knots sorted by x (torch.argsort, :149-151), n <= 4096, one launch. */
 int dd_sort_knots(const float *x, const float *y, int32_t n, float *x_sorted, float *y_sorted, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * the dense points as points3D.bin records, formatted on the device (ABI 8) -- replaces, for the
+ * dense cloud, the per-point loop rec.add_point3D(xyz, Track(), color) of scripts/test.py:355-358 and their
+ * serialisation by rec.write_binary (:363).  Per point 51 bytes, little-endian, no padding (COLMAP's public layout):
+ * point3D_id uint64 = first_id + i | xyz 3 x float64 (the float32 coordinate widened exactly) | rgb 3 x uint8 |
+ * error float64 = -1.0 | track length uint64 = 0.  Input: xyz (n,3) float32 + rgb (n,3) uint8 (NULL = black), or the
+ * 16-byte records xyz_rgba (n,4) of DDCloudOut (then xyz / rgb are ignored).  out: n * 51 bytes of device memory,
+ * 16-byte aligned; the caller copies them behind the records of the sparse points (chunk by chunk: a chunk that
+ * starts at point i0 passes first_id + i0).
+ * ------------------------------------------------------------------------------------------- */
+int dd_format_points3d(const float *xyz, const uint8_t *rgb, const uint32_t *xyz_rgba, int64_t n, uint64_t first_id,
+                       uint8_t *out, void *stream);
+const char *dd_model_last_error(void);
 
 #ifdef __cplusplus
 }

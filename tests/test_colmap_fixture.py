@@ -147,3 +147,62 @@ def test_rescale_follows_colmap(tmp_path):
     assert np.allclose(rad.params, [4627.3 * (sx + sy) / 2, 2473.0 * sx, 1643.0 * sy, 0.0172], rtol=0, atol=1e-12)
     pin.rescale(new_width=618, new_height=411)                     # same size again: identity (several images share a camera)
     assert np.allclose(pin.params[0], 1159.5 * 618 / 1237, atol=1e-12)
+
+
+# ------------------------------------------------------------------ dense points streamed from the GPU
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ("rows", "packed"))
+@pytest.mark.parametrize("n,chunk", ((0, 100), (1, 100), (255, 100), (256, 256), (1000, 257), (70_001, 4096)))
+def test_streamed_dense_records_equal_the_host_writer(tmp_path, form, n, chunk):
+    """``write_binary(dense=device cloud)`` (records formatted by ``dd_format_points3d`` and streamed in chunks) writes
+    the bytes that ``add_points3D`` + ``write_binary`` write: ids continuing after the sparse points, float64 xyz, rgb,
+    error -1, empty tracks -- ``scripts/test.py:355-358, 363``."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import depthdensifier_amd as dd
+    from depthdensifier_amd.colmap_io import Reconstruction
+
+    src = tmp_path / "src"
+    src.mkdir()
+    pack_model(src)
+    rng = np.random.default_rng(n)
+    xyz = (rng.standard_normal((n, 3)) * 10).astype(np.float32)
+    rgb = rng.integers(0, 256, (n, 3), dtype=np.uint8)
+    host = Reconstruction(src)
+    host.add_points3D(xyz.astype(np.float64), rgb)
+    host.write_binary(tmp_path / "host")
+
+    pts, col = torch.from_numpy(xyz).cuda(), torch.from_numpy(rgb).cuda()
+    offs = torch.tensor([0, n], dtype=torch.int64, device="cuda")
+    if form == "rows":
+        cloud = dd.FusedCloud(points=pts, colors=col, normals=None, pixel_index=None, view_index=None, view_offsets=offs)
+    else:
+        rec = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+        rec[:, :3] = pts
+        rgba = col.to(torch.int32)
+        word = rgba[:, 0] | (rgba[:, 1] << 8) | (rgba[:, 2] << 16) | (0xFF << 24)
+        rec.view(torch.int32)[:, 3] = word
+        cloud = dd.FusedCloud.from_packed(rec, offs)
+    dev = Reconstruction(src)
+    where = dev.write_binary(tmp_path / "dev", dense=cloud, chunk_points=chunk)
+    for name in ("cameras.bin", "images.bin", "points3D.bin"):
+        assert (tmp_path / "dev" / name).read_bytes() == (tmp_path / "host" / name).read_bytes(), name
+    back = Reconstruction(tmp_path / "dev")
+    assert back.num_points3D() == host.num_points3D()
+    assert where["first_dense_id"] == int(Reconstruction(src).point_ids.max()) + 1
+
+    # the sharded form: one call lays the file out, slices are written in place in any order
+    if n >= 256:
+        from depthdensifier_amd.model_writer import RECORD_BYTES, write_dense_at
+        lay = Reconstruction(src).write_binary(tmp_path / "shard", dense=None, dense_total=n)
+        cut = n // 3
+
+        def piece(a, b):
+            return dd.FusedCloud(points=pts[a:b], colors=col[a:b], normals=None, pixel_index=None, view_index=None,
+                                 view_offsets=torch.tensor([0, b - a], dtype=torch.int64, device="cuda"))
+        f = tmp_path / "shard" / "points3D.bin"
+        write_dense_at(f, lay["dense_offset"] + cut * RECORD_BYTES, piece(cut, n), lay["first_dense_id"] + cut, chunk_points=chunk)
+        write_dense_at(f, lay["dense_offset"], piece(0, cut), lay["first_dense_id"], chunk_points=chunk)
+        assert f.read_bytes() == (tmp_path / "host" / "points3D.bin").read_bytes()

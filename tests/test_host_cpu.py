@@ -22,7 +22,7 @@ def libmod():
 
 def test_header_symbols_are_exported(libmod):
     header = (ROOT / "include" / "ddcore.h").read_text()
-    declared = set(re.findall(r"\b(dd_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(dd_[a-z0-9_]+)\s*\(", header))
     assert declared == set(libmod.EXPORTS)
     handle = C.CDLL(str(libmod.LIB_PATH))
     for sym in declared:
