@@ -123,6 +123,27 @@ int main() {
         if (mode == 1) { int64_t cur; CK(hipMemcpy(&cur, d_cur, 8, hipMemcpyDeviceToHost)); if (cur != n_ref) { printf("cursor %lld != %lld\n", (long long)cur, (long long)n_ref); return 4; } }
         printf("mode %d: %lld points, xyz max rel err %.2e\n", mode, (long long)n_ref, worst);
     }
+    // the cloud as points3D.bin records (dd_format_points3d): 51 bytes per point, checked field by field
+    {
+        void *d_rec;
+        CK(hipMalloc(&d_rec, (size_t)n_ref * 51 + 16));
+        const uint64_t first_id = 1000000007ull;
+        if (dd_format_points3d((const float *)d_xyz, (const uint8_t *)d_col, NULL, n_ref, first_id, (uint8_t *)d_rec, stream) != DD_OK) {
+            printf("dd_format_points3d: %s\n", dd_model_last_error()); return 3; }
+        CK(hipStreamSynchronize(stream));
+        std::vector<unsigned char> recs((size_t)n_ref * 51);
+        CK(hipMemcpy(recs.data(), d_rec, recs.size(), hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n_ref; ++i) {
+            const unsigned char *r = recs.data() + (size_t)i * 51;
+            uint64_t id, track; double p[3], err;
+            memcpy(&id, r, 8); memcpy(p, r + 8, 24); memcpy(&err, r + 35, 8); memcpy(&track, r + 43, 8);
+            bool ok = id == first_id + (uint64_t)i && err == -1.0 && track == 0;
+            for (int c = 0; c < 3; ++c) ok = ok && p[c] == (double)xyz[3 * i + c] && r[32 + c] == col[3 * i + c];
+            if (!ok) { printf("points3D record %lld is wrong\n", (long long)i); return 4; }
+        }
+        if (dd_format_points3d(NULL, NULL, NULL, 1, 1, (uint8_t *)d_rec, stream) != DD_ERR_INVALID_ARG) { printf("error convention broken\n"); return 5; }
+        printf("points3D records OK\n");
+    }
     // error convention: invalid argument -> negative code + message, nothing thrown
     b.stride = 0;
     if (dd_workspace_bytes(&b) != DD_ERR_INVALID_ARG || strstr(dd_last_error(), "stride") == NULL) { printf("error convention broken\n"); return 5; }
