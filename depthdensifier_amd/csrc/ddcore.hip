@@ -669,7 +669,7 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
         static_assert(sizeof(DepthT) == 4 && SINGLE_PASS, "the fused refine stage runs in the float32 single-pass instantiation");
         // ---- src/depthdensifier/depth_refiner.py:180-205 on this tile, from the RAW depth (scripts/test.py:179-194 fused in) ----
         const DDViewParams *vp = a.params + v;
-        const int nk = vp->n_knots;                                   // wave-uniform
+        const int nk = vp->n_knots < REFINE_MAX_KNOTS ? vp->n_knots : REFINE_MAX_KNOTS;      // wave-uniform; 2..512 by contract (the clamp keeps a bad value inside the LDS array)
         float *const s_kx = s_knots, *const s_ky = s_knots + REFINE_MAX_KNOTS;
         for (int i = tid; i < nk; i += BT) { s_kx[i] = vp->knots_x[i]; s_ky[i] = vp->knots_y[i]; }
         // transformed values of the tile plus W + 1 pixels either side (a 3x3 window of a pixel of the tile reaches one
@@ -679,6 +679,8 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
         const unsigned lo = q0 > Wd + 1u ? q0 - (Wd + 1u) : 0u;
         const unsigned hi = (q0 + (unsigned)LT + Wd + 1u) < a.P ? (q0 + (unsigned)LT + Wd + 1u) : a.P;
         __syncthreads();
+        // (tried in round 2: batches of 7 pixels per lane with their loads issued together and a fixed-trip lockstep search --
+        // 6 % SLOWER on the same box; the other waves of the CU already hide these latencies and the early-exit search does less work)
         for (unsigned e = lo + (unsigned)tid; e < hi; e += (unsigned)BT) {
             const long long p = vbase + e;
             const float raw = a.raw_f16 ? (float)reinterpret_cast<const _Float16 *>(a.depth)[p] : reinterpret_cast<const float *>(a.depth)[p];
