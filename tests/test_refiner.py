@@ -1,5 +1,6 @@
 """DepthRefiner against outputs of the reference's own class (CPU/FP32 goldens)."""
 
+import os
 from pathlib import Path
 
 import numpy as np
@@ -290,3 +291,61 @@ def test_fused_refine_densify_equals_apply_then_densify(shape, with_mask, dtype,
     for name in ("points", "colors", "normals", "pixel_index", "view_index"):
         assert torch.equal(getattr(got, name), getattr(want, name)), name
     assert torch.equal(batch.refined.view(torch.int32), refined.view(torch.int32))          # NaNs included, bit for bit
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DD_REFINE_SEEDS", "16"))))      # soak: DD_REFINE_SEEDS=200
+def test_fused_refine_random(seed):
+    """Seeded sweep of the fused refine stage against dd_refine_apply + plain densify: random view sizes (rows shorter than
+    a wave, widths around the vector / tile sizes), 2..512 knots with repeated x values (the dx == 0 branch), field subsets,
+    both record forms, float16 / float32 raw depth, special values.  Everything must be equal bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import depthdensifier_amd as dd
+    from depthdensifier_amd.depth_refiner import DepthRefiner
+    from synth import random_pose
+    rng = np.random.default_rng(50_000 + seed)
+    g = torch.Generator().manual_seed(50_000 + seed)
+    V = int(rng.integers(1, 4))
+    H, W = (int(rng.integers(2, 60)), int(rng.integers(2, 400))) if rng.uniform() < 0.6 else (int(rng.integers(60, 260)), int(rng.integers(2, 130)))
+    if H * W < 4:
+        W = 4
+    skip = bool(rng.uniform() < 0.3)
+    dtype = torch.float16 if rng.uniform() < 0.4 else torch.float32
+    raw = torch.rand((V, H, W), generator=g) * 4 + 0.2
+    raw[torch.rand((V, H, W), generator=g) < 0.1] = 0.0
+    flat = raw.view(-1)
+    flat[::97] = float("nan"); flat[5::101] = float("inf"); flat[7::103] = -1.0
+    raw = raw.to(dtype).cuda()
+    mask = (torch.rand((V, H, W), generator=g) < float(rng.uniform(0.2, 1.0))).cuda() if rng.uniform() < 0.7 else None
+    normal = torch.nn.functional.normalize(torch.randn((V, H, W, 3), generator=g), dim=-1).cuda() if rng.uniform() < 0.6 else None
+    rgb = torch.randint(0, 256, (V, H, W, 3), generator=g, dtype=torch.uint8).cuda() if rng.uniform() < 0.6 else None
+    params = np.tile([0.9 * W, 0.9 * W, W / 2.0, H / 2.0], (V, 1))
+    E = np.stack([random_pose(rng) for _ in range(V)])
+    r = DepthRefiner(use_fp16=False, skip_smoothing=skip)
+    curves, refined = [], []
+    for v in range(V):
+        n = int(rng.choice([2, 3, 17, 200, 511, 512]))
+        x = torch.rand(n, generator=g) * 3 + 0.5
+        if n > 4:
+            x[1::3] = x[0::3][: len(x[1::3])]                     # repeated knots
+        y = 2.0 * x + 0.3 * torch.rand(n, generator=g)
+        kx, ky = r._sorted_knots(x.cuda(), y.cuda())
+        curves.append((kx, ky, skip))
+        refined.append(r._apply_curve_hip(raw[v], None if mask is None else mask[v], x.cuda(), y.cuda()))
+    refined = torch.stack(refined)
+    record = str(rng.choice(["rows", "xyz_rgba"]))
+    want = dd.unproject_views(refined, params, E, mask=mask, normal=normal, rgb=rgb, view_index=True, capacity="max", record=record)
+    batch = dd.ViewBatch(raw, params, E, mask=mask, normal=normal, rgb=rgb, refine=curves, refined_out=True)
+    rows = record == "rows"
+    b = dd.CloudBuilder(batch.max_points, points=rows, normals=normal is not None, colors=rgb is not None and rows, pixel_index=True,
+                        view_index=True, packed=not rows)
+    b.append(batch)
+    got = b.finish()
+    assert torch.equal(got.view_offsets, want.view_offsets)
+    for name in ("points", "colors", "normals", "pixel_index", "view_index", "packed"):
+        a_, b_ = getattr(got, name), getattr(want, name)
+        assert (a_ is None) == (b_ is None), name
+        if a_ is not None:
+            assert torch.equal(a_.contiguous().view(torch.uint8), b_.contiguous().view(torch.uint8)), name
+    assert torch.equal(batch.refined.view(torch.int32), refined.view(torch.int32))
