@@ -1,0 +1,73 @@
+"""bench.py keeps the driver's contract: ONE JSON line on stdout with the agreed keys, at N = 1 and (rehearsed with the
+ranks sharing the box's GPU over gloo) at N = 2, including the strong-scaling sub-record and the multi-scene workload."""
+
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+pytestmark = pytest.mark.gpu
+
+LINE_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+             "dtype", "data", "config", "roofline"}
+ROOFLINE_KEYS = {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+def _run(cmd, env_extra=None, timeout=240):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, **(env_extra or {}))
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, f"stdout must hold exactly one line, got {len(lines)}: {out.stdout[:500]}"
+    return json.loads(lines[0])
+
+
+def _check(line, n_gpus, steps, warmup):
+    assert LINE_KEYS <= set(line), LINE_KEYS - set(line)
+    assert line["n_gpus"] == n_gpus and line["steps"] == steps and line["warmup"] == warmup
+    assert line["higher_is_better"] is True and line["vs_baseline"] is None and line["data"] == "synthetic"
+    assert line["unit"] == "Mpixels/s" and line["value"] > 0 and line["ms_per_step"] > 0
+    assert "workload" in line["config"] and "model" not in line["config"]
+    r = line["roofline"]
+    assert ROOFLINE_KEYS <= set(r) and r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1 and 0 < r["read_frac"] < r["frac"]
+
+
+def test_single_gpu_line():
+    line = _run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--views", "6", "--strong-views", "8", "--strong-steps", "1",
+                 "--cpu-seconds", "1", "--cpu-procs", "2"])
+    _check(line, 1, 3, 1)
+    assert line["scaling"] == "weak" and line["config"]["workload"] == "garden185"
+    cpu = line["cpu_baseline"]
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(cpu) and cpu["cores"] == 1 and cpu["kind"] == "port" and cpu["value"] > 0
+    assert cpu["reference_formulation"]["value"] > 0
+    s = line["strong2000"]
+    assert s["views_total"] == 8 and all(s[k]["ms"] > 0 for k in ("sharded", "gathered", "gathered_compact")), s
+
+
+def test_two_ranks_sharing_the_gpu():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29655", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--views", "4", "--strong-views", "9",
+           "--strong-steps", "1", "--chunks", "2"]
+    line = _run(cmd, {"DD_BENCH_SHARE_GPU": "1", "DD_ALLGATHERV": "broadcast"})
+    _check(line, 2, 2, 1)
+    assert line["config"]["views_total"] == 8 and "cpu_baseline" not in line
+    s = line["strong2000"]
+    assert s["views_per_gpu"] in (4, 5) and all(s[k]["ms"] > 0 for k in ("sharded", "gathered", "gathered_compact")), s
+    assert s["gathered"]["bytes_received_per_rank"] > 0
+
+
+def test_scene_set_workload_on_three_ranks():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+           "--master-port", "29656", "bench.py", "--gpus", "3", "--workload", "mip360x7", "--views", "40", "--steps", "2", "--warmup", "1",
+           "--strong-views", "0"]
+    line = _run(cmd, {"DD_BENCH_SHARE_GPU": "1"})
+    _check(line, 3, 2, 1)
+    assert line["scaling"] == "strong" and line["config"]["workload"] == "mip360x7" and len(line["config"]["rank0_scenes"]) >= 2
