@@ -163,102 +163,10 @@ __device__ __forceinline__ bool pair_votes(const FArgs &a, const Cam &c, const i
     return zc < (double)limit;                           // :319-328
 }
 
-#ifndef DD_VOTES_CULL
-#define DD_VOTES_CULL 0      // 1 = per-workgroup view culling (bounding sphere vs frustum).  Measured on MI355X: identical
-                             // votes but 18-23 % SLOWER on the ring scene (rejected pairs are already cheap in the exact
-                             // test and skip a whole wave at a time; the cull adds LDS-indexed view lookups + barriers)
-#endif
-
-#if DD_VOTES_CULL
-// Can ANY point of the sphere (centre cx,cy,cz, radius r) pass "in front of the camera and inside the image" of the
-// view with camera block c?  The exact per-pair conditions (zc > 0, 0 <= u < W, 0 <= w < H with
-// u = (K0 . Pcam) / (zc + 1e-8)) are, for zc > 0, linear inequalities in the world point:
-//   zc > 0;  U.p >= 0;  (U - W Z).p - W 1e-8 < 0;  Wv.p >= 0;  (Wv - H Z).p - H 1e-8 < 0
-// (U, Wv, Z: rows K0 [R|t], K1 [R|t], [R|t]_z as 4-vectors, p = (x,y,z,1)).  A plane whose value over the whole
-// sphere has the failing sign -- with a 1e-6 relative safety margin, ten orders of magnitude above the rounding
-// of the exact evaluation -- rejects the view for every point of the workgroup.  NaN / inf anywhere compares
-// false and keeps the view, so the exact test still decides.
-__device__ __forceinline__ bool sphere_may_project(const double *c, const double cx, const double cy, const double cz,
-                                                   const double r, const double cnorm, const double wlim, const double hlim) {
-    double P[5][4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const double X = c[k], Y = c[4 + k], Z = c[8 + k];
-        const double U = c[12] * X + c[13] * Y + c[14] * Z, Wv = c[15] * X + c[16] * Y + c[17] * Z;
-        P[0][k] = Z; P[1][k] = U; P[2][k] = U - wlim * Z; P[3][k] = Wv; P[4][k] = Wv - hlim * Z;
-    }
-    P[2][3] -= wlim * 1e-8;
-    P[4][3] -= hlim * 1e-8;
-    bool out = false;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const double an = sqrt(P[k][0] * P[k][0] + P[k][1] * P[k][1] + P[k][2] * P[k][2]);
-        const double f = P[k][0] * cx + P[k][1] * cy + P[k][2] * cz + P[k][3];
-        const double margin = 1e-6 * (an * (cnorm + r) + fabs(P[k][3]));
-        if (k == 0 || k == 1 || k == 3) out = out || (f + an * r < -margin);      // needs value > 0 / >= 0: all negative
-        else out = out || (f - an * r > margin);                                  // needs value < 0: all positive
-    }
-    return !out;
-}
-#endif
-
 __global__ __launch_bounds__(256) void floater_votes_kernel(const FArgs a) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const bool live = i < a.n;
     const double wlim = (double)a.W, hlim = (double)a.H;
-#if DD_VOTES_CULL
-    __shared__ float s_box[4][6];
-    __shared__ unsigned short s_views[256];
-    __shared__ int s_cnt[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float qnan = __builtin_nanf("");
-    const float fx = live ? a.xyz[3 * i] : qnan, fy = live ? a.xyz[3 * i + 1] : qnan, fz = live ? a.xyz[3 * i + 2] : qnan;
-    const double x = fx, y = fy, z = fz;
-    double nx = 0, ny = 0, nz = 0;
-    if (live) { nx = a.normal[3 * i]; ny = a.normal[3 * i + 1]; nz = a.normal[3 * i + 2]; }
-    // bounding box of the workgroup's points (fminf / fmaxf skip NaN: idle lanes and NaN points do not count;
-    // a NaN point never votes anyway)
-    float lo0 = fx, lo1 = fy, lo2 = fz, hi0 = fx, hi1 = fy, hi2 = fz;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        lo0 = fminf(lo0, __shfl_xor(lo0, o)); lo1 = fminf(lo1, __shfl_xor(lo1, o)); lo2 = fminf(lo2, __shfl_xor(lo2, o));
-        hi0 = fmaxf(hi0, __shfl_xor(hi0, o)); hi1 = fmaxf(hi1, __shfl_xor(hi1, o)); hi2 = fmaxf(hi2, __shfl_xor(hi2, o));
-    }
-    if (lane == 0) { s_box[wave][0] = lo0; s_box[wave][1] = lo1; s_box[wave][2] = lo2; s_box[wave][3] = hi0; s_box[wave][4] = hi1; s_box[wave][5] = hi2; }
-    __syncthreads();
-    double bl[3], bh[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        bl[k] = fminf(fminf(s_box[0][k], s_box[1][k]), fminf(s_box[2][k], s_box[3][k]));
-        bh[k] = fmaxf(fmaxf(s_box[0][k + 3], s_box[1][k + 3]), fmaxf(s_box[2][k + 3], s_box[3][k + 3]));
-    }
-    const double cx = 0.5 * (bl[0] + bh[0]), cy = 0.5 * (bl[1] + bh[1]), cz = 0.5 * (bl[2] + bh[2]);
-    const double ex = bh[0] - bl[0], ey = bh[1] - bl[1], ez = bh[2] - bl[2];
-    const double r = 0.5 * sqrt(ex * ex + ey * ey + ez * ez) * (1.0 + 1e-9);     // half diagonal: every point is inside
-    const double cnorm = fabs(cx) + fabs(cy) + fabs(cz);
-    int votes = (live && a.accumulate) ? a.votes[i] : 0;
-    for (int v0 = 0; v0 < a.V; v0 += 256) {
-        // phase A: one lane per view of this chunk decides whether the workgroup can see it at all
-        const int mine = v0 + (int)threadIdx.x;
-        const bool keep = mine < a.V && sphere_may_project(a.cams + (size_t)mine * 24, cx, cy, cz, r, cnorm, wlim, hlim);
-        const unsigned long long b = __ballot(keep);
-        if (keep) s_views[wave * 64 + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)threadIdx.x;
-        if (lane == 0) s_cnt[wave] = __popcll(b);
-        __syncthreads();
-        // phase B: every lane runs the exact test against the surviving views only
-        if (live) {
-            for (int w = 0; w < 4; ++w) {
-                const int cnt = __builtin_amdgcn_readfirstlane(s_cnt[w]);
-                for (int k = 0; k < cnt; ++k) {
-                    const int v = v0 + __builtin_amdgcn_readfirstlane((int)s_views[w * 64 + k]);      // uniform: scalar loads
-                    votes += pair_votes(a, a.cams + (size_t)v * 24, v, x, y, z, nx, ny, nz, wlim, hlim) ? 1 : 0;
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (live) a.votes[i] = votes;
-#else
     if (!live) return;
     const double x = a.xyz[3 * i], y = a.xyz[3 * i + 1], z = a.xyz[3 * i + 2];
     const double nx = a.normal[3 * i], ny = a.normal[3 * i + 1], nz = a.normal[3 * i + 2];
@@ -278,7 +186,6 @@ __global__ __launch_bounds__(256) void floater_votes_kernel(const FArgs a) {
         cur = nxt;
     }
     a.votes[i] = votes;
-#endif
 }
 
 // ==================================================================================================
@@ -383,7 +290,15 @@ __device__ __forceinline__ bool pair_votes2(const FArgs &a, const Cam2 &c, const
     return zc < (double)limit;                           // :319-328
 }
 
-__global__ __launch_bounds__(256) void floater_votes_kernel2(const FArgs a, const double *tab) {
+// `decide`: NULL, or two counters written by votes_cull_estimate -- [0] (workgroup, view) cells that survive the cull,
+// [1] cells tested.  The plain kernel runs when culling would remove less than 30 % of the cells, the culling kernel
+// otherwise; both are launched and the one not chosen returns at once (no host round trip).
+__device__ __forceinline__ bool cull_chosen(const unsigned long long *decide) {
+    return decide[0] * 10ull < decide[1] * 7ull;
+}
+
+__global__ __launch_bounds__(256) void floater_votes_kernel2(const FArgs a, const double *tab, const unsigned long long *decide) {
+    if (decide && cull_chosen(decide)) return;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= a.n) return;
     const double wlim = (double)a.W, hlim = (double)a.H;
@@ -404,6 +319,153 @@ __global__ __launch_bounds__(256) void floater_votes_kernel2(const FArgs a, cons
         cur = nxt;
     }
     a.votes[i] = votes;
+}
+
+// ==================================================================================================
+// Per-workgroup view culling (round 2; the compile-time experiment of round 1 made a run-time choice).
+//
+// The exact per-pair conditions "in front of the camera and inside the image" (zc > 0, 0 <= u < W, 0 <= w < H with
+// u = (K0 . Pcam) / (zc + 1e-8)) are, for zc > 0, linear inequalities in the world point p4 = (x, y, z, 1):
+//   Z.p4 > 0;  U.p4 >= 0;  (U - W Z).p4 - W 1e-8 < 0;  Wv.p4 >= 0;  (Wv - H Z).p4 - H 1e-8 < 0
+// (U, Wv, Z: rows K0 [R|t], K1 [R|t], [R|t]_z).  A workgroup's 256 points are 256 consecutive surviving pixels of one
+// source view -- a short stretch of surface -- and lie inside a small sphere; when one of the five planes has the failing
+// sign over the whole sphere, with a 1e-6 relative safety margin (ten orders of magnitude above the rounding of the
+// exact evaluation), no point of the workgroup can collect a vote from that view and the view is skipped for all of
+// them.  NaN / inf anywhere compares false and keeps the view, so the exact test still decides.  Votes are unchanged
+// by construction (tests: equality with the un-culled kernels on every scene, the oracle, the reference's fixture).
+//
+// On an inward-facing ring every view sees almost every point: nothing to cull, and the culling kernel is 18-23 % slower
+// than the plain one (LDS view lists, barriers, no camera prefetch).  On a scan whose views look at different parts of
+// the scene -- what 2000 views of anything larger than a table top are -- most (workgroup, view) cells drop out.
+// votes_cull_estimate measures the surviving fraction on a sample of workgroups and the kernels choose on the device.
+// ==================================================================================================
+constexpr int PLANE_STRIDE = 32;      // doubles per view: 5 planes x (nx, ny, nz, d) [0..19], |normal| [20..24], |d| [25..29]
+
+__global__ __launch_bounds__(64) void votes_prepare_planes(const double *cams, double *planes, int V, int H, int W) {
+    const int v = blockIdx.x * 64 + threadIdx.x;
+    if (v >= V) return;
+    const double *c = cams + (size_t)v * 24;
+    double *o = planes + (size_t)v * PLANE_STRIDE;
+    const double wlim = (double)W, hlim = (double)H;
+    double P[5][4];
+    for (int k = 0; k < 4; ++k) {
+        const double X = c[k], Y = c[4 + k], Z = c[8 + k];
+        const double U = c[12] * X + c[13] * Y + c[14] * Z, Wv = c[15] * X + c[16] * Y + c[17] * Z;
+        P[0][k] = Z; P[1][k] = U; P[2][k] = U - wlim * Z; P[3][k] = Wv; P[4][k] = Wv - hlim * Z;
+    }
+    P[2][3] -= wlim * 1e-8;
+    P[4][3] -= hlim * 1e-8;
+    for (int k = 0; k < 5; ++k) {
+        for (int j = 0; j < 4; ++j) o[4 * k + j] = P[k][j];
+        o[20 + k] = sqrt(P[k][0] * P[k][0] + P[k][1] * P[k][1] + P[k][2] * P[k][2]);
+        o[25 + k] = fabs(P[k][3]);
+    }
+    o[30] = 0.0; o[31] = 0.0;
+}
+
+// can ANY point of the sphere (centre, radius r; cnorm = |cx| + |cy| + |cz|) pass the five conditions of view `o`?
+__device__ __forceinline__ bool sphere_may_project(const double *o, const double cx, const double cy, const double cz,
+                                                   const double r, const double cnorm) {
+    bool out = false;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const double an = o[20 + k];
+        const double f = o[4 * k] * cx + o[4 * k + 1] * cy + o[4 * k + 2] * cz + o[4 * k + 3];
+        const double margin = 1e-6 * (an * (cnorm + r) + o[25 + k]);
+        if (k == 0 || k == 1 || k == 3) out = out || (f + an * r < -margin);      // needs value > 0 / >= 0: negative everywhere
+        else out = out || (f - an * r > margin);                                  // needs value < 0: positive everywhere
+    }
+    return !out;
+}
+
+// bounding sphere of the workgroup's points (fminf / fmaxf skip NaN: idle lanes and NaN points do not count -- a NaN
+// point never votes anyway; an infinite coordinate makes r infinite or NaN and every view is kept)
+__device__ __forceinline__ void tile_sphere(const float fx, const float fy, const float fz, float (*s_box)[6], double &cx, double &cy,
+                                            double &cz, double &r, double &cnorm) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float lo0 = fx, lo1 = fy, lo2 = fz, hi0 = fx, hi1 = fy, hi2 = fz;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo0 = fminf(lo0, __shfl_xor(lo0, o)); lo1 = fminf(lo1, __shfl_xor(lo1, o)); lo2 = fminf(lo2, __shfl_xor(lo2, o));
+        hi0 = fmaxf(hi0, __shfl_xor(hi0, o)); hi1 = fmaxf(hi1, __shfl_xor(hi1, o)); hi2 = fmaxf(hi2, __shfl_xor(hi2, o));
+    }
+    if (lane == 0) { s_box[wave][0] = lo0; s_box[wave][1] = lo1; s_box[wave][2] = lo2; s_box[wave][3] = hi0; s_box[wave][4] = hi1; s_box[wave][5] = hi2; }
+    __syncthreads();
+    double bl[3], bh[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        bl[k] = fminf(fminf(s_box[0][k], s_box[1][k]), fminf(s_box[2][k], s_box[3][k]));
+        bh[k] = fmaxf(fmaxf(s_box[0][k + 3], s_box[1][k + 3]), fmaxf(s_box[2][k + 3], s_box[3][k + 3]));
+    }
+    cx = 0.5 * (bl[0] + bh[0]); cy = 0.5 * (bl[1] + bh[1]); cz = 0.5 * (bl[2] + bh[2]);
+    const double ex = bh[0] - bl[0], ey = bh[1] - bl[1], ez = bh[2] - bl[2];
+    r = 0.5 * sqrt(ex * ex + ey * ey + ez * ez) * (1.0 + 1e-9);                   // half diagonal: every point is inside
+    cnorm = fabs(cx) + fabs(cy) + fabs(cz);
+}
+
+// a sample of the workgroups (every `stride`-th): how many (workgroup, view) cells survive the cull?
+__global__ __launch_bounds__(256) void votes_cull_estimate(const FArgs a, const double *planes, unsigned long long *decide, const long long stride) {
+    __shared__ float s_box[4][6];
+    const long long i = (long long)blockIdx.x * stride * 256 + threadIdx.x;
+    const bool live = i < a.n;
+    const float qnan = __builtin_nanf("");
+    const float fx = live ? a.xyz[3 * i] : qnan, fy = live ? a.xyz[3 * i + 1] : qnan, fz = live ? a.xyz[3 * i + 2] : qnan;
+    double cx, cy, cz, r, cnorm;
+    tile_sphere(fx, fy, fz, s_box, cx, cy, cz, r, cnorm);
+    unsigned kept = 0;
+    for (int v = (int)threadIdx.x; v < a.V; v += 256) kept += sphere_may_project(planes + (size_t)v * PLANE_STRIDE, cx, cy, cz, r, cnorm) ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&decide[0], (unsigned long long)kept);
+        if (threadIdx.x == 0) atomicAdd(&decide[1], (unsigned long long)a.V);
+    }
+}
+
+__global__ __launch_bounds__(256) void floater_votes_kernel_cull(const FArgs a, const double *tab, const double *planes,
+                                                                 const unsigned long long *decide) {
+    if (decide && !cull_chosen(decide)) return;
+    __shared__ float s_box[4][6];
+    __shared__ unsigned short s_views[256];
+    __shared__ int s_cnt[4];
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < a.n;
+    const double wlim = (double)a.W, hlim = (double)a.H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float qnan = __builtin_nanf("");
+    const float fx = live ? a.xyz[3 * i] : qnan, fy = live ? a.xyz[3 * i + 1] : qnan, fz = live ? a.xyz[3 * i + 2] : qnan;
+    const double x = fx, y = fy, z = fz;
+    double nx = 0, ny = 0, nz = 0;
+    if (live) { nx = a.normal[3 * i]; ny = a.normal[3 * i + 1]; nz = a.normal[3 * i + 2]; }
+    const double S = fabs(x) + fabs(y) + fabs(z) + 1.0;
+    double cx, cy, cz, r, cnorm;
+    tile_sphere(fx, fy, fz, s_box, cx, cy, cz, r, cnorm);
+    int votes = (live && a.accumulate) ? a.votes[i] : 0;
+    for (int v0 = 0; v0 < a.V; v0 += 256) {
+        // phase A: one lane per view of this chunk decides whether the workgroup can see it at all
+        const int mine = v0 + (int)threadIdx.x;
+        const bool keep = mine < a.V && sphere_may_project(planes + (size_t)mine * PLANE_STRIDE, cx, cy, cz, r, cnorm);
+        const unsigned long long b = __ballot(keep);
+        if (keep) s_views[wave * 64 + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)threadIdx.x;
+        if (lane == 0) s_cnt[wave] = __popcll(b);
+        __syncthreads();
+        // phase B: every lane runs the exact test against the surviving views only
+        if (live) {
+            for (int w = 0; w < 4; ++w) {
+                const int cnt = __builtin_amdgcn_readfirstlane(s_cnt[w]);
+                for (int k = 0; k < cnt; ++k) {
+                    const int v = v0 + __builtin_amdgcn_readfirstlane((int)s_views[w * 64 + k]);      // uniform: scalar loads
+                    cam_vec4 *p = (cam_vec4 *)(tab + (size_t)v * 32);
+                    Cam2 c;
+                    c.zr = p[2]; c.m0 = p[6]; c.m1 = p[7];
+                    c.rest = (cam_double *)(tab + (size_t)v * 32);
+                    votes += pair_votes2(a, c, v, x, y, z, nx, ny, nz, S, wlim, hlim) ? 1 : 0;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (live) a.votes[i] = votes;
 }
 
 // ==================================================================================================
@@ -941,7 +1003,7 @@ int dd_floater_votes(const DDFilterViews *views, const float *xyz, const float *
     const size_t bitmap = (((size_t)blocks * (size_t)chunks_total + 31) / 32 * 4 + 15) & ~(size_t)15;
     const bool usable = views->workspace && views->workspace_bytes >= (int64_t)(fixed + bitmap + 8 * 4096 * V_SHARDS) &&
                         (unsigned long long)blocks * (unsigned long long)chunks_total < (1ull << 32) && V < (1 << 20) && n < (1ll << 43);
-    const bool first_pass = views->mode != 1 && usable && views->grazing_cos > 0.0 && views->grazing_cos < 1e6 &&
+    const bool first_pass = (views->mode == 0 || views->mode == 2) && usable && views->grazing_cos > 0.0 && views->grazing_cos < 1e6 &&
                             views->height < (1 << 23) && views->width < (1 << 23) && (long long)views->height * views->width < (1ll << 31);
     if (views->mode == 2 && !first_pass) return fail("mode 2 (verify) needs the workspace of dd_votes_workspace_bytes()");
     if (first_pass) {
@@ -975,11 +1037,28 @@ int dd_floater_votes(const DDFilterViews *views, const float *xyz, const float *
             hipLaunchKernelGGL(votes_resolve, dim3(resolve_blocks, V_SHARDS), dim3(256), 0, s, r, gq, entries, capacity);
             hipLaunchKernelGGL(votes_redo, dim3((unsigned)blocks), dim3(256), 0, s, r, v0, v1, redo, (int)chunks_total);
         }
+    } else if (views->mode == 3 || views->mode == 4) {
+        // float64 with per-workgroup view culling: 3 = always, 4 = chosen on the device from a sample of the workgroups
+        if (!views->workspace || views->workspace_bytes < (int64_t)V * 512 + 64) return fail("modes 3 / 4 need a workspace of 512 * num_views + 64 bytes");
+        if (((uintptr_t)views->workspace % 32) != 0) return fail("workspace must be 32-byte aligned");
+        double *tab = reinterpret_cast<double *>(views->workspace);
+        double *planes = tab + (size_t)V * 32;
+        unsigned long long *decide = reinterpret_cast<unsigned long long *>(planes + (size_t)V * PLANE_STRIDE);
+        hipLaunchKernelGGL(votes_prepare64, dim3((unsigned)((V + 63) / 64)), dim3(64), 0, s, views->cams, tab, V, views->height, views->width);
+        hipLaunchKernelGGL(votes_prepare_planes, dim3((unsigned)((V + 63) / 64)), dim3(64), 0, s, views->cams, planes, V, views->height, views->width);
+        if (views->mode == 4) {
+            if (hipMemsetAsync(decide, 0, 16, s) != hipSuccess) { snprintf(g_ferr, sizeof(g_ferr), "hipMemsetAsync(decide) failed"); return DD_ERR_LAUNCH; }
+            const long long sample = blocks < 512 ? blocks : 512, stride = blocks / sample;
+            hipLaunchKernelGGL(votes_cull_estimate, dim3((unsigned)sample), dim3(256), 0, s, a, (const double *)planes, decide, stride);
+            hipLaunchKernelGGL(floater_votes_kernel2, dim3((unsigned)blocks), dim3(256), 0, s, a, (const double *)tab, (const unsigned long long *)decide);
+        } else decide = nullptr;
+        hipLaunchKernelGGL(floater_votes_kernel_cull, dim3((unsigned)blocks), dim3(256), 0, s, a, (const double *)tab, (const double *)planes,
+                           (const unsigned long long *)decide);
     } else if (views->mode == 1 && views->workspace && views->workspace_bytes >= (int64_t)V * 256) {
         if (((uintptr_t)views->workspace % 32) != 0) return fail("workspace must be 32-byte aligned");
         double *tab = reinterpret_cast<double *>(views->workspace);
         hipLaunchKernelGGL(votes_prepare64, dim3((unsigned)((V + 63) / 64)), dim3(64), 0, s, views->cams, tab, V, views->height, views->width);
-        hipLaunchKernelGGL(floater_votes_kernel2, dim3((unsigned)blocks), dim3(256), 0, s, a, (const double *)tab);
+        hipLaunchKernelGGL(floater_votes_kernel2, dim3((unsigned)blocks), dim3(256), 0, s, a, (const double *)tab, (const unsigned long long *)nullptr);
     } else
     hipLaunchKernelGGL(floater_votes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     if (hipGetLastError() != hipSuccess) { snprintf(g_ferr, sizeof(g_ferr), "floater_votes launch failed"); return DD_ERR_LAUNCH; }

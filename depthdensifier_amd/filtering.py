@@ -52,17 +52,21 @@ def filter_cameras(intrinsics: ArrayLike, cam_from_world: ArrayLike) -> np.ndarr
     return cams
 
 
-VOTE_MODES = {"float64": 1, "float64_classic": 1, "float32_first": 0, "verify": 2}
+VOTE_MODES = {"auto": 4, "float64": 1, "float64_classic": 1, "float64_cull": 3, "float32_first": 0, "verify": 2}
 
 
 def floater_votes(points: torch.Tensor, normals: torch.Tensor, depth: ArrayLike, intrinsics: ArrayLike,
                   cam_from_world: ArrayLike, mask: Optional[ArrayLike] = None, depth_threshold: float = 0.7,
-                  votes: Optional[torch.Tensor] = None, mode: str = "float64", stats: Optional[dict] = None) -> torch.Tensor:
+                  votes: Optional[torch.Tensor] = None, mode: str = "auto", stats: Optional[dict] = None) -> torch.Tensor:
     """(N,) int32 votes of ``scripts/test.py:273-328``.  ``depth`` (V,H,W) float32 is the refined depth
     of the cached views (``:197-201``); with ``mask`` given, masked-out pixels read as 0 (``:194``).
     Pass ``votes`` to accumulate over several calls (views in chunks).
 
-    ``mode``: ``"float64"`` (default) = every decision in float64, the fastest form on MI355X (division-free image-bounds
+    ``mode``: ``"auto"`` (default) = ``"float64"`` or ``"float64_cull"``, chosen on the device from a sample of the
+    workgroups (no host round trip): ``"float64_cull"`` skips, for each workgroup of 256 consecutive points, every view
+    whose frustum the workgroup's bounding sphere cannot touch (conservative, same votes) -- several times faster when the
+    views look at different parts of the scene, ~20 % slower when every view sees everything (an inward-facing ring);
+    ``"float64"`` = every decision in float64, the fastest un-culled form on MI355X (division-free image-bounds
     test first, grazing second, reciprocal only for pairs that reach the lookup; a 256-byte table per view is built in a
     scratch buffer); ``"float64_classic"`` = the round-1 kernel (projection with a reciprocal for every pair in front of
     the camera; needs no scratch -- what a C caller gets with ``workspace = NULL``);
@@ -100,7 +104,8 @@ def floater_votes(points: torch.Tensor, normals: torch.Tensor, depth: ArrayLike,
     if votes is None:
         votes = torch.empty(pts.shape[0], dtype=torch.int32, device=dev)
     V, H, W = d.shape
-    ws_bytes = {"float64": 256 * V, "float64_classic": 16}.get(mode) or int(lib.dd_votes_workspace_bytes(V, pts.shape[0]))
+    ws_bytes = {"float64": 256 * V, "float64_classic": 16, "float64_cull": 512 * V + 64, "auto": 512 * V + 64}.get(mode) \
+        or int(lib.dd_votes_workspace_bytes(V, pts.shape[0]))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     fv = DDFilterViews(num_views=V, height=H, width=W, depth=d.data_ptr(), mask=None if m is None else m.data_ptr(),
                        cams=cams.data_ptr(), grazing_cos=GRAZING_COS, depth_threshold=float(depth_threshold),
@@ -110,7 +115,10 @@ def floater_votes(points: torch.Tensor, normals: torch.Tensor, depth: ArrayLike,
     if rc < 0:
         raise DDCoreError(rc, lib.dd_filter_last_error().decode())
     if stats is not None:
-        w = [0, 0] if mode.startswith("float64") else ws[:64 * 128].view(torch.int64).view(64, 16)[:, :2].sum(dim=0).tolist()   # 64 shards, a line each
+        if mode == "auto":          # the two counters of the on-device choice (workgroup x view cells that survive / were sampled)
+            d_ = ws[512 * V:512 * V + 16].view(torch.int64).tolist()
+            stats.update(cull_sample_survived=int(d_[0]), cull_sample_cells=int(d_[1]), culled=bool(d_[0] * 10 < d_[1] * 7))
+        w = [0, 0] if mode.startswith("float64") or mode == "auto" else ws[:64 * 128].view(torch.int64).view(64, 16)[:, :2].sum(dim=0).tolist()   # 64 shards, a line each
         stats.update(pairs=int(pts.shape[0]) * V, resolved_in_float64=int(w[0]), mismatches=int(w[1]), mode=mode)
     # asynchronous: temporaries freed here are only reused by later work on the same stream
     return votes

@@ -222,7 +222,10 @@ typedef struct DDFilterViews {
                                8 KiB hold 64 shards of 16 uint64: [0] pairs left undecided, [1] verify disagreements. */
     int64_t workspace_bytes;
     int32_t mode;           /* with a workspace: 0 = float32 first pass; 1 = float64 throughout; 2 = verify: every decision of
-                               the float32 pass is also taken in float64 and disagreements are counted (must be 0) */
+                               the float32 pass is also taken in float64 and disagreements are counted (must be 0);
+                               3 = float64 with per-workgroup view culling (a view is skipped for 256 consecutive points when
+                               their bounding sphere cannot touch its frustum -- conservative, same votes); 4 = 1 or 3, chosen on
+                               the device from a sample of the workgroups.  3 / 4 need 512 * num_views + 64 bytes, 32-B aligned */
     int32_t reserved3;
 } DDFilterViews;
 

@@ -266,3 +266,59 @@ def test_float32_first_pass_gives_the_float64_votes():
     rc = _lib.lib.dd_floater_votes(C.byref(fv), pts.data_ptr(), nrm.data_ptr(), n, out.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
     assert rc == 0, _lib.lib.dd_filter_last_error()
     assert torch.equal(out, v64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ("ring", "outward", "corridor"))
+def test_view_culling_keeps_the_votes(layout):
+    """Per-workgroup view culling ("float64_cull": a view is skipped for 256 consecutive points when their bounding sphere
+    cannot touch its frustum) and the on-device choice ("auto") give the votes of the un-culled kernels and of the oracle
+    -- on a ring where nothing can be culled, with cameras looking outward from one spot (every view sees its own points
+    only) and along a corridor (each view overlaps a few neighbours); special depths (inf -> infinite spheres) included."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import depthdensifier_amd as dd
+    V, H, W = 12, 72, 96
+    d = _scene(21, V, H, W)
+    rng = np.random.default_rng(3)
+    E = d["cam_from_world"]
+    if layout != "ring":
+        for v in range(V):
+            if layout == "outward":       # at the origin, looking away from it in 12 directions
+                a = 2 * np.pi * v / V
+                c = np.array([0.05 * np.cos(a), 0.0, 0.05 * np.sin(a)]); z = np.array([np.cos(a), 0.0, np.sin(a)])
+            else:                          # walking along x, looking sideways (+z), slightly panning
+                c = np.array([1.2 * v, 0.0, 0.0]); z = np.array([0.15 * np.sin(v), 0.0, 1.0]); z /= np.linalg.norm(z)
+            x = np.cross([0, 1.0, 0], z); x /= np.linalg.norm(x); y = np.cross(z, x)
+            R = np.stack([x, y, z]); E[v, :, :3] = R; E[v, :, 3] = -R @ c
+        # a smooth surface ~3 m away (a workgroup's 256 pixels then lie in a small sphere); the special depths stay
+        smooth = (3.0 + 0.2 * rng.standard_normal(d["depth"].shape)).astype(np.float32)
+        ordinary = np.isfinite(d["depth"]) & (d["depth"] > 0)
+        d["depth"] = np.where(ordinary, smooth, d["depth"])
+    K = dd.intrinsics_matrix(d["params"])
+    depth_in = np.where(np.isfinite(d["depth"]), d["depth"], 0).astype(np.float32)
+    cloud = dd.unproject_views(d["depth"], d["params"], E, mask=d["mask"], normal=d["normal"])     # inf depths -> inf points
+    res, stats = {}, {}
+    for mode in ("float64_classic", "float64", "float64_cull", "auto"):
+        st = {}
+        res[mode] = dd.floater_votes(cloud.points, cloud.normals, depth_in, K, E, mask=d["mask"], mode=mode, stats=st).cpu().numpy()
+        stats[mode] = st
+    for mode in ("float64", "float64_cull", "auto"):
+        assert np.array_equal(res[mode], res["float64_classic"]), mode
+    pts = cloud.points.cpu().numpy()
+    fin = np.isfinite(pts).all(axis=1)
+    culled = np.where(d["mask"], depth_in, 0).astype(np.float32)
+    ref = forc.floater_votes(pts[fin], cloud.normals.cpu().numpy()[fin], culled, K, E)
+    assert np.array_equal(res["auto"][fin], ref)
+    s = stats["auto"]
+    assert s["cull_sample_cells"] > 0 and 0 <= s["cull_sample_survived"] <= s["cull_sample_cells"]
+    frac = s["cull_sample_survived"] / s["cull_sample_cells"]
+    if layout == "outward":              # each point is inside two or three of the twelve 58-degree frusta
+        assert s["culled"] and frac < 0.7, frac
+    if layout == "ring":
+        assert not s["culled"], frac
+    # accumulating over chunks of views goes through the same choice per call
+    v2 = dd.floater_votes(cloud.points, cloud.normals, depth_in[:5], K[:5], E[:5], mask=d["mask"][:5], mode="float64_cull")
+    v2 = dd.floater_votes(cloud.points, cloud.normals, depth_in[5:], K[5:], E[5:], mask=d["mask"][5:], votes=v2, mode="auto")
+    assert np.array_equal(v2.cpu().numpy(), res["float64_classic"])

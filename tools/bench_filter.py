@@ -8,10 +8,14 @@ sys.path.insert(0, str(ROOT))
 import bench, depthdensifier_amd as dd
 
 ap = argparse.ArgumentParser(); ap.add_argument("--views", type=int, default=32); ap.add_argument("--verify", action="store_true")
-ap.add_argument("--modes", default="float64,float32_first,float64,float32_first", help="comma-separated vote modes, timed in this order")
+ap.add_argument("--modes", default="auto,float64,float64_cull,float64_classic", help="comma-separated vote modes, timed in this order")
 ap.add_argument("--normals", default="random", choices=("random", "smooth"),
                 help="random: independent unit normals per pixel (bench.py's scene; the grazing test then differs lane by lane); "
                      "smooth: a slowly varying field facing the camera, like a monocular normal map (coherent within a wave)")
+ap.add_argument("--layout", default="ring", choices=("ring", "corridor"),
+                help="ring: cameras around the scene looking inward, every view sees almost every point (bench.py's poses); "
+                     "corridor: cameras 1 m apart along a line looking sideways at a surface 1-8 m away -- a point is inside "
+                     "5-6 frusta whatever the number of views, like any scan larger than a table top")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 cfg = dict(bench.WORKLOADS["garden185"]); cfg["V"] = a.views
@@ -26,6 +30,11 @@ if a.normals == "smooth":
         scene["normal"][i] = torch.nn.functional.normalize(n, dim=-1)
 params = np.tile([0.8 * W, 0.8 * W, W / 2.0, H / 2.0], (a.views, 1))
 E = bench.ring_poses(ids, a.views)
+if a.layout == "corridor":
+    E = np.zeros((a.views, 3, 4))
+    for v in range(a.views):
+        E[v, :, :3] = np.eye(3)                     # looking along +z, x to the right
+        E[v, :, 3] = -np.array([1.0 * v, 0.0, 0.0])
 cloud = dd.unproject_views(scene["depth"], params, E, mask=scene["mask"], normal=scene["normal"], rgb=scene["rgb"])
 K = dd.intrinsics_matrix(params)
 torch.cuda.synchronize()
@@ -42,7 +51,8 @@ for mode in tuple(a.modes.split(",")) + (("verify",) if a.verify else ()):
     sums[mode] = (int(votes.long().sum()), int((votes.long() * (torch.arange(len(votes), device=votes.device) % 1000003)).sum()))
     print(f"[{mode:13s}] points {len(cloud)/1e6:.1f} M x views {a.views} = {pairs/1e9:.2f} G pairs in {dt*1e3:.1f} ms -> {pairs/dt/1e9:.1f} Gpairs/s; "
           f"votes>=5: {(votes >= 5).float().mean().item()*100:.2f} %  max {int(votes.max())}; resolved in float64 {st['resolved_in_float64']} "
-          f"({st['resolved_in_float64']/pairs*100:.3f} % of pairs); mismatches {st['mismatches']}; checksum {sums[mode]}")
+          f"({st['resolved_in_float64']/pairs*100:.3f} % of pairs); mismatches {st['mismatches']}; checksum {sums[mode]}"
+          + (f"; sampled cells surviving the cull {st['cull_sample_survived'] / max(st['cull_sample_cells'], 1) * 100:.1f} % -> {'culling' if st['culled'] else 'plain'} kernel" if mode == "auto" else ""))
 assert len(set(sums.values())) == 1, f"votes differ between modes: {sums}"
 print("votes identical in every mode")
 # the NumPy baseline of this stage is timed by tests/time_filter_oracle.py (the oracle is test infrastructure)
