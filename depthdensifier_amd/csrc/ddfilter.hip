@@ -422,8 +422,57 @@ __global__ __launch_bounds__(256) void votes_cull_estimate(const FArgs a, const 
     }
 }
 
+// Level 1 of the cull (scans of thousands of views, where V sphere tests per workgroup would start to dominate): a
+// SUPER-TILE is 256 workgroups = 65 536 consecutive points (a band of a few dozen image rows of one source view); its
+// bounding sphere is tested against every view once and the survivors are kept as a bit mask of V bits.  A workgroup
+// then tests its own, much smaller sphere only against the views of its super-tile's mask, and skips chunks of 256
+// views whose four mask words are zero without touching the plane table.
+constexpr int SUPER = 256;            // workgroups per super-tile
+
+__global__ __launch_bounds__(256) void votes_supertile_masks(const FArgs a, const double *planes, unsigned long long *masks,
+                                                             const int words, const unsigned long long *decide) {
+    if (decide && !cull_chosen(decide)) return;
+    __shared__ float s_box[4][6];
+    const long long base = (long long)blockIdx.x * SUPER * 256;
+    const float qnan = __builtin_nanf("");
+    float lo0 = qnan, lo1 = qnan, lo2 = qnan, hi0 = qnan, hi1 = qnan, hi2 = qnan;
+    for (int k = 0; k < SUPER; ++k) {
+        const long long i = base + (long long)k * 256 + threadIdx.x;
+        if (i >= a.n) break;
+        const float fx = a.xyz[3 * i], fy = a.xyz[3 * i + 1], fz = a.xyz[3 * i + 2];
+        lo0 = fminf(lo0, fx); lo1 = fminf(lo1, fy); lo2 = fminf(lo2, fz);
+        hi0 = fmaxf(hi0, fx); hi1 = fmaxf(hi1, fy); hi2 = fmaxf(hi2, fz);
+    }
+    // tile_sphere reduces one point per lane: feed it the two corners of this lane's box in turn and join the results
+    double c0[3], c1[3], r0, r1, n0, n1;
+    tile_sphere(lo0, lo1, lo2, s_box, c0[0], c0[1], c0[2], r0, n0);
+    __syncthreads();
+    const float l0 = fminf(fminf(s_box[0][0], s_box[1][0]), fminf(s_box[2][0], s_box[3][0]));
+    const float l1 = fminf(fminf(s_box[0][1], s_box[1][1]), fminf(s_box[2][1], s_box[3][1]));
+    const float l2 = fminf(fminf(s_box[0][2], s_box[1][2]), fminf(s_box[2][2], s_box[3][2]));
+    __syncthreads();
+    tile_sphere(hi0, hi1, hi2, s_box, c1[0], c1[1], c1[2], r1, n1);
+    const float h0 = fmaxf(fmaxf(s_box[0][3], s_box[1][3]), fmaxf(s_box[2][3], s_box[3][3]));
+    const float h1 = fmaxf(fmaxf(s_box[0][4], s_box[1][4]), fmaxf(s_box[2][4], s_box[3][4]));
+    const float h2 = fmaxf(fmaxf(s_box[0][5], s_box[1][5]), fmaxf(s_box[2][5], s_box[3][5]));
+    const double cx = 0.5 * ((double)l0 + h0), cy = 0.5 * ((double)l1 + h1), cz = 0.5 * ((double)l2 + h2);
+    const double ex = (double)h0 - l0, ey = (double)h1 - l1, ez = (double)h2 - l2;
+    const double r = 0.5 * sqrt(ex * ex + ey * ey + ez * ez) * (1.0 + 1e-9);
+    const double cnorm = fabs(cx) + fabs(cy) + fabs(cz);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int v0 = 0; v0 < a.V; v0 += 256) {
+        const int mine = v0 + (int)threadIdx.x;
+        // an empty box (no finite coordinate at all: NaN centre) compares false everywhere -> every view is kept
+        const bool keep = mine < a.V && sphere_may_project(planes + (size_t)mine * PLANE_STRIDE, cx, cy, cz, r, cnorm);
+        const unsigned long long b = __ballot(keep);
+        const int word = (v0 >> 6) + wave;
+        if (lane == 0 && word < words) masks[(size_t)blockIdx.x * words + word] = b;
+    }
+}
+
 __global__ __launch_bounds__(256) void floater_votes_kernel_cull(const FArgs a, const double *tab, const double *planes,
-                                                                 const unsigned long long *decide) {
+                                                                 const unsigned long long *decide, const unsigned long long *masks,
+                                                                 const int words) {
     if (decide && !cull_chosen(decide)) return;
     __shared__ float s_box[4][6];
     __shared__ unsigned short s_views[256];
@@ -441,10 +490,20 @@ __global__ __launch_bounds__(256) void floater_votes_kernel_cull(const FArgs a, 
     double cx, cy, cz, r, cnorm;
     tile_sphere(fx, fy, fz, s_box, cx, cy, cz, r, cnorm);
     int votes = (live && a.accumulate) ? a.votes[i] : 0;
+    const unsigned long long *my_masks = masks ? masks + (size_t)(blockIdx.x / SUPER) * words : nullptr;
     for (int v0 = 0; v0 < a.V; v0 += 256) {
+        // level 1: the views this workgroup's super-tile can see at all (wave-uniform words -> scalar loads)
+        unsigned long long m = ~0ull;
+        if (my_masks) {
+            const int w0 = v0 >> 6;
+            const unsigned long long m0 = my_masks[w0], m1 = w0 + 1 < words ? my_masks[w0 + 1] : 0ull;
+            const unsigned long long m2 = w0 + 2 < words ? my_masks[w0 + 2] : 0ull, m3 = w0 + 3 < words ? my_masks[w0 + 3] : 0ull;
+            if ((m0 | m1 | m2 | m3) == 0ull) continue;       // the same words for the whole workgroup: nobody reaches a barrier
+            m = wave == 0 ? m0 : wave == 1 ? m1 : wave == 2 ? m2 : m3;
+        }
         // phase A: one lane per view of this chunk decides whether the workgroup can see it at all
         const int mine = v0 + (int)threadIdx.x;
-        const bool keep = mine < a.V && sphere_may_project(planes + (size_t)mine * PLANE_STRIDE, cx, cy, cz, r, cnorm);
+        const bool keep = mine < a.V && ((m >> lane) & 1ull) && sphere_may_project(planes + (size_t)mine * PLANE_STRIDE, cx, cy, cz, r, cnorm);
         const unsigned long long b = __ballot(keep);
         if (keep) s_views[wave * 64 + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)threadIdx.x;
         if (lane == 0) s_cnt[wave] = __popcll(b);
@@ -975,7 +1034,10 @@ int64_t dd_votes_workspace_bytes(int32_t num_views, int64_t n_points) {
     double q = 0.03 * (double)n_points * (double)num_views * 8.0;
     if (q < 8.0 * 1048576) q = 8.0 * 1048576;
     if (q > 256.0 * 1048576) q = 256.0 * 1048576;
-    return fixed + bitmap + ((int64_t)q & ~(int64_t)15);
+    const int64_t first_pass = fixed + bitmap + ((int64_t)q & ~(int64_t)15);
+    // modes 3 / 4: two 256-byte tables per view, the decision counters, one mask of V bits per 65 536 points
+    const int64_t cull = (int64_t)num_views * 512 + 64 + ((blocks + SUPER - 1) / SUPER) * (int64_t)((num_views + 63) / 64) * 8;
+    return first_pass > cull ? first_pass : cull;
 }
 
 int dd_floater_votes(const DDFilterViews *views, const float *xyz, const float *normal, int64_t n,
@@ -1044,6 +1106,11 @@ int dd_floater_votes(const DDFilterViews *views, const float *xyz, const float *
         double *tab = reinterpret_cast<double *>(views->workspace);
         double *planes = tab + (size_t)V * 32;
         unsigned long long *decide = reinterpret_cast<unsigned long long *>(planes + (size_t)V * PLANE_STRIDE);
+        // with room for them: one mask of V bits per super-tile of 65 536 points (level 1 of the cull)
+        const long long supers = (blocks + SUPER - 1) / SUPER;
+        const int words = (V + 63) / 64;
+        unsigned long long *masks = decide + 8;
+        const bool two_level = views->workspace_bytes >= (int64_t)V * 512 + 64 + supers * words * 8;
         hipLaunchKernelGGL(votes_prepare64, dim3((unsigned)((V + 63) / 64)), dim3(64), 0, s, views->cams, tab, V, views->height, views->width);
         hipLaunchKernelGGL(votes_prepare_planes, dim3((unsigned)((V + 63) / 64)), dim3(64), 0, s, views->cams, planes, V, views->height, views->width);
         if (views->mode == 4) {
@@ -1052,8 +1119,10 @@ int dd_floater_votes(const DDFilterViews *views, const float *xyz, const float *
             hipLaunchKernelGGL(votes_cull_estimate, dim3((unsigned)sample), dim3(256), 0, s, a, (const double *)planes, decide, stride);
             hipLaunchKernelGGL(floater_votes_kernel2, dim3((unsigned)blocks), dim3(256), 0, s, a, (const double *)tab, (const unsigned long long *)decide);
         } else decide = nullptr;
+        if (two_level) hipLaunchKernelGGL(votes_supertile_masks, dim3((unsigned)supers), dim3(256), 0, s, a, (const double *)planes, masks, words,
+                                          (const unsigned long long *)decide);
         hipLaunchKernelGGL(floater_votes_kernel_cull, dim3((unsigned)blocks), dim3(256), 0, s, a, (const double *)tab, (const double *)planes,
-                           (const unsigned long long *)decide);
+                           (const unsigned long long *)decide, (const unsigned long long *)(two_level ? masks : nullptr), words);
     } else if (views->mode == 1 && views->workspace && views->workspace_bytes >= (int64_t)V * 256) {
         if (((uintptr_t)views->workspace % 32) != 0) return fail("workspace must be 32-byte aligned");
         double *tab = reinterpret_cast<double *>(views->workspace);

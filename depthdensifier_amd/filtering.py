@@ -52,7 +52,7 @@ def filter_cameras(intrinsics: ArrayLike, cam_from_world: ArrayLike) -> np.ndarr
     return cams
 
 
-VOTE_MODES = {"auto": 4, "float64": 1, "float64_classic": 1, "float64_cull": 3, "float32_first": 0, "verify": 2}
+VOTE_MODES = {"auto": 4, "float64": 1, "float64_classic": 1, "float64_cull": 3, "float64_cull1": 3, "float32_first": 0, "verify": 2}
 
 
 def floater_votes(points: torch.Tensor, normals: torch.Tensor, depth: ArrayLike, intrinsics: ArrayLike,
@@ -66,6 +66,7 @@ def floater_votes(points: torch.Tensor, normals: torch.Tensor, depth: ArrayLike,
     workgroups (no host round trip): ``"float64_cull"`` skips, for each workgroup of 256 consecutive points, every view
     whose frustum the workgroup's bounding sphere cannot touch (conservative, same votes) -- several times faster when the
     views look at different parts of the scene, ~20 % slower when every view sees everything (an inward-facing ring);
+    ``"float64_cull1"`` = the same without the super-tile masks (level 1 of the cull), for A/B;
     ``"float64"`` = every decision in float64, the fastest un-culled form on MI355X (division-free image-bounds
     test first, grazing second, reciprocal only for pairs that reach the lookup; a 256-byte table per view is built in a
     scratch buffer); ``"float64_classic"`` = the round-1 kernel (projection with a reciprocal for every pair in front of
@@ -104,7 +105,9 @@ def floater_votes(points: torch.Tensor, normals: torch.Tensor, depth: ArrayLike,
     if votes is None:
         votes = torch.empty(pts.shape[0], dtype=torch.int32, device=dev)
     V, H, W = d.shape
-    ws_bytes = {"float64": 256 * V, "float64_classic": 16, "float64_cull": 512 * V + 64, "auto": 512 * V + 64}.get(mode) \
+    # culling modes: two 256-byte tables per view, the decision counters, one mask of V bits per 65 536 points (level 1)
+    cull_bytes = 512 * V + 64 + -(-pts.shape[0] // 65536) * (-(-V // 64)) * 8
+    ws_bytes = {"float64": 256 * V, "float64_classic": 16, "float64_cull": cull_bytes, "float64_cull1": 512 * V + 64, "auto": cull_bytes}.get(mode) \
         or int(lib.dd_votes_workspace_bytes(V, pts.shape[0]))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     fv = DDFilterViews(num_views=V, height=H, width=W, depth=d.data_ptr(), mask=None if m is None else m.data_ptr(),

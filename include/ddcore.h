@@ -225,7 +225,9 @@ typedef struct DDFilterViews {
                                the float32 pass is also taken in float64 and disagreements are counted (must be 0);
                                3 = float64 with per-workgroup view culling (a view is skipped for 256 consecutive points when
                                their bounding sphere cannot touch its frustum -- conservative, same votes); 4 = 1 or 3, chosen on
-                               the device from a sample of the workgroups.  3 / 4 need 512 * num_views + 64 bytes, 32-B aligned */
+                               the device from a sample of the workgroups.  3 / 4 need 512 * num_views + 64 bytes, 32-B aligned; with
+                               ceil(n / 65536) * ceil(num_views / 64) * 8 bytes more (dd_votes_workspace_bytes() covers it) the cull
+                               is two-level: a mask of visible views per 65 536 consecutive points first */
     int32_t reserved3;
 } DDFilterViews;
 

@@ -300,11 +300,11 @@ def test_view_culling_keeps_the_votes(layout):
     depth_in = np.where(np.isfinite(d["depth"]), d["depth"], 0).astype(np.float32)
     cloud = dd.unproject_views(d["depth"], d["params"], E, mask=d["mask"], normal=d["normal"])     # inf depths -> inf points
     res, stats = {}, {}
-    for mode in ("float64_classic", "float64", "float64_cull", "auto"):
+    for mode in ("float64_classic", "float64", "float64_cull", "float64_cull1", "auto"):
         st = {}
         res[mode] = dd.floater_votes(cloud.points, cloud.normals, depth_in, K, E, mask=d["mask"], mode=mode, stats=st).cpu().numpy()
         stats[mode] = st
-    for mode in ("float64", "float64_cull", "auto"):
+    for mode in ("float64", "float64_cull", "float64_cull1", "auto"):
         assert np.array_equal(res[mode], res["float64_classic"]), mode
     pts = cloud.points.cpu().numpy()
     fin = np.isfinite(pts).all(axis=1)
