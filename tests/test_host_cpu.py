@@ -178,3 +178,13 @@ def test_bench_byte_model_matches_survey_examples():
     assert b5 / P5 == 14.0
     b4 = bench.algorithmic_bytes(bench.WORKLOADS["mip360conf"], 1, int(0.425 * P), True) - 72
     assert abs(b4 / P - (9 + 0.425 * (15 + 31))) < 1e-6
+
+
+def test_votes_workspace_covers_every_mode(libmod):
+    """dd_votes_workspace_bytes() is documented to suffice for the float32 first pass AND the culling modes (two
+    256-byte tables per view, the decision counters, one mask of V bits per 65 536 points)."""
+    for V, n in ((1, 0), (1, 1), (185, 326_000_000), (2000, 3_300_000_000), (1_000_000, 10), (70_000, 5_000_000_000)):
+        need = 512 * V + 64 + -(-n // 65536) * (-(-V // 64)) * 8
+        got = libmod.lib.dd_votes_workspace_bytes(V, n)
+        assert got >= need and got % 8 == 0, (V, n, got, need)
+    assert libmod.lib.dd_votes_workspace_bytes(0, 10) < 0 and libmod.lib.dd_votes_workspace_bytes(4, -1) < 0
