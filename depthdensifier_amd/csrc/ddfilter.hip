@@ -12,6 +12,16 @@
 // (NumPy promotes everything to float64 there except `depth_threshold * depth`, a float32
 // product under NEP 50), so the votes are reproduced exactly; cheap tests run first (behind the
 // camera, outside the image) and most pairs never reach the square root.
+//
+// What is in this file (DDFilterViews.mode; every form gives the same votes, bit for bit):
+//   floater_votes_kernel            the round-1 float64 kernel (mode 1 without a workspace)
+//   floater_votes_kernel2           float64, image bounds without the division, reciprocal only before the lookup (mode 1)
+//   floater_votes_kernel_cull       kernel2's pair test behind a two-level view cull: a mask of visible views per 65 536
+//                                   points, then the workgroup's own bounding sphere (mode 3; mode 4 = default of the host
+//                                   layer: votes_cull_estimate samples the workgroups and kernel2 or the cull runs)
+//   floater_votes_kernel32 + votes_resolve + votes_redo   the float32 first pass with error bounds (modes 0 / 2; an
+//                                   experiment that measured slower -- v_fma_f64 issues as fast as v_fma_f32 on gfx950)
+//   compact_* kernels               dd_compact_cloud: stable compaction of the cloud by votes < threshold
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
