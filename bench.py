@@ -191,7 +191,7 @@ def strong_scaling_record(args, dd, D, dist, use_dist, rank, world, device, fenc
     the chunks exchanged in place while the next chunk's kernel runs (xyz + normals + colours, 27 B/point);
     "gathered_compact" = the same with one 16-byte xyz+rgba record per point."""
     cfg = dict(WORKLOADS["scene2000"])
-    cfg["mask_kind"] = "blob"
+    cfg["mask_kind"] = args.mask_kind          # blob (default) or the per-pixel Bernoulli cull of SURVEY.md 8d config 3
     V_total = args.strong_views
     lo, hi = D.shard_views(V_total, world, rank)
     H, W = cfg["H"], cfg["W"]
@@ -204,6 +204,7 @@ def strong_scaling_record(args, dd, D, dist, use_dist, rank, world, device, fenc
     torch.cuda.synchronize(device)
     t_gen = time.perf_counter() - t_gen
     rec = {"views_total": V_total, "views_per_gpu": len(ids), "height": H, "width": W, "scaling": "strong", "chunks": args.chunks,
+           "mask_kind": args.mask_kind,
            "scene_generation_s": round(t_gen, 2)}
 
     def timed(fn, passes):
