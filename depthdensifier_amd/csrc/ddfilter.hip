@@ -273,15 +273,17 @@ __device__ __forceinline__ bool pair_votes2(const FArgs &a, const Cam2 &c, const
         const double len2 = dx * dx + dy * dy + dz * dz;
         const double t = -(nx * dx + ny * dy + nz * dz), g = a.grazing_cos;
         const double s = t * t, q = g * g * len2;
-        if (g > 0.0 && t <= 0.0) return false;
-        if (g > 0.0 && fabs(s - q) > 2.5e-9 * (s + q) && s < 1e300) {
-            if (!(s > q)) return false;
-        } else {
+        // one exit for the whole test (every `return` inside the view loop costs exec-mask bookkeeping on the scalar unit):
+        // decided by the squared comparison unless the two sides are within 2.5e-9 of each other or not finite
+        const bool sure = g > 0.0 && (t <= 0.0 || (fabs(s - q) > 2.5e-9 * (s + q) && s < 1e300));
+        bool pass = t > 0.0 && s > q;
+        if (!sure) {
             const double len = sqrt(len2);
             dx /= len; dy /= len; dz /= len;
             const double facing = nx * -dx + ny * -dy + nz * -dz;
-            if (!(facing > a.grazing_cos)) return false;
+            pass = facing > a.grazing_cos;
         }
+        if (!pass) return false;
     }
     if (!exact) {
         double rden = __builtin_amdgcn_rcp(den);
@@ -321,13 +323,18 @@ __global__ __launch_bounds__(256) void floater_votes_kernel2(const FArgs a, cons
         c.zr = p[2]; c.m0 = p[6]; c.m1 = p[7];
         c.rest = (cam_double *)(tab + (size_t)v * 32);
     };
-    Cam2 cur, nxt;
-    fetch(0, cur);
-    for (int v = 0; v < a.V; ++v) {
-        fetch(v + 1 < a.V ? v + 1 : v, nxt);
-        votes += pair_votes2(a, cur, v, x, y, z, nx, ny, nz, S, wlim, hlim) ? 1 : 0;
-        cur = nxt;
+    // two views per trip with the two register sets taking turns: `cur = nxt` cost twelve s_mov_b64 per view, and the
+    // scalar unit (one per CU) was issuing as many instructions as the vector units (profiles/r02_pmc_votes.json)
+    Cam2 ca, cb;
+    fetch(0, ca);
+    int v = 0;
+    for (; v + 1 < a.V; v += 2) {
+        fetch(v + 1, cb);
+        votes += pair_votes2(a, ca, v, x, y, z, nx, ny, nz, S, wlim, hlim) ? 1 : 0;
+        fetch(v + 2 < a.V ? v + 2 : v + 1, ca);
+        votes += pair_votes2(a, cb, v + 1, x, y, z, nx, ny, nz, S, wlim, hlim) ? 1 : 0;
     }
+    if (v < a.V) votes += pair_votes2(a, ca, v, x, y, z, nx, ny, nz, S, wlim, hlim) ? 1 : 0;
     a.votes[i] = votes;
 }
 
