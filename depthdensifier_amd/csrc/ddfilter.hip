@@ -303,10 +303,10 @@ __device__ __forceinline__ bool pair_votes2(const FArgs &a, const Cam2 &c, const
 }
 
 // `decide`: NULL, or two counters written by votes_cull_estimate -- [0] (workgroup, view) cells that survive the cull,
-// [1] cells tested.  The plain kernel runs when culling would remove less than 30 % of the cells, the culling kernel
+// [1] cells tested.  The plain kernel runs when culling would remove less than 10 % of the cells, the culling kernel
 // otherwise; both are launched and the one not chosen returns at once (no host round trip).
 __device__ __forceinline__ bool cull_chosen(const unsigned long long *decide) {
-    return decide[0] * 10ull < decide[1] * 7ull;
+    return decide[0] * 10ull < decide[1] * 9ull;      // the culling kernel costs 2-5 % when it removes nothing
 }
 
 __global__ __launch_bounds__(256) void floater_votes_kernel2(const FArgs a, const double *tab, const unsigned long long *decide) {
@@ -384,7 +384,9 @@ __global__ __launch_bounds__(64) void votes_prepare_planes(const double *cams, d
 __device__ __forceinline__ bool sphere_may_project(const double *o, const double cx, const double cy, const double cz,
                                                    const double r, const double cnorm) {
     bool out = false;
-#pragma unroll
+    // NOT unrolled: with the five planes' 30 doubles loaded up front the culling kernel needed 108 VGPRs (4 waves per
+    // SIMD); this test runs once per workgroup and 256 views, the pair loop that follows needs the occupancy
+#pragma unroll 1
     for (int k = 0; k < 5; ++k) {
         const double an = o[20 + k];
         const double f = o[4 * k] * cx + o[4 * k + 1] * cy + o[4 * k + 2] * cz + o[4 * k + 3];
@@ -504,8 +506,15 @@ __global__ __launch_bounds__(256) void floater_votes_kernel_cull(const FArgs a, 
     double nx = 0, ny = 0, nz = 0;
     if (live) { nx = a.normal[3 * i]; ny = a.normal[3 * i + 1]; nz = a.normal[3 * i + 2]; }
     const double S = fabs(x) + fabs(y) + fabs(z) + 1.0;
-    double cx, cy, cz, r, cnorm;
-    tile_sphere(fx, fy, fz, s_box, cx, cy, cz, r, cnorm);
+    __shared__ double s_sphere[5];
+    {
+        double cx, cy, cz, r, cnorm;
+        tile_sphere(fx, fy, fz, s_box, cx, cy, cz, r, cnorm);
+        // parked in LDS and re-read by phase A of every chunk: held in registers across the pair loop, the five
+        // (uniform) doubles cost 10 VGPRs per lane and a step of occupancy
+        if (threadIdx.x == 0) { s_sphere[0] = cx; s_sphere[1] = cy; s_sphere[2] = cz; s_sphere[3] = r; s_sphere[4] = cnorm; }
+    }
+    __syncthreads();
     int votes = (live && a.accumulate) ? a.votes[i] : 0;
     const unsigned long long *my_masks = masks ? masks + (size_t)(blockIdx.x / SUPER) * words : nullptr;
     for (int v0 = 0; v0 < a.V; v0 += 256) {
@@ -520,7 +529,8 @@ __global__ __launch_bounds__(256) void floater_votes_kernel_cull(const FArgs a, 
         }
         // phase A: one lane per view of this chunk decides whether the workgroup can see it at all
         const int mine = v0 + (int)threadIdx.x;
-        const bool keep = mine < a.V && ((m >> lane) & 1ull) && sphere_may_project(planes + (size_t)mine * PLANE_STRIDE, cx, cy, cz, r, cnorm);
+        const bool keep = mine < a.V && ((m >> lane) & 1ull) &&
+                          sphere_may_project(planes + (size_t)mine * PLANE_STRIDE, s_sphere[0], s_sphere[1], s_sphere[2], s_sphere[3], s_sphere[4]);
         const unsigned long long b = __ballot(keep);
         if (keep) s_views[wave * 64 + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)threadIdx.x;
         if (lane == 0) s_cnt[wave] = __popcll(b);

@@ -120,7 +120,7 @@ def floater_votes(points: torch.Tensor, normals: torch.Tensor, depth: ArrayLike,
     if stats is not None:
         if mode == "auto":          # the two counters of the on-device choice (workgroup x view cells that survive / were sampled)
             d_ = ws[512 * V:512 * V + 16].view(torch.int64).tolist()
-            stats.update(cull_sample_survived=int(d_[0]), cull_sample_cells=int(d_[1]), culled=bool(d_[0] * 10 < d_[1] * 7))
+            stats.update(cull_sample_survived=int(d_[0]), cull_sample_cells=int(d_[1]), culled=bool(d_[0] * 10 < d_[1] * 9))
         w = [0, 0] if mode.startswith("float64") or mode == "auto" else ws[:64 * 128].view(torch.int64).view(64, 16)[:, :2].sum(dim=0).tolist()   # 64 shards, a line each
         stats.update(pairs=int(pts.shape[0]) * V, resolved_in_float64=int(w[0]), mismatches=int(w[1]), mode=mode)
     # asynchronous: temporaries freed here are only reused by later work on the same stream
