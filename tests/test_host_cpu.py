@@ -188,3 +188,15 @@ def test_votes_workspace_covers_every_mode(libmod):
         got = libmod.lib.dd_votes_workspace_bytes(V, n)
         assert got >= need and got % 8 == 0, (V, n, got, need)
     assert libmod.lib.dd_votes_workspace_bytes(0, 10) < 0 and libmod.lib.dd_votes_workspace_bytes(4, -1) < 0
+
+
+def test_integration_md_stub_matches_the_binding(libmod):
+    """The ctypes stub shown to a reference maintainer in INTEGRATION.md declares the same fields, in the same order, as
+    the binding the package itself uses (a missing trailing field would make the library read past the struct)."""
+    text = (ROOT / "INTEGRATION.md").read_text()
+    for name, cls in (("DDViewBatch", libmod.DDViewBatch), ("DDCloudOut", libmod.DDCloudOut)):
+        body = re.search(r"class %s\(C\.Structure\):.*?_fields_ = \[(.*?)\]\s*(#.*)?\n\n" % name, text, re.S).group(1)
+        shown = re.findall(r'\("(\w+)",\s*C\.(\w+)\)', body)
+        assert [n for n, _ in shown] == [f[0] for f in cls._fields_], name
+        assert [getattr(C, t) for _, t in shown] == [f[1] for f in cls._fields_], name
+    assert "dd_abi_version() == %d" % libmod.DD_ABI_VERSION in text
