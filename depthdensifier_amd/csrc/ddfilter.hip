@@ -1074,6 +1074,7 @@ int dd_floater_votes(const DDFilterViews *views, const float *xyz, const float *
     if (views->num_views <= 0 || views->height <= 0 || views->width <= 0) return fail("num_views/height/width must be positive");
     if (!views->depth || !views->cams) return fail("depth / cams is NULL");
     if (n < 0) return fail("n is negative");
+    if (views->mode < 0 || views->mode > 4) return fail("mode must be 0 .. 4");
     if (n > 0 && (!xyz || !normal || !votes_dev)) return fail("xyz / normal / votes_dev is NULL");
     if (n == 0) return DD_OK;
     FArgs a;

@@ -331,3 +331,43 @@ def test_view_culling_keeps_the_votes(layout, normals):
     v2 = dd.floater_votes(cloud.points, cloud.normals, depth_in[:5], K[:5], E[:5], mask=d["mask"][:5], mode="float64_cull")
     v2 = dd.floater_votes(cloud.points, cloud.normals, depth_in[5:], K[5:], E[5:], mask=d["mask"][5:], votes=v2, mode="auto")
     assert np.array_equal(v2.cpu().numpy(), res["float64_classic"])
+
+
+@pytest.mark.gpu
+def test_floater_votes_argument_errors():
+    """dd_floater_votes refuses what it cannot run, with a message: an unknown mode, a culling mode without its workspace,
+    NULL pointers -- error code and dd_filter_last_error(), nothing thrown, nothing launched."""
+    import ctypes as C
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from depthdensifier_amd import _lib
+    lib = _lib.lib
+    n, V, H, W = 300, 2, 8, 8
+    pts = torch.zeros((n, 3), device="cuda"); nrm = torch.zeros((n, 3), device="cuda")
+    depth = torch.ones((V, H, W), device="cuda"); cams = torch.zeros((V, 24), dtype=torch.float64, device="cuda")
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    ws = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def call(**kw):
+        f = dict(num_views=V, height=H, width=W, depth=depth.data_ptr(), mask=None, cams=cams.data_ptr(), grazing_cos=0.087, depth_threshold=0.7,
+                 workspace=None, workspace_bytes=0, mode=1)
+        f.update(kw)
+        rc = lib.dd_floater_votes(C.byref(_lib.DDFilterViews(**f)), pts.data_ptr(), nrm.data_ptr(), n, out.data_ptr(), 0, stream)
+        return rc, lib.dd_filter_last_error().decode()
+
+    assert call()[0] == 0
+    rc, msg = call(mode=7)
+    assert rc == -1 and "mode" in msg
+    rc, msg = call(mode=4)
+    assert rc == -1 and "workspace" in msg
+    rc, msg = call(mode=3, workspace=ws.data_ptr(), workspace_bytes=100)
+    assert rc == -1 and "workspace" in msg
+    rc, msg = call(mode=3, workspace=ws.data_ptr(), workspace_bytes=ws.numel())      # 512 * 2 + 64 fit: runs (single-level cull)
+    assert rc == 0
+    rc, msg = call(cams=None)
+    assert rc == -1 and "cams" in msg
+    rc, msg = call(mode=2)
+    assert rc == -1 and "verify" in msg
+    torch.cuda.synchronize()
