@@ -206,3 +206,24 @@ def test_streamed_dense_records_equal_the_host_writer(tmp_path, form, n, chunk):
         write_dense_at(f, lay["dense_offset"] + cut * RECORD_BYTES, piece(cut, n), lay["first_dense_id"] + cut, chunk_points=chunk)
         write_dense_at(f, lay["dense_offset"], piece(0, cut), lay["first_dense_id"], chunk_points=chunk)
         assert f.read_bytes() == (tmp_path / "host" / "points3D.bin").read_bytes()
+
+
+@pytest.mark.gpu
+def test_format_points3d_argument_errors():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from depthdensifier_amd import _lib
+    lib = _lib.lib
+    xyz = torch.zeros((4, 3), device="cuda"); out = torch.zeros(4 * 51 + 64, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    base = out.data_ptr() + (-out.data_ptr()) % 16
+    assert lib.dd_format_points3d(xyz.data_ptr(), None, None, 4, 1, base, s) == 0
+    assert lib.dd_format_points3d(xyz.data_ptr(), None, None, 0, 1, None, s) == 0            # nothing to do
+    for args, word in (((None, None, None, 4, 1, base, s), "xyz"), ((xyz.data_ptr(), None, None, -1, 1, base, s), "negative"),
+                       ((xyz.data_ptr(), None, None, 4, 1, base + 4, s), "aligned"), ((xyz.data_ptr(), None, None, 4, 1, None, s), "out"),
+                       ((None, None, xyz.data_ptr() + 4, 4, 1, base, s), "aligned")):
+        assert lib.dd_format_points3d(*args) == -1 and word in lib.dd_model_last_error().decode(), word
+    torch.cuda.synchronize()
+    rec = out[base - out.data_ptr(): base - out.data_ptr() + 51].cpu().numpy()
+    assert struct.unpack("<Q3d3BdQ", rec.tobytes()) == (1, 0.0, 0.0, 0.0, 0, 0, 0, -1.0, 0)         # rgb NULL -> black
