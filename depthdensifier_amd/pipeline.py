@@ -197,24 +197,34 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
     stage = {"image_decode": 0.0, "depth_source": 0.0, "refine": 0.0, "densify": 0.0}     # host seconds per stage
     clock = time.perf_counter
 
-    def fetch(im):                                                              # host-only: safe on an I/O thread
+    def fetch(im, slot=None):                                                   # no GPU work: safe on an I/O thread
         rgb = _load_rgb(config.paths.image_dir / im.name, f)                    # :145-152
-        return rgb, source.prepare(im.name, rgb)
+        if slot is None:
+            return rgb, source.prepare(im.name, rgb), None
+        slot.wait()                                                             # the uploads of the slot's previous view are done
+        rgb = slot.put("rgb", rgb)
+        if getattr(source, "accepts_staging", False):
+            return rgb, source.prepare(im.name, rgb, staging=slot), slot
+        return rgb, source.prepare(im.name, rgb), slot
 
-    # decode / cache reads run `ahead` views in front of the GPU on a small pool; order of consumption is unchanged
+    # decode / cache reads run `ahead` views in front of the GPU on a small pool; order of consumption is unchanged.
+    # Each view in flight owns a slot of pinned staging buffers (ahead + 1 of them, round-robin): the maps are uploaded by
+    # asynchronous DMA instead of the driver's pageable copy on this thread.
     pool = ThreadPoolExecutor(max_workers=config.processing.io_threads) if config.processing.io_threads > 0 else None
     ahead = 2 * config.processing.io_threads
-    pending: deque = deque(pool.submit(fetch, im) for im in mine[:ahead]) if pool else deque()
+    from .depth_source import StagingSlot
+    slots = [StagingSlot() for _ in range(ahead + 1)] if pool else []
+    pending: deque = deque(pool.submit(fetch, im, slots[j % len(slots)]) for j, im in enumerate(mine[:ahead])) if pool else deque()
     t_loop = time.time()
     for k, image in enumerate(mine):
         pts_world = rec.xyz_of(image.observed_point3D_ids())                    # :139
         t1 = clock()
         if pool:
-            rgb, prepared = pending.popleft().result()
-            if k + ahead < len(mine):
-                pending.append(pool.submit(fetch, mine[k + ahead]))
+            rgb, prepared, slot = pending.popleft().result()
+            if k + ahead < len(mine):                                           # its slot was consumed ahead + 1 views ago
+                pending.append(pool.submit(fetch, mine[k + ahead], slots[(k + ahead) % len(slots)]))
         else:
-            rgb, prepared = fetch(image)
+            rgb, prepared, slot = fetch(image)
         new_h, new_w = rgb.shape[:2]
         t2 = clock()
         maps = source.infer(image.name, rgb, device, prepared=prepared)         # :161-168, stays on device
@@ -247,6 +257,8 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
             batch = ViewBatch(refined, camera.pinhole_params()[None], E[None], mask=maps["mask"], normal=normal, rgb=rgb,
                               stride=s, view_index_base=lo + len(cached), device=device)
         builder.append(batch)
+        if slot is not None:
+            slot.release(torch.cuda.current_stream(device))                     # every upload from the slot is enqueued by now
         cached.append(dict(depth=refined, mask=maps["mask"], K=K, E=E))         # :197-201
         t5 = clock()
         stage["image_decode"] += t2 - t1; stage["depth_source"] += t3 - t2
