@@ -15,6 +15,8 @@ without the reference's ``.cpu().numpy()`` round trip (``scripts/test.py:166-168
 
 from __future__ import annotations
 
+import os
+import threading
 from pathlib import Path
 from typing import Optional
 
@@ -29,6 +31,11 @@ class StagingSlot:
     ~30 ms -- hidden there, ruinous per view on the main thread, which round 1 tried), and kept for the views that follow.
     ``release`` is called by the consumer once the uploads are enqueued; ``wait`` by the next producer of the slot."""
 
+    # page-locked bytes all slots of the process may hold (12 MP views need 244 MB per slot); beyond it a slot falls back to
+    # ordinary memory -- still correct, the upload is then the driver's synchronous pageable copy again
+    budget = int(os.environ.get("DD_PINNED_BUDGET_MB", "4096")) << 20
+    _lock = threading.Lock()
+
     def __init__(self):
         self._bufs: dict = {}
         self._free: Optional[torch.cuda.Event] = None
@@ -37,7 +44,14 @@ class StagingSlot:
         tdt = torch.from_numpy(np.empty(0, dtype=dtype)).dtype
         t = self._bufs.get(key)
         if t is None or tuple(t.shape) != tuple(shape) or t.dtype != tdt:
-            t = torch.empty(tuple(shape), dtype=tdt, pin_memory=True)
+            need = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            with StagingSlot._lock:
+                if t is not None and t.is_pinned():
+                    StagingSlot.budget += t.numel() * t.element_size()
+                pin = StagingSlot.budget >= need
+                if pin:
+                    StagingSlot.budget -= need
+            t = torch.empty(tuple(shape), dtype=tdt, pin_memory=pin)
             self._bufs[key] = t
         return t.numpy()
 

@@ -393,3 +393,19 @@ def test_colmap_text_model(tmp_path):
     assert np.array_equal(r.cameras[1].params, b.cameras[1].params) and r.cameras[1].model_name == "PINHOLE"
     with pytest.raises(FileNotFoundError):
         Reconstruction(tmp_path)
+
+
+def test_staging_slot_falls_back_to_ordinary_memory_without_budget(monkeypatch):
+    """The pinned staging slots of the pipeline's ingest hold at most DD_PINNED_BUDGET_MB of page-locked memory; beyond it
+    a slot keeps its maps in ordinary memory (same contents, the upload is simply synchronous again)."""
+    import torch
+    from depthdensifier_amd.depth_source import StagingSlot
+    monkeypatch.setattr(StagingSlot, "budget", 0)
+    s = StagingSlot()
+    a = s.put("depth", np.arange(12, dtype=np.float16).reshape(3, 4))
+    assert a.dtype == np.float16 and a[2, 3] == 11 and not torch.from_numpy(a).is_pinned()
+    m = s.put("mask", np.array([[True, False]]))
+    assert m.dtype == np.bool_ and m.tolist() == [[True, False]]
+    again = s.put("depth", np.zeros((3, 4), np.float16))
+    assert again.ctypes.data == a.ctypes.data                   # same buffer reused for the next view of that shape
+    s.wait()                                                     # nothing pending: returns at once
