@@ -200,3 +200,29 @@ def test_integration_md_stub_matches_the_binding(libmod):
         assert [n for n, _ in shown] == [f[0] for f in cls._fields_], name
         assert [getattr(C, t) for _, t in shown] == [f[1] for f in cls._fields_], name
     assert "dd_abi_version() == %d" % libmod.DD_ABI_VERSION in text
+
+
+def test_bench_byte_model_matches_the_survey():
+    """bench.py's algorithmic bytes are SURVEY.md 8(d)'s: config 3 (f32 depth + u8 mask + normals + rgb, rho = 0.8) is
+    17 B read + 21.6 B written = 38.6 B/px, config 5 (f16 depth in, xyz out, dense) 2 + 12 = 14 B/px (+ 72 B per view);
+    whole scenes are dealt to the ranks largest first."""
+    import bench
+    P = 1080 * 1920
+    V, rho = 10, 0.8
+    n = int(rho * V * P)
+    cfg = dict(bench.WORKLOADS["scene2000"])
+    total = bench.algorithmic_bytes(cfg, V, n, pixel_index=False)
+    reads = bench.algorithmic_bytes(cfg, V, n, pixel_index=False, reads_only=True)
+    assert abs(total / (V * P) - 38.6) < 1e-3 and abs(reads / (V * P) - 17.0) < 1e-3
+    assert bench.algorithmic_bytes(cfg, V, n, pixel_index=True) - total == 4 * n
+    cfg5 = dict(bench.WORKLOADS["roofline12mp"])
+    P5 = cfg5["H"] * cfg5["W"]
+    assert bench.algorithmic_bytes(cfg5, 3, 3 * P5, pixel_index=False) == 3 * P5 * 14 + 3 * 72
+    conf = dict(bench.WORKLOADS["mip360conf"])
+    assert bench.algorithmic_bytes(conf, 1, 0, pixel_index=False) == P * 9 + 72          # depth + mask + f32 confidence
+    sizes = [v for _, v in bench.WORKLOADS["mip360x7"]["scenes"]]
+    assert sum(sizes) == bench.WORKLOADS["mip360x7"]["V"] == 1626
+    for world in (1, 2, 3, 7, 8):
+        owner = bench.deal_scenes(sizes, world)
+        load = [sum(s for s, o in zip(sizes, owner) if o == r) for r in range(world)]
+        assert sorted(set(owner)) == list(range(min(world, len(sizes)))) and max(load) - min(l for l in load if l) <= max(sizes)
