@@ -105,7 +105,10 @@ class CachedSource(DepthSource):
             raise FileNotFoundError(f"depth cache directory not found: {self.dir}")
 
     def prepare(self, image_name, rgb_u8, staging=None):
-        stem = Path(image_name).stem
+        # COLMAP image names may carry sub-folders ("cam1/0001.jpg"): a cache laid out the same way wins, so that two
+        # cameras' "0001" do not collide; otherwise the flat <stem> files
+        nested, flat = str(Path(image_name).with_suffix("")), Path(image_name).stem
+        stem = nested if nested != flat and any((self.dir / (nested + ext)).exists() for ext in (".npz", "_depth.npy")) else flat
         f = self.dir / (stem + ".npz")
         keep = (lambda k, a: staging.put(k, a)) if staging is not None else (lambda k, a: np.asarray(a))
         if f.exists():

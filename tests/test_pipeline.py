@@ -409,3 +409,19 @@ def test_staging_slot_falls_back_to_ordinary_memory_without_budget(monkeypatch):
     again = s.put("depth", np.zeros((3, 4), np.float16))
     assert again.ctypes.data == a.ctypes.data                   # same buffer reused for the next view of that shape
     s.wait()                                                     # nothing pending: returns at once
+
+
+def test_cached_source_prefers_a_nested_layout(tmp_path):
+    """Image names with sub-folders: ``<cache>/cam1/0001_depth.npy`` is used for ``cam1/0001.jpg`` when it exists (two
+    cameras' 0001 must not collide); without it the flat ``<cache>/0001_depth.npy`` is read as before."""
+    from depthdensifier_amd.depth_source import CachedSource
+    rgb = np.zeros((2, 3, 3), np.uint8)
+    (tmp_path / "cam1").mkdir()
+    np.save(tmp_path / "0001_depth.npy", np.full((2, 3), 1.0, np.float32))
+    np.save(tmp_path / "cam1" / "0001_depth.npy", np.full((2, 3), 7.0, np.float32))
+    src = CachedSource(tmp_path)
+    assert src.prepare("cam1/0001.jpg", rgb)["depth"][0, 0] == 7.0
+    assert src.prepare("cam2/0001.jpg", rgb)["depth"][0, 0] == 1.0
+    assert src.prepare("0001.jpg", rgb)["depth"][0, 0] == 1.0
+    with pytest.raises(FileNotFoundError):
+        src.prepare("cam1/0002.jpg", rgb)
