@@ -173,7 +173,7 @@ class DepthRefiner:
         out[~mask] = 0
         return out
 
-    def _fit_hip(self, depth: torch.Tensor, points3D: ArrayLike, cam_from_world: ArrayLike, K: ArrayLike):
+    def _fit_hip(self, depth: torch.Tensor, points3D: ArrayLike, cam_from_world: ArrayLike, K: ArrayLike, also: Optional[torch.Tensor] = None):
         """The correspondence half (``depth_refiner.py:244-299``) as ONE kernel launch + one small device->host read
         (``dd_refine_fit``, ``csrc/ddrefine.hip``) instead of ~25 tensor launches and several synchronisations.
         Returns ``(z_mono, z_metric, in_bounds, positive, kept, removed, scale)``.  In the reference's FP16 mode
@@ -197,8 +197,12 @@ class DepthRefiner:
                                torch.cuda.current_stream(self.device).cuda_stream)
         if rc < 0:
             raise DDCoreError(rc, lib.dd_refine_last_error().decode())
-        inb, pos, kept, removed, scale_bits = meta[:5].tolist()                 # the one synchronisation of the fit
+        if also is not None:                     # a count the caller needs on the host as well rides along in the same read
+            meta[5] = also.to(torch.int32)
+        inb, pos, kept, removed, scale_bits, extra = meta[:6].tolist()          # the one synchronisation of the fit
         scale = float(np.array([scale_bits], dtype=np.int32).view(np.float32)[0])
+        if also is not None:
+            return buf[0][:kept], buf[1][:kept], inb, pos, kept, removed, scale, extra
         return buf[0][:kept], buf[1][:kept], inb, pos, kept, removed, scale
 
     # ---- API --------------------------------------------------------------------------
@@ -226,7 +230,9 @@ class DepthRefiner:
 
         if depth.is_cuda and depth.dim() == 2 and min(depth.shape) >= 2:
             # GPU: the whole correspondence half is one hand-written kernel
-            z_mono, z_metric, inb, pos, kept, removed, scale = self._fit_hip(depth, points3D, cam_from_world, K)
+            # (the number of masked pixels, needed below to choose the apply path, is read in the fit's own synchronisation)
+            z_mono, z_metric, inb, pos, kept, removed, scale, n_masked = self._fit_hip(depth, points3D, cam_from_world, K,
+                                                                                    also=m.sum().clamp(max=2 ** 31 - 1))
             if inb == 0:
                 return unchanged(0, "No valid correspondences found")
             if pos == 0:
@@ -236,16 +242,18 @@ class DepthRefiner:
             if self.adaptive_correspondences and kept > 500:
                 pick = torch.randperm(kept, device=self.device, generator=generator)[:500]
                 z_mono, z_metric = z_mono[pick], z_metric[pick]
-                scale = float(torch.median(z_metric / (z_mono + 1e-6)).cpu())
+                scale = torch.median(z_metric / (z_mono + 1e-6))               # stays on the device unless somebody asks (below)
             n_corr = int(z_mono.numel())
             if fit_only:
                 # hand the curve out instead of applying it: the densify kernel refines on the fly (ViewBatch(refine=...)).
                 # Only where dd_refine_apply would have been taken (>= 4 masked pixels, see _apply_curve) and the curve fits
                 # the kernel's LDS table; otherwise the caller gets the refined map as usual.
-                if 2 <= n_corr <= 512 and int(m.sum().item()) >= 4:
+                if 2 <= n_corr <= 512 and n_masked >= 4:
                     kx, ky = self._sorted_knots(z_mono, z_metric)
+                    # scale_factor: a float, or (adaptive subsample) a 0-dim device tensor -- no second synchronisation here
                     return {"refined_depth": None, "curve": (kx, ky, bool(self.skip_smoothing)), "raw_depth": depth,
                             "num_correspondences": n_corr, "outliers_removed": removed, "scale_factor": scale}
+            scale = float(scale)
             refined = self._apply_curve(depth, m, z_mono, z_metric)
             if self.verbose > 0:
                 print(f"[DepthRefiner] Refined using {n_corr} correspondences")

@@ -46,6 +46,14 @@ class MoGeConfig:
     """Directory of precomputed <image stem>.npz maps (depth, mask, normal); used instead of MoGe."""
 
 
+def _default_io_threads() -> int:
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:                      # not on Linux
+        cores = os.cpu_count() or 4
+    return max(2, min(16, cores - 2))
+
+
 @dataclass
 class ProcessingConfig:
     """Parameters for processing and densification."""
@@ -53,8 +61,9 @@ class ProcessingConfig:
     """Factor to downsample images before processing. Larger is faster."""
     downsample_density: int = 32
     """Controls final point cloud density (1=densest)."""
-    io_threads: int = 8
-    """Host threads that decode images / read cached maps ahead of the GPU (0 = inline, like the reference)."""
+    io_threads: int = field(default_factory=lambda: _default_io_threads())
+    """Host threads that decode images / read cached maps ahead of the GPU (0 = inline, like the reference).  Default: the
+    cores this process may use minus two, between 2 and 16 -- image decoding is what bounds a scan once the maps are cached."""
     shard_views: bool = True
     """Under torchrun (one process per GPU): shard this scan's views over the ranks.  The batch driver turns it
     off because it shards by scan."""
