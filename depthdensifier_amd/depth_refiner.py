@@ -173,37 +173,59 @@ class DepthRefiner:
         out[~mask] = 0
         return out
 
-    def _fit_hip(self, depth: torch.Tensor, points3D: ArrayLike, cam_from_world: ArrayLike, K: ArrayLike, also: Optional[torch.Tensor] = None):
-        """The correspondence half (``depth_refiner.py:244-299``) as ONE kernel launch + one small device->host read
-        (``dd_refine_fit``, ``csrc/ddrefine.hip``) instead of ~25 tensor launches and several synchronisations.
-        Returns ``(z_mono, z_metric, in_bounds, positive, kept, removed, scale)``.  In the reference's FP16 mode
-        (``:85-86``) the inputs and the correspondences are quantised to half like there; the arithmetic in between is
-        float32 (no golden exists for that mode, and this is at least as close to the FP32 result)."""
+    def _fit_launch(self, depth: torch.Tensor, points3D: ArrayLike, cam_from_world: ArrayLike, K: ArrayLike, also: Optional[torch.Tensor] = None):
+        """The correspondence half (``depth_refiner.py:244-299``) as ONE kernel launch (``dd_refine_fit``,
+        ``csrc/ddrefine.hip``) instead of ~25 tensor launches and several synchronisations; the eight result words are
+        copied to page-locked host memory asynchronously and an event marks them ready, so the caller may enqueue other
+        work (the next view's uploads and fit) before ``_fit_finish`` reads them.  In the reference's FP16 mode (``:85-86``)
+        the inputs and the correspondences are quantised to half like there; the arithmetic in between is float32 (no
+        golden exists for that mode, and this is at least as close to the FP32 result).  ``also``: a device count the caller
+        wants on the host as well; it rides along in the same read."""
         import ctypes as C
         from ._lib import DD_F16, DD_F32, DDCoreError, lib
         half = self.dtype == torch.float16
         q = (lambda a: np.asarray(a, dtype=np.float64).astype(np.float16).astype(np.float32)) if half else (lambda a: np.asarray(a, dtype=np.float32))
         E = q(cam_from_world.cpu().numpy() if isinstance(cam_from_world, torch.Tensor) else cam_from_world)[:3, :4].reshape(-1)
         Kq = q(K.cpu().numpy() if isinstance(K, torch.Tensor) else K)[:2, :3].reshape(-1)
-        pts = (torch.from_numpy(np.ascontiguousarray(points3D, dtype=np.float32)) if isinstance(points3D, np.ndarray) else points3D.float()).to(self.device).contiguous()
+        if isinstance(points3D, np.ndarray):
+            from .densify import upload_small
+            pts = upload_small(np.ascontiguousarray(points3D, dtype=np.float32).reshape(-1, 3), self.device)   # no host wait
+        else:
+            pts = points3D.float().to(self.device).contiguous()
         n = int(pts.shape[0])
         buf = torch.empty((3, max(n, 1)), dtype=torch.float32, device=self.device)
         meta = torch.zeros(8, dtype=torch.int32, device=self.device)
         d = depth.contiguous()
+        stream = torch.cuda.current_stream(self.device)
         rc = lib.dd_refine_fit(pts.data_ptr(), n, (C.c_float * 12)(*E.tolist()), (C.c_float * 6)(*Kq.tolist()), d.data_ptr(),
                                DD_F16 if d.dtype == torch.float16 else DD_F32, d.shape[0], d.shape[1], int(self.edge_margin),
                                1 if self.robust else 0, float(self.outlier_threshold), 1 if half else 0,
-                               buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), meta.data_ptr(),
-                               torch.cuda.current_stream(self.device).cuda_stream)
+                               buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), meta.data_ptr(), stream.cuda_stream)
         if rc < 0:
             raise DDCoreError(rc, lib.dd_refine_last_error().decode())
-        if also is not None:                     # a count the caller needs on the host as well rides along in the same read
-            meta[5] = also.to(torch.int32)
-        inb, pos, kept, removed, scale_bits, extra = meta[:6].tolist()          # the one synchronisation of the fit
-        scale = float(np.array([scale_bits], dtype=np.int32).view(np.float32)[0])
         if also is not None:
-            return buf[0][:kept], buf[1][:kept], inb, pos, kept, removed, scale, extra
-        return buf[0][:kept], buf[1][:kept], inb, pos, kept, removed, scale
+            meta[5] = also.to(torch.int32)
+        if not hasattr(self, "_meta_slots"):
+            self._meta_slots = [torch.empty(8, dtype=torch.int32, pin_memory=True) for _ in range(8)]
+            self._meta_next = 0
+        host = self._meta_slots[self._meta_next % len(self._meta_slots)]      # a few page-locked result slots, round-robin
+        self._meta_next += 1
+        host.copy_(meta, non_blocking=True)
+        ready = torch.cuda.Event()
+        ready.record(stream)
+        return {"buf": buf, "meta": meta, "host": host, "ready": ready, "keep": (pts, d)}
+
+    def _fit_finish(self, fit: dict):
+        """``(z_mono, z_metric, in_bounds, positive, kept, removed, scale, extra)``: the one synchronisation of the fit."""
+        fit["ready"].synchronize()
+        inb, pos, kept, removed, scale_bits, extra = fit["host"][:6].tolist()
+        scale = float(np.array([scale_bits], dtype=np.int32).view(np.float32)[0])
+        buf = fit["buf"]
+        return buf[0][:kept], buf[1][:kept], inb, pos, kept, removed, scale, extra
+
+    def _fit_hip(self, depth: torch.Tensor, points3D: ArrayLike, cam_from_world: ArrayLike, K: ArrayLike):
+        """Launch + finish in one go: ``(z_mono, z_metric, in_bounds, positive, kept, removed, scale)``."""
+        return self._fit_finish(self._fit_launch(depth, points3D, cam_from_world, K))[:7]
 
     # ---- API --------------------------------------------------------------------------
     def refine_depth(self, depth_map: ArrayLike, normal_map: Optional[ArrayLike], points3D: ArrayLike,
@@ -216,23 +238,45 @@ class DepthRefiner:
         ``fit_only=True`` (GPU) stops after the correspondence fit and returns ``curve = (knots_x, knots_y,
         skip_smoothing)`` with ``refined_depth = None`` when the curve can be applied inside the densify kernel
         (``ViewBatch(refine=...)``; ``raw_depth`` is the map in the refiner's working precision, which is what the curve
-        must be applied to) -- early exits and unusual curves still return a map."""
+        must be applied to) -- early exits and unusual curves still return a map.
+
+        ``begin_refine`` + ``finish_refine`` are the two halves of this call: on a GPU the first only ENQUEUES the
+        correspondence fit, so a caller that streams views can start the next view before it asks for this one's result."""
+        return self.finish_refine(self.begin_refine(depth_map, normal_map, points3D, cam_from_world, K, mask=mask,
+                                                    return_tensor=return_tensor, generator=generator, fit_only=fit_only, **kwargs))
+
+    def begin_refine(self, depth_map: ArrayLike, normal_map: Optional[ArrayLike], points3D: ArrayLike,
+                     cam_from_world: ArrayLike, K: ArrayLike, mask: Optional[ArrayLike] = None,
+                     return_tensor: bool = False, generator: Optional[torch.Generator] = None, fit_only: bool = False,
+                     **kwargs) -> dict:
+        """First half of ``refine_depth``: inputs to the device and, on a GPU, the correspondence fit enqueued (no host
+        synchronisation).  Returns the handle ``finish_refine`` takes."""
         if self.verbose > 1:
             print(f"[DepthRefiner] Input depth shape: {tuple(depth_map.shape)}")
             print(f"[DepthRefiner] COLMAP points: {len(points3D)}")
         depth = self._to(depth_map)
         m = self._to(mask, torch.bool) if mask is not None else depth > 0
+        h = dict(depth_map=depth_map, depth=depth, m=m, points3D=points3D, cam_from_world=cam_from_world, K=K,
+                 return_tensor=return_tensor, generator=generator, fit_only=fit_only)
+        if depth.is_cuda and depth.dim() == 2 and min(depth.shape) >= 2:
+            # GPU: the whole correspondence half is one hand-written kernel (the number of masked pixels, needed later to
+            # choose the apply path, is read in the fit's own synchronisation)
+            h["fit"] = self._fit_launch(depth, points3D, cam_from_world, K, also=m.sum().clamp(max=2 ** 31 - 1))
+        return h
+
+    def finish_refine(self, h: dict) -> dict[str, Any]:
+        """Second half of ``refine_depth``: waits for the fit (GPU) and produces the result dictionary."""
+        depth_map, depth, m = h["depth_map"], h["depth"], h["m"]
+        points3D, cam_from_world, K = h["points3D"], h["cam_from_world"], h["K"]
+        return_tensor, generator, fit_only = h["return_tensor"], h["generator"], h["fit_only"]
 
         def unchanged(n, why):
             if self.verbose > 0:
                 print(f"[DepthRefiner] {why}")
             return {"refined_depth": depth_map, "num_correspondences": n, "scale_factor": 1.0}
 
-        if depth.is_cuda and depth.dim() == 2 and min(depth.shape) >= 2:
-            # GPU: the whole correspondence half is one hand-written kernel
-            # (the number of masked pixels, needed below to choose the apply path, is read in the fit's own synchronisation)
-            z_mono, z_metric, inb, pos, kept, removed, scale, n_masked = self._fit_hip(depth, points3D, cam_from_world, K,
-                                                                                    also=m.sum().clamp(max=2 ** 31 - 1))
+        if "fit" in h:
+            z_mono, z_metric, inb, pos, kept, removed, scale, n_masked = self._fit_finish(h["fit"])
             if inb == 0:
                 return unchanged(0, "No valid correspondences found")
             if pos == 0:

@@ -222,15 +222,17 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
     pool = ThreadPoolExecutor(max_workers=config.processing.io_threads) if config.processing.io_threads > 0 else None
     ahead = 2 * config.processing.io_threads
     from .depth_source import StagingSlot
-    slots = [StagingSlot() for _ in range(ahead + 1)] if pool else []
+    slots = [StagingSlot() for _ in range(ahead + 2)] if pool else []
     pending: deque = deque(pool.submit(fetch, im, slots[j % len(slots)]) for j, im in enumerate(mine[:ahead])) if pool else deque()
     t_loop = time.time()
-    for k, image in enumerate(mine):
+
+    def begin(k, image) -> dict:
+        """Everything of a view up to the ENQUEUED correspondence fit: nothing here waits for the GPU."""
         pts_world = rec.xyz_of(image.observed_point3D_ids())                    # :139
         t1 = clock()
         if pool:
             rgb, prepared, slot = pending.popleft().result()
-            if k + ahead < len(mine):                                           # its slot was consumed ahead + 1 views ago
+            if k + ahead < len(mine):                                           # its slot was released two views ago at the latest
                 pending.append(pool.submit(fetch, mine[k + ahead], slots[(k + ahead) % len(slots)]))
         else:
             rgb, prepared, slot = fetch(image)
@@ -248,30 +250,49 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
         if normal is None:
             normal = torch.zeros((new_h, new_w, 3), dtype=torch.float32, device=device)
         fuse = s == 1 and new_w <= 3071          # full density: the densify kernel applies the transfer curve itself
-        res = refiner.refine_depth(depth_map=maps["depth"], normal_map=normal, points3D=pts_world, cam_from_world=E, K=K,
-                                   mask=maps["mask"], return_tensor=True, fit_only=fuse)   # :179-186
+        handle = refiner.begin_refine(depth_map=maps["depth"], normal_map=normal, points3D=pts_world, cam_from_world=E, K=K,
+                                      mask=maps["mask"], return_tensor=True, fit_only=fuse)   # :179-186, first half
+        t4 = clock()
+        stage["image_decode"] += t2 - t1; stage["depth_source"] += t3 - t2; stage["refine"] += t4 - t3
+        # (the camera may be rescaled again by the next view before this one is finished: its intrinsics are taken now)
+        return dict(rgb=rgb, slot=slot, maps=maps, normal=normal, E=E, K=K, pinhole=camera.pinhole_params().copy(), handle=handle)
+
+    def finish(v: dict) -> None:
+        t3 = clock()
+        res = refiner.finish_refine(v["handle"])                                # the fit's result: its one synchronisation
         refined = res["refined_depth"]
+        maps, normal, E, K = v["maps"], v["normal"], v["E"], v["K"]
         t4 = clock()
         # :194 "refined_depth[~moge_mask] = 0" is the kernels' validity rule (mask AND depth > 0);
         # :203-240 densify + append
         if refined is None:
             # raw depth -> LUT + 3x3 median -> validity -> unprojection in ONE kernel; the refined map it writes on the way
             # is the filter's cache (:197-201).  Same bits as dd_refine_apply followed by the plain densify call.
-            batch = ViewBatch(res["raw_depth"], camera.pinhole_params()[None], E[None], mask=maps["mask"], normal=normal, rgb=rgb,
+            batch = ViewBatch(res["raw_depth"], v["pinhole"][None], E[None], mask=maps["mask"], normal=normal, rgb=v["rgb"],
                               stride=s, view_index_base=lo + len(cached), device=device, refine=res["curve"], refined_out=True)
             refined = batch.refined[0]
         else:
             refined = refined if isinstance(refined, torch.Tensor) else torch.as_tensor(refined, device=device)
             refined = refined.float()
-            batch = ViewBatch(refined, camera.pinhole_params()[None], E[None], mask=maps["mask"], normal=normal, rgb=rgb,
+            batch = ViewBatch(refined, v["pinhole"][None], E[None], mask=maps["mask"], normal=normal, rgb=v["rgb"],
                               stride=s, view_index_base=lo + len(cached), device=device)
         builder.append(batch)
-        if slot is not None:
-            slot.release(torch.cuda.current_stream(device))                     # every upload from the slot is enqueued by now
+        if v["slot"] is not None:
+            v["slot"].release(torch.cuda.current_stream(device))                # every upload from the slot is enqueued by now
         cached.append(dict(depth=refined, mask=maps["mask"], K=K, E=E))         # :197-201
         t5 = clock()
-        stage["image_decode"] += t2 - t1; stage["depth_source"] += t3 - t2
-        stage["refine"] += t4 - t3; stage["densify"] += t5 - t4                  # refine syncs (scale_factor), densify only enqueues
+        stage["refine"] += t4 - t3; stage["densify"] += t5 - t4
+
+    # One view of lag between the two halves: while the GPU runs view k's uploads and fit, the host starts view k + 1; by
+    # the time it asks for view k's fit the answer is there.  (With refiner messages on, no lag: the log keeps its order.)
+    lag = 0 if verbose else 1
+    inflight: deque = deque()
+    for k, image in enumerate(mine):
+        inflight.append(begin(k, image))
+        if len(inflight) > lag:
+            finish(inflight.popleft())
+    while inflight:
+        finish(inflight.popleft())
     if pool:
         pool.shutdown(wait=False, cancel_futures=True)
     say(f"-> Image processing loop finished in {time.time() - t_loop:.2f}s.")

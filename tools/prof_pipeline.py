@@ -1,0 +1,24 @@
+import sys, tempfile, time, contextlib, io, cProfile, pstats
+from pathlib import Path
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import numpy as np
+from scan_factory import make_scan
+from depthdensifier_amd import pipeline as P
+with tempfile.TemporaryDirectory() as tmp:
+    scan, _c, _t = make_scan(Path(tmp), "scan", V=48, H=1080, W=1920, seed=1)
+    npy = scan / "moge_cache_npy"; npy.mkdir()
+    for f in sorted((scan / "moge_cache").glob("*.npz")):
+        with np.load(f) as z:
+            for k in z.files: np.save(npy / f"{f.stem}_{k}.npy", z[k])
+    cfg = P.ScriptConfig()
+    cfg.paths = P.PathsConfig(recon_path=scan / "sparse" / "0", image_dir=scan / "images", output_model_dir=Path(tmp) / "out")
+    cfg.moge.cache_dir = npy
+    with contextlib.redirect_stdout(io.StringIO()):
+        P.main(cfg)
+    pr = cProfile.Profile()
+    with contextlib.redirect_stdout(io.StringIO()):
+        pr.enable(); r = P.main(cfg); pr.disable()
+    print({k: round(v, 3) for k, v in r["timings"].items()})
+    st = pstats.Stats(pr); st.sort_stats("cumulative"); st.print_stats(45)
+    st.print_callers("method 'to' of")
+    st.print_callers("synchronize")
