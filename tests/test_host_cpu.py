@@ -226,3 +226,27 @@ def test_bench_byte_model_matches_the_survey():
         owner = bench.deal_scenes(sizes, world)
         load = [sum(s for s, o in zip(sizes, owner) if o == r) for r in range(world)]
         assert sorted(set(owner)) == list(range(min(world, len(sizes)))) and max(load) - min(l for l in load if l) <= max(sizes)
+
+
+def test_csrc_makefile_builds_a_loadable_library(libmod, tmp_path):
+    """`make -C depthdensifier_amd/csrc` is a documented build path (_lib.py): it must compile the same
+    sources with the same flags as __graft_entry__.build() and its result must export every symbol the binding resolves."""
+    import shutil
+    import subprocess
+    import __graft_entry__ as g
+    mk = (ROOT / "depthdensifier_amd" / "csrc" / "Makefile").read_text()
+    srcs = re.search(r"^SRCS\s*:=\s*(.+)$", mk, re.M).group(1).split()
+    assert sorted(srcs) == sorted(p.name for p in g.HIP_SOURCES)
+    for name, flags in g.EXTRA_FLAGS.items():
+        assert re.search(rf"{Path(name).stem}\.o: EXTRA := {' '.join(flags)}", mk), name
+    assert "-ldl" in mk and "ddrefine_math.h" in mk
+    if shutil.which("hipcc") is None or shutil.which("make") is None:
+        pytest.skip("hipcc / make not on PATH")
+    out = tmp_path / "libddcore.so"
+    subprocess.run(["make", "-j5", "-C", str(ROOT / "depthdensifier_amd" / "csrc"), f"OUT={out}", f"OBJDIR={tmp_path / 'obj'}"],
+                   check=True, capture_output=True, timeout=600)
+    handle = C.CDLL(str(out))
+    for sym in libmod.EXPORTS:
+        assert getattr(handle, sym) is not None
+    handle.dd_abi_version.restype = C.c_int
+    assert handle.dd_abi_version() == libmod.DD_ABI_VERSION
