@@ -17,7 +17,7 @@
 // consecutive rows of the (N,3) outputs at their final position.  The tile's first row comes either
 //   * from a ticket + decoupled look-back over 8-byte {status,value} granules (relaxed agent-scope
 //     atomics; the granule is the whole payload, so no fence) -- dd_unproject_compact on aligned
-//     stride-1 maps: 8192-pixel tiles, a 16-granule window (polling loads cross XCDs, so few of them),
+//     stride-1 maps: 12288-pixel tiles (12 waves), a 16-granule window (polling loads cross XCDs, so few of them),
 //     and the other waves issue their first gathers while wave 0 looks back; or
 //   * from a counting pass + two small scans (dd_plan), after which the scatter pass (dd_scatter) has
 //     no inter-workgroup dependency at all -- the exact-allocation API and the generic path.
@@ -394,7 +394,7 @@ template <> __device__ __forceinline__ float raw_depth<_Float16>(const uint4 &d,
 }
 
 // element-aligned (not vector-aligned) wide loads: a view of H*W pixels starts wherever the previous one ended, and
-// gfx950 serves dword- / byte-aligned dwordx4 accesses in hardware (tools/ubench.hip: -25 % at worst on a pure
+// gfx950 serves dword- / byte-aligned dwordx4 accesses in hardware (tools/experiments/ubench.hip: -25 % at worst on a pure
 // store stream; nothing measurable on aligned addresses, where the instruction is the same)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -788,7 +788,7 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
     // Which listed point a lane handles in sweep i.  Sweep 0 takes the tile's first BT points as they come (its
     // gathers are issued before the tile's first row is known).  From sweep 1 on the points are shifted by `hrot`
     // rows so that every wave's run of 64 rows starts on a 128-byte line of the (N,3) float32 outputs (32 rows = 3
-    // lines): a wave's store instruction then covers 6 whole lines instead of touching 7 (tools/ubench_tile.hip:
+    // lines): a wave's store instruction then covers 6 whole lines instead of touching 7 (tools/experiments/ubench_tile.hip:
     // 5.5 vs 4.8 TB/s of row stores).  The hrot points skipped behind sweep 0 are taken by the lanes that the
     // shift pushes past the end of the list.
     int hrot = 0;
@@ -1152,7 +1152,7 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
     if (b->tuning & TUNE_FORCE_GENERIC) aligned = false;
     p.lean = aligned;
     // fused call: single-pass on the lean path (measured 8-23 % faster than plan + scatter on MI355X with
-    // 8192-pixel tiles and a 16-granule look-back window), two-pass on the generic path
+    // 12288-pixel tiles and a 16-granule look-back window), two-pass on the generic path
     p.single = (b->tuning & TUNE_SINGLE_PASS) != 0 || (p.lean && !(b->tuning & TUNE_TWO_PASS));
     a.sp_static = (b->tuning & 16u) != 0;   // diagnostic only: relies on in-order dispatch
     a.align_runs = (b->tuning & 32u) == 0;  // tuning bit 32: rows in list order (A/B of the line-aligned sweeps)
@@ -1343,7 +1343,7 @@ int dd_unproject_compact(const DDViewBatch *batch, const DDCloudOut *out, int64_
     a.cursor = reinterpret_cast<const long long *>(cursor_dev);
 
     if (p.single) {
-        if (p.lean) {   // the single-pass lean kernel works on 8192-pixel tiles
+        if (p.lean) {   // the single-pass lean kernel works on SP_WAVES * 1024 = 12288-pixel tiles
             a.tiles_per_view = (a.P + SP_WAVES * L_WSPAN - 1) / (SP_WAVES * L_WSPAN);
             a.num_tiles = a.tiles_per_view * (unsigned)a.V;
         }

@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256) void floater_votes_kernel_cull(const FArgs a, 
 // Float32 first pass with rigorous error bounds (default when the caller provides DDFilterViews.workspace).
 //
 // The float64 kernel above is VALU-bound (~75 instructions per wave and view).  NOTE (measured after this pass was
-// built, tools/ubench_fma.hip): on gfx950 v_fma_f64 issues at 0.88x the rate of a scalar-per-lane v_fma_f32 -- only the
+// built, tools/experiments/ubench_fma.hip): on gfx950 v_fma_f64 issues at 0.88x the rate of a scalar-per-lane v_fma_f32 -- only the
 // PACKED float32 form is twice as fast -- so a float32 evaluation that needs about twice the instructions for its error
 // bounds has no arithmetic advantage to collect; that is why this pass measures slower.  Every (point, view) pair is first evaluated in float32
 // together with an upper bound of the distance between each float32 quantity and the value the float64 formulation

@@ -5,7 +5,7 @@ and time the kernel on each allocation; then the same with all tensors carved ou
 import sys
 from pathlib import Path
 import numpy as np, torch
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 import bench, depthdensifier_amd as dd
 

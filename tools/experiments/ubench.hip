@@ -1,5 +1,5 @@
 // Micro-benchmark of the memory access shapes used by the scatter kernel (GPU box only):
-//   hipcc --offload-arch=gfx950 -O3 -o ubench tools/ubench.hip && ./ubench
+//   hipcc --offload-arch=gfx950 -O3 -o ubench tools/experiments/ubench.hip && ./ubench
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

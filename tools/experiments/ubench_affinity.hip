@@ -2,7 +2,7 @@
 // when every other store shape stays near 5.6?  Hypothesis: workgroups are dealt round-robin over the 8 XCDs and
 // physical memory is interleaved over the HBM stacks in 4 KiB units, so workgroup i (XCD i % 8) writes the stack next
 // to its XCD.  Test: permute which chunk a workgroup writes.  (GPU box only.)
-//   hipcc --offload-arch=gfx950 -O3 -o tools/ubench_affinity tools/ubench_affinity.hip && tools/ubench_affinity
+//   hipcc --offload-arch=gfx950 -O3 -o tools/experiments/ubench_affinity tools/experiments/ubench_affinity.hip && tools/experiments/ubench_affinity
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

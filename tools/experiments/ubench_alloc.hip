@@ -1,6 +1,6 @@
 // Does the physical placement the driver picks for an allocation change streaming bandwidth, and does the virtual-memory
 // API (one physical handle per buffer / per 1 GiB / per 2 MiB) behave differently from hipMalloc?  (GPU box only.)
-//   hipcc --offload-arch=gfx950 -O3 -o tools/ubench_alloc tools/ubench_alloc.hip && tools/ubench_alloc
+//   hipcc --offload-arch=gfx950 -O3 -o tools/experiments/ubench_alloc tools/experiments/ubench_alloc.hip && tools/experiments/ubench_alloc
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,5 +1,5 @@
 // Issue rate of v_fma_f64 vs v_fma_f32 vs v_pk_fma_f32 on gfx950 (GPU box only):
-//   hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -o /tmp/ubench_fma tools/ubench_fma.hip && /tmp/ubench_fma
+//   hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -o /tmp/ubench_fma tools/experiments/ubench_fma.hip && /tmp/ubench_fma
 // 8 independent accumulators per lane, 4096 rounds; 256 CUs x 8 workgroups x 256 threads.  Answers whether a float32
 // first pass of the floater-vote kernel has an arithmetic advantage over float64 at all.
 #include <hip/hip_runtime.h>

@@ -1,5 +1,5 @@
 // Store-shape micro-benchmark in the scatter kernel's own launch geometry (GPU box only):
-//   hipcc --offload-arch=gfx950 -O3 -o tools/ubench_tile tools/ubench_tile.hip && tools/ubench_tile
+//   hipcc --offload-arch=gfx950 -O3 -o tools/experiments/ubench_tile tools/experiments/ubench_tile.hip && tools/experiments/ubench_tile
 // One 768-thread workgroup per tile of 12288 output rows of 12 B (2 workgroups per CU through a 72 KiB LDS
 // allocation, like compact_lean<single-pass,12 waves>), 16 iterations, every wave writes a run of 64 rows
 // (768 B) per iteration.  Question: do 16-byte aligned dwordx4 stores of the same bytes

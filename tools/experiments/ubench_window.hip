@@ -1,5 +1,5 @@
 // Does the width of the chip-wide write window matter?  (GPU box only)
-//   hipcc --offload-arch=gfx950 -O3 -o tools/ubench_window tools/ubench_window.hip && tools/ubench_window
+//   hipcc --offload-arch=gfx950 -O3 -o tools/experiments/ubench_window tools/experiments/ubench_window.hip && tools/experiments/ubench_window
 // Every workgroup of T threads writes one contiguous tile of T*R rows of 12 B as R sweeps of dwordx3 row stores;
 // `lds` bytes of dynamic LDS cap the workgroups per CU.  Rows in flight per CU = waves/CU * 64 * R: the tile kernel
 // (compact_lean<single-pass>) sits at T=768, R=16, 2 workgroups per CU.

@@ -1,11 +1,11 @@
 #!/bin/bash
 # UTCL1 (per-CU address translation cache) hit / miss counters of the densify kernel over several re-allocations inside one
-# process (tools/placement2.py): does the slow placement state show up as translation misses?   usage: tools/pmc_tlb.sh <outdir>
+# process (tools/experiments/placement2.py): does the slow placement state show up as translation misses?   usage: tools/pmc_tlb.sh <outdir>
 set -uo pipefail
 OUT=$(realpath -m "$1"); R=$(cd "$(dirname "$0")/.." && pwd)
 export TMPDIR=/tmp; cd /tmp; rm -rf /tmp/prof_tlb; mkdir -p "$OUT"
 timeout -k 10 400 rocprofv3 --pmc TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum GRBM_UTCL2_BUSY GRBM_GUI_ACTIVE \
-    --kernel-include-regex "compact_lean" --kernel-trace --output-format csv -d /tmp/prof_tlb -- python3 "$R/tools/placement2.py" > "$OUT/placement2_under_pmc.txt" 2>&1 || { echo failed; tail -5 "$OUT/placement2_under_pmc.txt"; exit 1; }
+    --kernel-include-regex "compact_lean" --kernel-trace --output-format csv -d /tmp/prof_tlb -- python3 "$R/tools/experiments/placement2.py" > "$OUT/placement2_under_pmc.txt" 2>&1 || { echo failed; tail -5 "$OUT/placement2_under_pmc.txt"; exit 1; }
 python3 - "$OUT" <<'PY'
 import csv, sys, collections
 from pathlib import Path
