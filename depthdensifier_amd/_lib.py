@@ -21,7 +21,7 @@ import torch  # noqa: F401  (load order, see above)
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("DDCORE_LIB", _HERE / "libddcore.so"))
 
-DD_ABI_VERSION = 8
+DD_ABI_VERSION = 9
 DD_OK = 0
 DD_F32, DD_F16 = 0, 1
 DD_VALID_DEPTH_POSITIVE = 0x1
@@ -52,6 +52,14 @@ EXPORTS = (
     "dd_comm_last_error",
     "dd_format_points3d",
     "dd_model_last_error",
+    "dd_arena_create",
+    "dd_arena_alloc",
+    "dd_arena_free",
+    "dd_arena_classes",
+    "dd_arena_probe",
+    "dd_arena_stats",
+    "dd_arena_destroy",
+    "dd_arena_last_error",
 )
 
 
@@ -105,6 +113,22 @@ class DDFilterViews(C.Structure):
         ("workspace_bytes", C.c_int64),
         ("mode", C.c_int32),
         ("reserved3", C.c_int32),
+    ]
+
+
+class DDArenaStats(C.Structure):
+    _fields_ = [
+        ("chunk_bytes", C.c_int64),
+        ("probe_bytes", C.c_int64),
+        ("num_classes", C.c_int32),
+        ("degraded_allocs", C.c_int32),
+        ("chunks_created", C.c_int64),
+        ("chunks_released", C.c_int64),
+        ("probes", C.c_int64),
+        ("chunks_held", C.c_int64 * 3),
+        ("same_class_ms", C.c_float),
+        ("cross_class_ms", C.c_float),
+        ("seconds", C.c_double),
     ]
 
 
@@ -168,6 +192,22 @@ def _load() -> C.CDLL:
     lib.dd_format_points3d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.dd_model_last_error.restype = C.c_char_p
     lib.dd_model_last_error.argtypes = []
+    lib.dd_arena_create.restype = C.c_int
+    lib.dd_arena_create.argtypes = [C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]
+    lib.dd_arena_alloc.restype = C.c_int
+    lib.dd_arena_alloc.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_void_p)]
+    lib.dd_arena_free.restype = C.c_int
+    lib.dd_arena_free.argtypes = [C.c_void_p, C.c_void_p]
+    lib.dd_arena_classes.restype = C.c_int
+    lib.dd_arena_classes.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int32]
+    lib.dd_arena_probe.restype = C.c_int
+    lib.dd_arena_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+    lib.dd_arena_stats.restype = C.c_int
+    lib.dd_arena_stats.argtypes = [C.c_void_p, C.POINTER(DDArenaStats)]
+    lib.dd_arena_destroy.restype = C.c_int
+    lib.dd_arena_destroy.argtypes = [C.c_void_p]
+    lib.dd_arena_last_error.restype = C.c_char_p
+    lib.dd_arena_last_error.argtypes = []
     got = lib.dd_abi_version()
     if got != DD_ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI version {got}, binding expects {DD_ABI_VERSION}; rebuild the library")

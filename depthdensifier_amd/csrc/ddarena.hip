@@ -1,0 +1,490 @@
+// ddarena.hip -- HBM zone arena: where the cloud's large arrays live in the 288 GB of an MI355X (round 3).
+//
+// What it is for.  The densify kernel (ddcore.hip; scripts/test.py:203-244, 262-266 fused) writes two large row streams in
+// lock step -- the points and the normals, 12 bytes per point each (the two list appends of scripts/test.py:238-240) -- beside
+// its read streams.  Measured on MI355X (profiles/r03_placement_*.txt): the physical memory falls into THREE classes of
+// about a third of the HBM each; two lock-step write streams inside one class run 20-26 % slower than in two different
+// classes (a plain two-stream store kernel: 0.146 vs 0.116 ms per 2 x 384 MiB), which is 4-11 % of the whole densify
+// kernel (2.94 vs 2.60 ms on 185 1080p views) and was the unexplained "box state" of rounds 1 and 2: a fresh process gets
+// all its memory from one end of the device, i.e. from one class.  The relation is an equivalence (pairwise table in
+// profiles/r03_zone_probe.txt), so a chunk's class is found by timing it against one anchor chunk per class.
+//
+// What it does.  Physical memory is taken in chunks (default 1 GiB) through the virtual-memory API (hipMemCreate), every
+// new chunk is mapped into a scouting range and classified with the two-stream store probe below against the anchors;
+// an allocation request names a GROUP per array, arrays of different groups are built from chunks of different classes
+// (mapped back to back into a fresh virtual range, so the caller sees one contiguous array), chunks that are not needed
+// go straight back to the driver.  Nothing here touches results: the arena only chooses physical pages.
+//
+// C ABI: dd_arena_* in include/ddcore.h.  Host-side memory management; the only kernel is the probe.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <mutex>
+#include <vector>
+
+#include "ddcore.h"
+
+namespace {
+
+thread_local char g_aerr[320] = "";
+
+int afail(int code, const char *msg) {
+    snprintf(g_aerr, sizeof(g_aerr), "%s", msg);
+    return code;
+}
+int afail_hip(const char *what, hipError_t e) {
+    snprintf(g_aerr, sizeof(g_aerr), "%s: %s", what, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? DD_ERR_WORKSPACE : DD_ERR_LAUNCH;
+}
+
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+typedef f32x3 f32x3_rows __attribute__((aligned(4)));
+
+// Two row streams written in lock step, one 12-byte row per lane and stream: the store shape of the densify kernel's
+// points + normals.  Write-only: the classes show more clearly than with read streams in the mix.
+__global__ __launch_bounds__(256) void zone_pair_store(float *a, float *b, const size_t rows) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    f32x3 p;
+    p.x = (float)(unsigned)i; p.y = 1.0f; p.z = 2.0f;
+    *reinterpret_cast<f32x3_rows *>(a + 3 * i) = p;
+    *reinterpret_cast<f32x3_rows *>(b + 3 * i) = p;
+}
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+constexpr int MAX_CLASSES = 3;
+constexpr size_t SCOUT_SLOTS = 512;
+constexpr int SCOUT_BATCH = 8;
+
+struct Chunk {
+    hipMemGenericAllocationHandle_t h;
+    int cls;        // -1 = not classified
+    int slot;       // scouting slot it is mapped in, -1 = mapped into an allocation
+    bool live;      // handle not yet released
+    bool used;      // part of an allocation
+    bool anchor;
+};
+
+struct Mapping {
+    char *va;
+    size_t bytes;               // reserved (multiple of the chunk size)
+    std::vector<int> chunks;
+};
+
+}  // namespace
+
+struct DDArena {
+    int device;
+    size_t chunk;
+    size_t rows;                // probe window, rows of 12 bytes
+    char *scout_va;
+    std::vector<int> slot_owner;      // SCOUT_SLOTS entries, chunk index or -1
+    std::vector<Chunk> chunks;
+    std::vector<Mapping> maps;
+    int anchors[MAX_CLASSES];
+    int n_classes;
+    int group_class[MAX_CLASSES];     // class a group was given at its first use (-1 = not yet): sticky, so that arrays of
+                                      // later calls land relative to the arrays of earlier ones
+    float same_ms;              // probe level of two windows inside one chunk (same class by construction)
+    float fast_ms;              // fastest pair seen
+    hipStream_t stream;
+    hipEvent_t e0, e1;
+    hipMemAllocationProp prop;
+    std::mutex mu;
+    // statistics
+    int64_t created, released, probes;
+    double seconds;
+    int32_t degraded;           // allocations that could not be given distinct classes
+};
+
+namespace {
+
+#define AHIP(call, what)                                   \
+    do {                                                   \
+        hipError_t e_ = (call);                            \
+        if (e_ != hipSuccess) return afail_hip(what, e_);  \
+    } while (0)
+
+char *slot_ptr(DDArena *A, int slot) { return A->scout_va + (size_t)slot * A->chunk; }
+
+// median-free timing: the minimum of `reps` runs after one warm-up (disturbances only ever add time)
+int probe_pair(DDArena *A, float *a, float *b, float *ms_out) {
+    const dim3 grid((unsigned)((A->rows + 255) / 256)), block(256);
+    float best = 1e30f;
+    for (int r = 0; r < 4; ++r) {
+        AHIP(hipEventRecord(A->e0, A->stream), "hipEventRecord");
+        hipLaunchKernelGGL(zone_pair_store, grid, block, 0, A->stream, a, b, A->rows);
+        AHIP(hipGetLastError(), "zone_pair_store launch");
+        AHIP(hipEventRecord(A->e1, A->stream), "hipEventRecord");
+        AHIP(hipEventSynchronize(A->e1), "hipEventSynchronize");
+        float ms = 0.f;
+        AHIP(hipEventElapsedTime(&ms, A->e0, A->e1), "hipEventElapsedTime");
+        if (r > 0 && ms < best) best = ms;
+    }
+    A->probes += 1;
+    *ms_out = best;
+    return DD_OK;
+}
+
+// is a pair at `ms` inside one class?  Same-class pairs sit at the level of two windows inside one chunk (same_ms),
+// cross-class pairs 20-26 % below it; the cut is the geometric middle once a fast pair has been seen, 9 % below same_ms before.
+bool is_same_class(const DDArena *A, float ms) {
+    float cut = 0.91f * A->same_ms;
+    if (A->fast_ms < 0.9f * A->same_ms) cut = sqrtf(A->fast_ms * A->same_ms);
+    return ms > cut;
+}
+
+int release_chunk(DDArena *A, int ci) {
+    Chunk &c = A->chunks[ci];
+    if (!c.live) return DD_OK;
+    if (c.slot >= 0) {
+        AHIP(hipMemUnmap(slot_ptr(A, c.slot), A->chunk), "hipMemUnmap(scout)");
+        A->slot_owner[c.slot] = -1;
+        c.slot = -1;
+    }
+    AHIP(hipMemRelease(c.h), "hipMemRelease");
+    c.live = false;
+    A->released += 1;
+    return DD_OK;
+}
+
+// One more physical chunk, mapped into a free scouting slot and classified.  DD_ERR_WORKSPACE = the device is out of memory
+// (or out of scouting slots): the caller stops scouting.
+int scout_one(DDArena *A, int *chunk_out) {
+    int slot = -1;
+    for (size_t s = 0; s < SCOUT_SLOTS; ++s)
+        if (A->slot_owner[s] < 0) { slot = (int)s; break; }
+    if (slot < 0) return afail(DD_ERR_WORKSPACE, "arena: no free scouting slot");
+    Chunk c;
+    memset(&c, 0, sizeof(c));
+    c.cls = -1; c.slot = slot; c.live = true; c.used = false; c.anchor = false;
+    hipError_t e = hipMemCreate(&c.h, A->chunk, &A->prop, 0);
+    if (e != hipSuccess) return afail_hip("hipMemCreate", e);
+    e = hipMemMap(slot_ptr(A, slot), A->chunk, 0, c.h, 0);
+    if (e != hipSuccess) { (void)hipMemRelease(c.h); return afail_hip("hipMemMap(scout)", e); }
+    hipMemAccessDesc acc;
+    memset(&acc, 0, sizeof(acc));
+    acc.location = A->prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    e = hipMemSetAccess(slot_ptr(A, slot), A->chunk, &acc, 1);
+    if (e != hipSuccess) { (void)hipMemUnmap(slot_ptr(A, slot), A->chunk); (void)hipMemRelease(c.h); return afail_hip("hipMemSetAccess(scout)", e); }
+    A->chunks.push_back(c);
+    const int ci = (int)A->chunks.size() - 1;
+    A->slot_owner[slot] = ci;
+    A->created += 1;
+    float *w = reinterpret_cast<float *>(slot_ptr(A, slot));
+    int rc;
+    if (A->n_classes == 0) {
+        // the very first chunk: anchor of class 0; its two halves give the same-class level
+        float ms;
+        if ((rc = probe_pair(A, w, reinterpret_cast<float *>(slot_ptr(A, slot) + A->chunk / 2), &ms)) != DD_OK) return rc;
+        A->same_ms = ms;
+        A->fast_ms = ms;
+        A->chunks[ci].cls = 0;
+        A->chunks[ci].anchor = true;
+        A->anchors[0] = ci;
+        A->n_classes = 1;
+        *chunk_out = ci;
+        return DD_OK;
+    }
+    float t[MAX_CLASSES];
+    int cls = -1;
+    for (int k = 0; k < A->n_classes; ++k) {
+        float *anchor = reinterpret_cast<float *>(slot_ptr(A, A->chunks[A->anchors[k]].slot));
+        if ((rc = probe_pair(A, anchor, w, &t[k])) != DD_OK) return rc;
+        if (t[k] < A->fast_ms) A->fast_ms = t[k];
+    }
+    for (int k = 0; k < A->n_classes; ++k)          // decided after all probes: fast_ms may have moved
+        if (is_same_class(A, t[k]) && (cls < 0 || t[k] > t[cls])) cls = k;
+    if (cls < 0) {
+        if (A->n_classes < MAX_CLASSES) {            // differs from every anchor: a new class, this chunk anchors it
+            cls = A->n_classes++;
+            A->anchors[cls] = ci;
+            A->chunks[ci].anchor = true;
+        } else {                                     // cannot be: three classes are all there is.  Take the slowest pairing.
+            cls = 0;
+            for (int k = 1; k < MAX_CLASSES; ++k) if (t[k] > t[cls]) cls = k;
+        }
+    }
+    A->chunks[ci].cls = cls;
+    *chunk_out = ci;
+    return DD_OK;
+}
+
+int free_count(const DDArena *A, int cls) {
+    int n = 0;
+    for (const Chunk &c : A->chunks) if (c.live && !c.used && !c.anchor && c.cls == cls) ++n;
+    return n;
+}
+
+// best assignment of groups to classes for the chunks at hand: maximise the chunks served from a group's own class;
+// groups that were given a class by an earlier call keep it
+int best_assignment(const DDArena *A, const int need[MAX_CLASSES], int perm_out[MAX_CLASSES]) {
+    int avail[MAX_CLASSES];
+    for (int k = 0; k < MAX_CLASSES; ++k) avail[k] = free_count(A, k);
+    int p[MAX_CLASSES] = {0, 1, 2}, best = -1;
+    do {
+        bool ok = true;
+        for (int g = 0; g < MAX_CLASSES; ++g) if (A->group_class[g] >= 0 && A->group_class[g] != p[g]) ok = false;
+        if (!ok) continue;
+        int served = 0;
+        for (int g = 0; g < MAX_CLASSES; ++g) served += std::min(need[g], avail[p[g]]);
+        if (served > best) { best = served; memcpy(perm_out, p, sizeof(p)); }
+    } while (std::next_permutation(p, p + MAX_CLASSES));
+    return best;
+}
+
+int take_chunk(DDArena *A, int cls) {      // a free chunk of the class; -1 = none
+    for (size_t i = 0; i < A->chunks.size(); ++i) {
+        Chunk &c = A->chunks[i];
+        if (c.live && !c.used && !c.anchor && c.cls == cls) return (int)i;
+    }
+    return -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *dd_arena_last_error(void) { return g_aerr; }
+
+int dd_arena_create(int32_t device, int64_t chunk_bytes, DDArena **arena_out) {
+    if (!arena_out) return afail(DD_ERR_INVALID_ARG, "arena_out is NULL");
+    *arena_out = nullptr;
+    if (chunk_bytes == 0) chunk_bytes = (int64_t)1 << 30;
+    if (chunk_bytes < ((int64_t)64 << 20) || (chunk_bytes & (((int64_t)2 << 20) - 1)))
+        return afail(DD_ERR_INVALID_ARG, "chunk_bytes must be a multiple of 2 MiB and at least 64 MiB");
+    int ndev = 0;
+    AHIP(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
+    if (device < 0 || device >= ndev) return afail(DD_ERR_INVALID_ARG, "no such device");
+    int prev = 0;
+    AHIP(hipGetDevice(&prev), "hipGetDevice");
+    AHIP(hipSetDevice(device), "hipSetDevice");
+    DDArena *A = new DDArena();
+    A->device = device;
+    A->chunk = (size_t)chunk_bytes;
+    A->rows = std::min<size_t>((size_t)32 << 20, A->chunk / 24);      // two windows fit one chunk (the same-class reference)
+    A->n_classes = 0;
+    A->same_ms = A->fast_ms = 0.f;
+    A->created = A->released = A->probes = 0;
+    A->seconds = 0.0;
+    A->degraded = 0;
+    for (int k = 0; k < MAX_CLASSES; ++k) A->anchors[k] = A->group_class[k] = -1;
+    A->slot_owner.assign(SCOUT_SLOTS, -1);
+    memset(&A->prop, 0, sizeof(A->prop));
+    A->prop.type = hipMemAllocationTypePinned;
+    A->prop.location.type = hipMemLocationTypeDevice;
+    A->prop.location.id = device;
+    int rc = DD_OK;
+    hipError_t e;
+    A->scout_va = nullptr; A->stream = nullptr; A->e0 = A->e1 = nullptr;
+    if ((e = hipMemAddressReserve(reinterpret_cast<void **>(&A->scout_va), SCOUT_SLOTS * A->chunk, 0, nullptr, 0)) != hipSuccess) rc = afail_hip("hipMemAddressReserve(scout)", e);
+    if (rc == DD_OK && (e = hipStreamCreateWithFlags(&A->stream, hipStreamNonBlocking)) != hipSuccess) rc = afail_hip("hipStreamCreate", e);
+    if (rc == DD_OK && (e = hipEventCreate(&A->e0)) != hipSuccess) rc = afail_hip("hipEventCreate", e);
+    if (rc == DD_OK && (e = hipEventCreate(&A->e1)) != hipSuccess) rc = afail_hip("hipEventCreate", e);
+    (void)hipSetDevice(prev);
+    if (rc != DD_OK) {
+        if (A->e0) (void)hipEventDestroy(A->e0);
+        if (A->e1) (void)hipEventDestroy(A->e1);
+        if (A->stream) (void)hipStreamDestroy(A->stream);
+        if (A->scout_va) (void)hipMemAddressFree(A->scout_va, SCOUT_SLOTS * A->chunk);
+        delete A;
+        return rc;
+    }
+    *arena_out = A;
+    return DD_OK;
+}
+
+int dd_arena_alloc(DDArena *A, int32_t n, const int64_t *sizes, const int32_t *groups, int64_t max_scout_bytes, void **ptrs_out) {
+    if (!A || !sizes || !groups || !ptrs_out || n <= 0 || n > 64) return afail(DD_ERR_INVALID_ARG, "arena / sizes / groups / ptrs_out is NULL or n outside 1..64");
+    std::lock_guard<std::mutex> lock(A->mu);
+    const double t_start = now_s();
+    int need[MAX_CLASSES] = {0, 0, 0};
+    std::vector<int> nch(n);
+    for (int i = 0; i < n; ++i) {
+        if (sizes[i] <= 0) return afail(DD_ERR_INVALID_ARG, "sizes must be positive");
+        if (groups[i] < 0 || groups[i] >= MAX_CLASSES) return afail(DD_ERR_INVALID_ARG, "groups must be 0, 1 or 2");
+        nch[i] = (int)(((size_t)sizes[i] + A->chunk - 1) / A->chunk);
+        need[groups[i]] += nch[i];
+        ptrs_out[i] = nullptr;
+    }
+    int prev = 0;
+    AHIP(hipGetDevice(&prev), "hipGetDevice");
+    AHIP(hipSetDevice(A->device), "hipSetDevice");
+    struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{prev};
+    AHIP(hipDeviceSynchronize(), "hipDeviceSynchronize");          // probes are timed: nothing else should be running
+    const int total_need = need[0] + need[1] + need[2];
+    int perm[MAX_CLASSES] = {0, 1, 2};
+    int64_t scouted = 0;
+    bool oom = false;
+    int rc = DD_OK;
+    // scout until every group can be served from a class of its own, or the budget / the memory is spent
+    for (;;) {
+        if (best_assignment(A, need, perm) >= total_need) break;
+        if (oom) break;
+        int live_free = 0;
+        for (const Chunk &c : A->chunks) if (c.live && !c.used && !c.anchor) ++live_free;
+        // the budget counts chunks beyond what the request itself needs
+        if ((int64_t)(live_free - total_need + SCOUT_BATCH) * (int64_t)A->chunk > max_scout_bytes && live_free >= total_need) break;
+        for (int b = 0; b < SCOUT_BATCH; ++b) {
+            int ci;
+            rc = scout_one(A, &ci);
+            if (rc == DD_ERR_WORKSPACE) { oom = true; rc = DD_OK; break; }
+            if (rc != DD_OK) return rc;
+            scouted += (int64_t)A->chunk;
+        }
+    }
+    best_assignment(A, need, perm);
+    for (int g = 0; g < MAX_CLASSES; ++g) if (need[g] > 0) A->group_class[g] = perm[g];
+    // choose the chunks: own class first, then whatever is left (degraded)
+    std::vector<std::vector<int>> chosen(n);
+    bool degraded = false;
+    for (int i = 0; i < n && rc == DD_OK; ++i) {
+        for (int k = 0; k < nch[i]; ++k) {
+            int ci = take_chunk(A, perm[groups[i]]);
+            if (ci < 0) {
+                degraded = true;
+                for (int c2 = 0; c2 < MAX_CLASSES && ci < 0; ++c2) ci = take_chunk(A, c2);
+            }
+            if (ci < 0) { rc = afail(DD_ERR_WORKSPACE, "arena: out of device memory"); break; }
+            A->chunks[ci].used = true;
+            chosen[i].push_back(ci);
+        }
+    }
+    if (rc != DD_OK) {
+        for (auto &v : chosen) for (int ci : v) A->chunks[ci].used = false;
+        for (size_t ci = 0; ci < A->chunks.size(); ++ci) if (A->chunks[ci].live && !A->chunks[ci].used && !A->chunks[ci].anchor) (void)release_chunk(A, (int)ci);
+        return rc;
+    }
+    // build the arrays: chunks leave the scouting range and are mapped back to back into a fresh range
+    hipMemAccessDesc acc;
+    memset(&acc, 0, sizeof(acc));
+    acc.location = A->prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    for (int i = 0; i < n; ++i) {
+        Mapping m;
+        m.bytes = (size_t)nch[i] * A->chunk;
+        m.va = nullptr;
+        AHIP(hipMemAddressReserve(reinterpret_cast<void **>(&m.va), m.bytes, 0, nullptr, 0), "hipMemAddressReserve(array)");
+        for (int k = 0; k < nch[i]; ++k) {
+            Chunk &c = A->chunks[chosen[i][k]];
+            AHIP(hipMemUnmap(slot_ptr(A, c.slot), A->chunk), "hipMemUnmap(scout)");
+            A->slot_owner[c.slot] = -1;
+            c.slot = -1;
+            AHIP(hipMemMap(m.va + (size_t)k * A->chunk, A->chunk, 0, c.h, 0), "hipMemMap(array)");
+        }
+        AHIP(hipMemSetAccess(m.va, m.bytes, &acc, 1), "hipMemSetAccess(array)");
+        m.chunks = chosen[i];
+        A->maps.push_back(m);
+        ptrs_out[i] = m.va;
+    }
+    // what was scouted and not needed goes back to the driver (the anchors stay)
+    for (size_t ci = 0; ci < A->chunks.size(); ++ci)
+        if (A->chunks[ci].live && !A->chunks[ci].used && !A->chunks[ci].anchor) {
+            if ((rc = release_chunk(A, (int)ci)) != DD_OK) return rc;
+        }
+    if (degraded) A->degraded += 1;
+    A->seconds += now_s() - t_start;
+    return degraded ? 1 : DD_OK;
+}
+
+int dd_arena_free(DDArena *A, void *ptr) {
+    if (!A || !ptr) return afail(DD_ERR_INVALID_ARG, "arena or ptr is NULL");
+    std::lock_guard<std::mutex> lock(A->mu);
+    for (size_t i = 0; i < A->maps.size(); ++i) {
+        if (A->maps[i].va != ptr) continue;
+        int prev = 0;
+        AHIP(hipGetDevice(&prev), "hipGetDevice");
+        AHIP(hipSetDevice(A->device), "hipSetDevice");
+        struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{prev};
+        AHIP(hipDeviceSynchronize(), "hipDeviceSynchronize");      // kernels that still use the array must have drained
+        Mapping m = A->maps[i];
+        A->maps.erase(A->maps.begin() + (long)i);
+        AHIP(hipMemUnmap(m.va, m.bytes), "hipMemUnmap(array)");
+        for (int ci : m.chunks) {
+            Chunk &c = A->chunks[ci];
+            c.used = false;
+            AHIP(hipMemRelease(c.h), "hipMemRelease");
+            c.live = false;
+            A->released += 1;
+        }
+        AHIP(hipMemAddressFree(m.va, m.bytes), "hipMemAddressFree(array)");
+        return DD_OK;
+    }
+    return afail(DD_ERR_INVALID_ARG, "ptr was not allocated by this arena");
+}
+
+int dd_arena_classes(DDArena *A, const void *ptr, int32_t *classes_out, int32_t capacity) {
+    if (!A || !ptr || !classes_out) return afail(DD_ERR_INVALID_ARG, "arena / ptr / classes_out is NULL");
+    std::lock_guard<std::mutex> lock(A->mu);
+    for (const Mapping &m : A->maps) {
+        if (m.va != ptr) continue;
+        const int k = (int)m.chunks.size();
+        for (int i = 0; i < k && i < capacity; ++i) classes_out[i] = A->chunks[m.chunks[i]].cls;
+        return k;
+    }
+    return afail(DD_ERR_INVALID_ARG, "ptr was not allocated by this arena");
+}
+
+int dd_arena_probe(DDArena *A, void *a, void *b, float *ms_out) {
+    if (!A || !a || !b || !ms_out) return afail(DD_ERR_INVALID_ARG, "arena / a / b / ms_out is NULL");
+    std::lock_guard<std::mutex> lock(A->mu);
+    int prev = 0;
+    AHIP(hipGetDevice(&prev), "hipGetDevice");
+    AHIP(hipSetDevice(A->device), "hipSetDevice");
+    struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{prev};
+    AHIP(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    return probe_pair(A, reinterpret_cast<float *>(a), reinterpret_cast<float *>(b), ms_out);
+}
+
+int dd_arena_stats(DDArena *A, DDArenaStats *out) {
+    if (!A || !out) return afail(DD_ERR_INVALID_ARG, "arena or out is NULL");
+    std::lock_guard<std::mutex> lock(A->mu);
+    memset(out, 0, sizeof(*out));
+    out->chunk_bytes = (int64_t)A->chunk;
+    out->probe_bytes = (int64_t)A->rows * 12;
+    out->num_classes = A->n_classes;
+    out->chunks_created = A->created;
+    out->chunks_released = A->released;
+    out->probes = A->probes;
+    out->same_class_ms = A->same_ms;
+    out->cross_class_ms = A->fast_ms;
+    out->seconds = A->seconds;
+    out->degraded_allocs = A->degraded;
+    for (const Chunk &c : A->chunks)
+        if (c.live && c.cls >= 0 && c.cls < MAX_CLASSES) out->chunks_held[c.cls] += 1;
+    return DD_OK;
+}
+
+int dd_arena_destroy(DDArena *A) {
+    if (!A) return DD_OK;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(A->device);
+    (void)hipDeviceSynchronize();
+    for (Mapping &m : A->maps) {
+        (void)hipMemUnmap(m.va, m.bytes);
+        (void)hipMemAddressFree(m.va, m.bytes);
+    }
+    for (Chunk &c : A->chunks) {
+        if (!c.live) continue;
+        if (c.slot >= 0) (void)hipMemUnmap(slot_ptr(A, c.slot), A->chunk);
+        (void)hipMemRelease(c.h);
+    }
+    (void)hipMemAddressFree(A->scout_va, SCOUT_SLOTS * A->chunk);
+    (void)hipEventDestroy(A->e0);
+    (void)hipEventDestroy(A->e1);
+    (void)hipStreamDestroy(A->stream);
+    (void)hipSetDevice(prev);
+    delete A;
+    return DD_OK;
+}
+
+}  // extern "C"

@@ -434,11 +434,14 @@ class CloudBuilder:
 
     def __init__(self, capacity: int, *, normals: bool = False, colors: bool = False,
                  pixel_index: bool = True, view_index: bool = False, packed: bool = False, points: bool = True,
-                 buffers: Optional[dict] = None, start=None, device=None):
+                 buffers: Optional[dict] = None, start=None, device=None, placement: Optional[str] = None):
         """``packed``: also (or, with ``points=False``, only) write the 16-byte ``x, y, z, rgba`` record per point
         (``DDCloudOut.xyz_rgba``).  ``buffers``: caller-owned tensors to write into instead of allocating, keyed like
         ``FIELDS`` -- the multi-GPU fuse hands in the GLOBAL cloud so that every point is written once, at its final
-        row.  ``start``: first row (int or (1,) int64 device tensor), e.g. ``rank_offsets[rank]``."""
+        row.  ``start``: first row (int or (1,) int64 device tensor), e.g. ``rank_offsets[rank]``.  ``placement``:
+        ``"probed"`` (default, or ``DD_PLACEMENT``) puts the points and the normals of a large cloud this builder allocates
+        into different classes of HBM address ranges (``placement.place_outputs``; ``self.placement`` reports what was done),
+        ``"first"`` takes the arrays as the allocator returns them."""
         dev = _require_gpu(device)
         self.device = dev
         self.capacity = int(capacity)
@@ -446,9 +449,20 @@ class CloudBuilder:
         want = {"points": points, "normals": normals, "colors": colors, "pixel_index": pixel_index, "view_index": view_index, "packed": packed}
         if not (points or packed):
             raise ValueError("a cloud needs points or the packed record")
+        self.placement = None
+        if buffers is None and points and normals:
+            # the two lock-step row streams of the kernel: allocate them where they do not share an HBM class
+            from . import placement as _placement
+            p_xyz, p_nrm, p_rgb, self.placement = _placement.place_outputs(n, colors=colors, device=dev, mode=placement)
+            placed = {"points": p_xyz, "normals": p_nrm, "colors": p_rgb}
+        else:
+            placed = {}
         got = {}
         for name, on in want.items():
             tail, dtype = self.FIELDS[name]
+            if placed.get(name) is not None:
+                got[name] = placed[name]
+                continue
             t = None if buffers is None else buffers.get(name)
             if t is not None:
                 if t.dtype != dtype or tuple(t.shape) != (t.shape[0],) + tail or t.shape[0] < self.capacity or not t.is_contiguous() or t.device != dev:

@@ -1,0 +1,191 @@
+"""Where the cloud's large arrays live in HBM (round 3; measurements in ``profiles/r03_placement_*.txt``).
+
+The densify kernel writes two large row streams in lock step -- ``points`` and ``normals``, 12 bytes per point each, the
+same row of both at the same moment (the two list appends of ``scripts/test.py:238-240``, fused).  On MI355X the 288 GB of
+HBM fall into three classes of physical address ranges of about a third of the memory each.  Two such streams inside ONE
+class run 20-26 % slower than in two different classes, which costs 4-11 % of the densify kernel (2.94 vs 2.60 ms on the
+185-view 1080p workload).  A fresh process is handed memory from one end of the device, so everything it owns starts in
+one class -- the "box state" lottery of rounds 1 and 2.
+
+``ZoneArena`` (``csrc/ddarena.hip`` behind ``dd_arena_*``) takes physical chunks through the virtual-memory API,
+classifies them with a two-stream store probe and builds each requested array from chunks of one class, arrays of different
+groups from different classes.  ``place_outputs`` is what ``CloudBuilder`` calls: points in one class, normals in another,
+colours in the third.  Nothing here changes a result: it only chooses physical pages.
+
+Arrays from the arena are ordinary device tensors for every kernel, but their memory is not IPC-exportable: buffers that
+RCCL sends or receives (``distributed.fuse_replicated``) are allocated normally and handed to ``CloudBuilder(buffers=...)``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from dataclasses import dataclass
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib
+
+GIB = 1 << 30
+MIN_ROWS = 32 << 20            # clouds below 32 Mi rows (384 MiB of points) are left where they land: small streams do not care
+GROUP_POINTS, GROUP_NORMALS, GROUP_OTHER = 0, 1, 2
+
+
+def default_mode() -> str:
+    """``DD_PLACEMENT`` = ``probed`` (default) or ``first`` (take what the allocator returns, rounds 1-2 behaviour)."""
+    m = os.environ.get("DD_PLACEMENT", "probed").lower()
+    return m if m in ("probed", "first") else "probed"
+
+
+@dataclass
+class PlacementReport:
+    """What ``place_outputs`` did -- kept on the ``CloudBuilder`` as ``.placement`` and printed by ``bench.py``."""
+    mode: str                                   # "probed" | "first" | "skipped: <why>" | "degraded: <why>"
+    classes: Optional[Dict[str, list]] = None   # per array: the distinct classes of its chunks
+    seconds: float = 0.0
+    stats: Optional[dict] = None
+
+    def as_dict(self) -> dict:
+        return {"mode": self.mode, "classes": self.classes, "seconds": round(self.seconds, 3), "arena": self.stats}
+
+
+class ArenaError(RuntimeError):
+    pass
+
+
+def _acheck(rc: int) -> int:
+    if rc < 0:
+        raise ArenaError(f"libddcore arena error {rc}: {lib.dd_arena_last_error().decode('utf-8', 'replace')}")
+    return rc
+
+
+class _Block:
+    """One array of the arena, exported through ``__cuda_array_interface__``; torch keeps this object alive for as long as
+    any tensor (or view) shares the memory, and the array goes back to the driver when the last of them dies."""
+
+    def __init__(self, arena: "ZoneArena", ptr: int, nbytes: int):
+        self._arena, self.ptr, self.nbytes = arena, ptr, nbytes
+
+    @property
+    def __cuda_array_interface__(self) -> dict:
+        return {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 2, "strides": None}
+
+    def __del__(self):
+        arena = getattr(self, "_arena", None)
+        if arena is not None and arena._handle is not None and self.ptr:
+            try:
+                lib.dd_arena_free(arena._handle, C.c_void_p(self.ptr))
+            except Exception:      # noqa: BLE001  (interpreter shutdown)
+                pass
+            self.ptr = 0
+
+
+class ZoneArena:
+    """Process-wide arena of one device (``get_arena``).  ``alloc`` takes ``{name: (shape, dtype, group)}`` and returns
+    ``{name: tensor}``; all arrays of one call are placed against each other."""
+
+    def __init__(self, device: torch.device, chunk_bytes: int = 0):
+        self.device = torch.device(device)
+        h = C.c_void_p()
+        _acheck(lib.dd_arena_create(self.device.index or 0, int(chunk_bytes), C.byref(h)))
+        self._handle = h
+        self._lock = threading.Lock()
+
+    def alloc(self, specs: Dict[str, Tuple[Sequence[int], torch.dtype, int]], max_scout_bytes: Optional[int] = None) -> Tuple[Dict[str, torch.Tensor], bool]:
+        """-> (tensors, degraded).  ``degraded``: some group had to share a class (budget or memory too small)."""
+        names = list(specs)
+        n = len(names)
+        nbytes = [int(np.prod(specs[k][0], dtype=np.int64)) * torch.empty((), dtype=specs[k][1]).element_size() for k in names]
+        if any(b <= 0 for b in nbytes):
+            raise ValueError("arena arrays must not be empty")
+        if max_scout_bytes is None:
+            free = torch.cuda.mem_get_info(self.device)[0]
+            max_scout_bytes = int(min(64 * GIB, max(0, free - sum(nbytes)) // 2))
+        sizes = (C.c_int64 * n)(*nbytes)
+        groups = (C.c_int32 * n)(*[int(specs[k][2]) for k in names])
+        ptrs = (C.c_void_p * n)()
+        with self._lock:
+            rc = _acheck(lib.dd_arena_alloc(self._handle, n, sizes, groups, int(max_scout_bytes), ptrs))
+        out = {}
+        for k, b, p in zip(names, nbytes, ptrs):
+            shape, dtype, _ = specs[k]
+            raw = torch.as_tensor(_Block(self, int(p), b), device=self.device)
+            out[k] = raw.view(dtype).view(tuple(shape))
+        return out, rc == 1
+
+    def classes_of(self, t: torch.Tensor) -> list:
+        """Class of every chunk behind an arena array (``t`` must start at the array's first byte)."""
+        buf = (C.c_int32 * 512)()
+        k = _acheck(lib.dd_arena_classes(self._handle, C.c_void_p(t.data_ptr()), buf, 512))
+        return [int(buf[i]) for i in range(min(k, 512))]
+
+    def probe_ms(self, a: torch.Tensor, b: torch.Tensor) -> float:
+        """The two-stream store probe on the first ``stats()['probe_bytes']`` bytes of ``a`` and ``b`` (OVERWRITES them)."""
+        need = self.stats()["probe_bytes"]
+        if a.numel() * a.element_size() < need or b.numel() * b.element_size() < need:
+            raise ValueError(f"probe windows need {need} bytes")
+        ms = C.c_float()
+        _acheck(lib.dd_arena_probe(self._handle, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.byref(ms)))
+        return float(ms.value)
+
+    def stats(self) -> dict:
+        s = _lib.DDArenaStats()
+        _acheck(lib.dd_arena_stats(self._handle, C.byref(s)))
+        return {"chunk_bytes": int(s.chunk_bytes), "probe_bytes": int(s.probe_bytes), "num_classes": int(s.num_classes),
+                "degraded_allocs": int(s.degraded_allocs), "chunks_created": int(s.chunks_created), "chunks_released": int(s.chunks_released),
+                "probes": int(s.probes), "chunks_held": [int(x) for x in s.chunks_held], "same_class_ms": round(float(s.same_class_ms), 4),
+                "cross_class_ms": round(float(s.cross_class_ms), 4), "seconds": round(float(s.seconds), 3)}
+
+
+_arenas: Dict[int, ZoneArena] = {}
+_arenas_lock = threading.Lock()
+
+
+def get_arena(device) -> ZoneArena:
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    with _arenas_lock:
+        a = _arenas.get(idx)
+        if a is None:
+            a = _arenas[idx] = ZoneArena(torch.device("cuda", idx), int(os.environ.get("DD_ARENA_CHUNK_MIB", "0")) << 20)
+        return a
+
+
+def place_arrays(specs: Dict[str, Tuple[Sequence[int], torch.dtype, int]], device, mode: Optional[str] = None) -> Tuple[Dict[str, torch.Tensor], PlacementReport]:
+    """Allocate the arrays of ``specs`` = ``{name: (shape, dtype, group)}``: through the arena (``probed``), or plainly
+    (``first``, and whenever the arena cannot serve the request -- the report says why)."""
+    import time
+    mode = mode or default_mode()
+    dev = torch.device(device)
+    plain = lambda: {k: torch.empty(tuple(s), dtype=d, device=dev) for k, (s, d, _) in specs.items()}
+    if mode == "first":
+        return plain(), PlacementReport("first")
+    t0 = time.perf_counter()
+    try:
+        arena = get_arena(dev)
+        tensors, degraded = arena.alloc(specs)
+    except (ArenaError, RuntimeError) as e:          # the virtual-memory API is missing or out of memory: carry on unplaced
+        return plain(), PlacementReport(f"skipped: {e}"[:200])
+    rep = PlacementReport("degraded: some arrays share a class" if degraded else "probed", seconds=time.perf_counter() - t0)
+    rep.classes = {k: sorted(set(arena.classes_of(t))) for k, t in tensors.items()}
+    rep.stats = arena.stats()
+    return tensors, rep
+
+
+def place_outputs(capacity: int, *, colors: bool, device, mode: Optional[str] = None) -> tuple:
+    """(points, normals, colors | None, PlacementReport) for a cloud of ``capacity`` rows that carries normals."""
+    n = max(int(capacity), 1)
+    specs = {"points": ((n, 3), torch.float32, GROUP_POINTS), "normals": ((n, 3), torch.float32, GROUP_NORMALS)}
+    if colors:
+        specs["colors"] = ((n, 3), torch.uint8, GROUP_OTHER)
+    mode = mode or default_mode()
+    if mode != "first" and n < MIN_ROWS:
+        t, rep = place_arrays(specs, device, "first")
+        rep.mode = f"skipped: {n} rows < {MIN_ROWS} (small streams do not care)"
+    else:
+        t, rep = place_arrays(specs, device, mode)
+    return t["points"], t["normals"], t.get("colors"), rep

@@ -10,8 +10,9 @@
  *
  *  - every function returns DD_OK (0) or a negative DD_ERR_* code and never
  *    throws; dd_last_error() returns a thread-local message for the last error;
- *  - the caller owns every buffer (device memory unless stated); the library
- *    allocates nothing and keeps no global mutable state; calls are re-entrant;
+ *  - the caller owns every buffer (device memory unless stated); the compute entry
+ *    points allocate nothing and keep no global mutable state; calls are re-entrant
+ *    (the one allocator is the explicit DDArena object at the end of this header);
  *  - all work is enqueued asynchronously on `stream` (a hipStream_t passed as
  *    void*; NULL = the default stream).  Nothing synchronises the host.
  */
@@ -24,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 8
+#define DD_ABI_VERSION 9
 
 enum {
     DD_OK = 0,
@@ -291,6 +292,50 @@ int dd_sort_knots(const float *x, const float *y, int32_t n, float *x_sorted, fl
 int dd_format_points3d(const float *xyz, const uint8_t *rgb, const uint32_t *xyz_rgba, int64_t n, uint64_t first_id,
                        uint8_t *out, void *stream);
 const char *dd_model_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * HBM zone arena (ABI 9): where the large arrays of the fused cloud (scripts/test.py:264-266 final_point_cloud /
+ * final_normals / final_colors) and of the per-view maps (:166-168) live in the 288 GB of an MI355X.  The physical memory
+ * falls into three classes of about a third each; the densify kernel's two lock-step row streams (points + normals) cost
+ * 4-11 % of the kernel's time when they share a class (profiles/r03_placement_*.txt).  The arena takes
+ * physical chunks through the virtual-memory API, classifies each with a two-stream store probe against one anchor chunk
+ * per class, and builds every requested array from chunks of ONE class, arrays of different groups from different
+ * classes.  Host-side memory management: it changes addresses, never results.  Not for buffers handed to RCCL
+ * (dd_allgatherv): memory from the virtual-memory API is not IPC-exportable -- allocate those normally.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct DDArena DDArena;
+
+typedef struct DDArenaStats {
+    int64_t chunk_bytes;
+    int64_t probe_bytes;        /* bytes each of the two probe streams writes */
+    int32_t num_classes;        /* classes discovered so far (<= 3) */
+    int32_t degraded_allocs;    /* allocations that could not be given a class of their own per group */
+    int64_t chunks_created;
+    int64_t chunks_released;
+    int64_t probes;
+    int64_t chunks_held[3];     /* live chunks per class (anchors and allocations) */
+    float same_class_ms;        /* probe level inside one chunk */
+    float cross_class_ms;       /* fastest pair seen */
+    double seconds;             /* time spent inside dd_arena_alloc */
+} DDArenaStats;
+
+/* An empty arena on `device`; chunk_bytes = 0 means 1 GiB (multiple of 2 MiB, >= 64 MiB). */
+int dd_arena_create(int32_t device, int64_t chunk_bytes, DDArena **arena_out);
+/* n arrays at once: sizes[i] bytes (rounded up to whole chunks), groups[i] in {0,1,2} -- arrays of one group share a class,
+ * different groups get different classes.  Scouts (creates + classifies) physical chunks until that is possible, holding at
+ * most max_scout_bytes beyond the request; chunks not needed go back to the driver before the call returns.  Synchronises
+ * the device (the probes are timed).  Returns DD_OK, 1 = allocated but some group had to share a class (budget or memory
+ * too small), or a negative error (DD_ERR_WORKSPACE = out of device memory). */
+int dd_arena_alloc(DDArena *arena, int32_t n, const int64_t *sizes, const int32_t *groups, int64_t max_scout_bytes, void **ptrs_out);
+/* Unmaps and releases one array of dd_arena_alloc; synchronises the device first. */
+int dd_arena_free(DDArena *arena, void *ptr);
+/* Class of every chunk behind an array: returns the number of chunks, writes min(that, capacity) entries. */
+int dd_arena_classes(DDArena *arena, const void *ptr, int32_t *classes_out, int32_t capacity);
+/* The probe on two windows (probe_bytes each) chosen by the caller, milliseconds (diagnostics, tests). */
+int dd_arena_probe(DDArena *arena, void *a, void *b, float *ms_out);
+int dd_arena_stats(DDArena *arena, DDArenaStats *out);
+int dd_arena_destroy(DDArena *arena);
+const char *dd_arena_last_error(void);
 
 #ifdef __cplusplus
 }

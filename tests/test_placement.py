@@ -1,0 +1,113 @@
+"""HBM zone arena (csrc/ddarena.hip, depthdensifier_amd/placement.py): the arrays of a cloud are built from physical chunks of
+different HBM classes.  Placement changes addresses only: the cloud must equal the unplaced one bit for bit."""
+
+import ctypes as C
+import gc
+
+import numpy as np
+import pytest
+
+
+def test_arena_entry_points_validate_without_a_gpu():
+    """Argument errors come back as codes with a message; nothing is launched (runs on a machine without a GPU)."""
+    import __graft_entry__ as g
+    g.build()
+    from depthdensifier_amd import _lib
+    L = _lib.lib
+    h = C.c_void_p()
+    assert L.dd_arena_create(0, 12345, C.byref(h)) == -1 and b"2 MiB" in L.dd_arena_last_error()
+    assert L.dd_arena_create(0, 0, None) == -1
+    assert L.dd_arena_alloc(None, 1, None, None, 0, None) == -1
+    assert L.dd_arena_free(None, None) == -1 and L.dd_arena_stats(None, None) == -1
+    assert L.dd_arena_classes(None, None, None, 0) == -1 and L.dd_arena_probe(None, None, None, None) == -1
+    assert L.dd_arena_destroy(None) == 0
+    assert C.sizeof(_lib.DDArenaStats) == 8 + 8 + 4 + 4 + 3 * 8 + 3 * 8 + 4 + 4 + 8
+
+
+def test_placement_mode_from_environment(monkeypatch):
+    from depthdensifier_amd import placement as pl
+    monkeypatch.delenv("DD_PLACEMENT", raising=False)
+    assert pl.default_mode() == "probed"
+    monkeypatch.setenv("DD_PLACEMENT", "first")
+    assert pl.default_mode() == "first"
+    monkeypatch.setenv("DD_PLACEMENT", "nonsense")
+    assert pl.default_mode() == "probed"
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    import __graft_entry__ as g
+    g.build()
+    return torch.device("cuda", 0)
+
+
+@pytest.mark.gpu
+def test_arena_gives_every_group_its_own_class(gpu):
+    import torch
+    from depthdensifier_amd import placement as pl
+    arena = pl.get_arena(gpu)
+    rows = 40 << 20                                   # 480 MiB of float32 rows: more than one probe window
+    specs = {"a": ((rows, 3), torch.float32, 0), "b": ((rows, 3), torch.float32, 1), "c": ((3 * rows,), torch.uint8, 2)}
+    t, degraded = arena.alloc(specs)
+    assert not degraded
+    cls = {k: set(arena.classes_of(v)) for k, v in t.items()}
+    assert all(len(c) == 1 for c in cls.values()), cls                      # every array from ONE class
+    assert len(set.union(*cls.values())) == 3, cls                          # three arrays, three classes
+    st = arena.stats()
+    assert st["num_classes"] == 3 and st["cross_class_ms"] < 0.9 * st["same_class_ms"], st
+    # the arrays are ordinary device memory
+    t["a"].fill_(1.5); t["c"].fill_(7)
+    assert float(t["a"].sum(dtype=torch.float64)) == 1.5 * 3 * rows and int(t["c"][-1]) == 7
+    # the probe sees what the classes say: two arrays of different groups are a fast pair, two halves of one array a slow one
+    cross = arena.probe_ms(t["a"], t["b"])
+    same = arena.probe_ms(t["a"], t["a"][rows // 2:]) if (rows // 2) * 12 >= st["probe_bytes"] else None
+    assert cross < 0.92 * st["same_class_ms"], (cross, st)
+    if same is not None:
+        assert same > cross * 1.08, (same, cross)
+    # a later call keeps the groups where they are
+    t2, _ = arena.alloc({"d": ((rows, 3), torch.float32, 1)})
+    assert set(arena.classes_of(t2["d"])) == cls["b"]
+    held = sum(arena.stats()["chunks_held"])
+    del t, t2
+    gc.collect()
+    assert sum(arena.stats()["chunks_held"]) < held                         # the arrays went back to the driver
+
+
+@pytest.mark.gpu
+def test_placed_cloud_equals_unplaced_cloud(gpu):
+    """18 views of 1080p (37 M rows: above the placement threshold): same rows, same bits, whichever pages hold them; and the
+    cloud stays alive after its builder is gone."""
+    import torch
+    import depthdensifier_amd as dd
+    from synth import make_views
+    V, H, W = 18, 1080, 1920
+    d = make_views(11, V, H, W, rho=0.8)
+    params = np.tile([0.8 * W, 0.8 * W, W / 2.0, H / 2.0], (V, 1))
+    batch = dd.ViewBatch(d["depth"], params, d["cam_from_world"], mask=d["mask"], normal=d["normal"], rgb=d["rgb"], device=gpu)
+    clouds = {}
+    for mode in ("first", "probed"):
+        b = dd.CloudBuilder(batch.max_points, normals=True, colors=True, pixel_index=True, device=gpu, placement=mode)
+        assert b.placement.mode == mode, b.placement.as_dict()
+        b.append(batch)
+        clouds[mode] = b.finish()
+        if mode == "probed":
+            cl = b.placement.classes
+            assert cl["points"] != cl["normals"] and len(cl["points"]) == 1 and len(cl["normals"]) == 1, cl
+        del b
+    gc.collect()
+    a, p = clouds["first"], clouds["probed"]
+    assert len(a) == len(p) > 0
+    for f in ("points", "normals", "colors", "pixel_index", "view_offsets"):
+        assert torch.equal(getattr(a, f), getattr(p, f)), f
+
+
+@pytest.mark.gpu
+def test_small_clouds_are_left_alone(gpu):
+    import depthdensifier_amd as dd
+    b = dd.CloudBuilder(1000, normals=True, colors=True, device=gpu)
+    assert b.placement is not None and b.placement.mode.startswith("skipped"), b.placement.as_dict()
+    b2 = dd.CloudBuilder(1000, normals=False, colors=False, device=gpu)
+    assert b2.placement is None

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Round 3: the product's placement (CloudBuilder(placement="probed"), the HBM zone arena) against "first", re-allocated R times
+in one process; then the input stacks moved into the arena's third class as well.  GPU box only.
+usage: placement10.py [rounds] [workload]"""
+import sys, time
+from pathlib import Path
+import numpy as np, torch
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT))
+import bench, depthdensifier_amd as dd
+from depthdensifier_amd import placement as pl
+
+dev = torch.device("cuda", 0)
+wl = sys.argv[2] if len(sys.argv) > 2 else "garden185"
+cfg = dict(bench.WORKLOADS[wl]); cfg["mask_kind"] = "blob"
+V, H, W = cfg["V"], cfg["H"], cfg["W"]
+ids = np.arange(V)
+params = np.tile([0.8 * W, 0.8 * W, W / 2.0, H / 2.0], (V, 1))
+E = bench.ring_poses(ids, V)
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+
+
+def time_it(batch, builder, n=10, warm=3):
+    for _ in range(warm):
+        builder.reset(); builder.append(batch)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        builder.reset()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); builder.append(batch); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts))
+
+
+def mk_batch(sc):
+    return dd.ViewBatch(sc["depth"], params, E, mask=sc["mask"], normal=sc["normal"], rgb=sc["rgb"], conf=sc.get("conf"),
+                        conf_threshold=cfg.get("conf"), device=dev)
+
+
+scene = bench.make_scene(cfg, ids, dev)
+batch = mk_batch(scene)
+P = batch.max_points
+print(f"{wl}: {V} views, cloud capacity {P} rows", flush=True)
+for r in range(R):
+    for mode in ("first", "probed"):
+        t0 = time.perf_counter()
+        b = dd.CloudBuilder(P, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=False, device=dev, placement=mode)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        t = time_it(batch, b)
+        rep = b.placement.as_dict() if b.placement is not None else None
+        print(f"round {r} {mode:7s}: kernel {t:.3f} ms   builder {dt:.2f} s   {rep}", flush=True)
+        if mode == "probed" and r == 0 and b.placement is not None and b.placement.mode == "probed":
+            n0 = b.cloud_check() if hasattr(b, "cloud_check") else None
+            a = pl.get_arena(dev)
+            print(f"   probe points|normals {a.probe_ms(b.xyz, b.normal):.4f} ms; points|points+half {a.probe_ms(b.xyz, b.xyz[P // 2:]):.4f} ms", flush=True)
+        del b
+        torch.cuda.empty_cache()
+    ballast = torch.empty((r + 1) * 3 * 2**30, dtype=torch.uint8, device=dev)      # the next round starts somewhere else
+del ballast
+if cfg["normal"]:
+    print("inputs moved into the arena (all in the group of the colours = the class neither points nor normals use):", flush=True)
+    b = dd.CloudBuilder(P, normals=True, colors=cfg["rgb"], pixel_index=False, device=dev, placement="probed")
+    t_before = time_it(batch, b)
+    specs = {k: (tuple(v.shape), torch.uint8 if v.dtype == torch.bool else v.dtype, pl.GROUP_OTHER) for k, v in scene.items() if v is not None}
+    placed, rep = pl.place_arrays(specs, dev)
+    for k, v in placed.items():
+        v.copy_(scene[k].view(torch.uint8) if scene[k].dtype == torch.bool else scene[k])
+    sc2 = {k: (placed[k].view(torch.bool) if (k in placed and scene[k].dtype == torch.bool) else placed.get(k)) for k in scene}
+    t_after = time_it(mk_batch(sc2), b)
+    print(f"   kernel {t_before:.3f} -> {t_after:.3f} ms   {rep.as_dict()}", flush=True)
