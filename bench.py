@@ -7,9 +7,11 @@ One "step" = one pass of the hot path (cull + unproject + cam->world + stable co
 fuse) over one batch of synthetic views already resident in HBM.  At N=1 the workload is
 BASELINE.json configs[1] ("garden": 185 views, 1920x1080, depth f32 + normal f32x3 + mask u8
 + rgb u8x3; synthetic stand-in).  For N>1 the driver launches one rank per GPU
-(torch.distributed.run); every rank densifies its own 185-view shard of a 185*N-view scene
-(weak scaling; views are independent) and the fuse step exchanges the per-view
-counts (RCCL all-gather) so every rank holds the global view offsets of the distributed cloud.
+(torch.distributed.run) and the default workload is BASELINE configs[2], the north-star curve: the
+2000-view 1080p scene split over the N ranks in contiguous shards (strong scaling; views are
+independent), `value` = the sharded fuse (fused kernel + RCCL all-gather of the per-view
+counts: every rank holds the global view offsets of the distributed cloud); `--workload garden185` at
+N>1 is the weak-scaling variant (185 views per rank).
 Every line, at every N, also carries a "strong2000" sub-record: BASELINE configs[2], the 2000-view
 1080p scene split over the N ranks (strong scaling), timed three ways -- sharded fuse (count
 exchange only), replicated fuse in place (all-gatherv of xyz + normals + colours, 27 B/point) and
@@ -183,6 +185,49 @@ def cpu_baseline(cfg: dict, scene: dict, params: np.ndarray, E: np.ndarray, budg
     }
 
 
+def verify_views(dd, cfg: dict, scene: dict, params: np.ndarray, E: np.ndarray, views, offsets: torch.Tensor, cloud: dict, device,
+                 view_index_base: int = 0) -> dict:
+    """The timed cloud against the oracle (scripts/test.py:194-266 restated in NumPy) on the given local views: per-view counts
+    bit-exact; rows of the timed cloud equal to an untimed pass that also emits pixel_index (same kernel, one more output);
+    pixel_index order, colours and pass-through normals bit-exact against the oracle; xyz within 1e-4 of the scene scale
+    (SURVEY.md 8d).  Raises AssertionError on any mismatch."""
+    from oracle import densify_oracle as orc          # checker only, never the product path
+    offs = offsets.cpu().numpy()
+    worst, n_pts = 0.0, 0
+    for i in views:
+        d = scene["depth"][i].cpu().numpy()
+        m = None if scene["mask"] is None else scene["mask"][i].cpu().numpy()
+        nm = None if scene["normal"] is None else scene["normal"][i].cpu().numpy()
+        c = None if scene["rgb"] is None else scene["rgb"][i].cpu().numpy()
+        cf = None if scene.get("conf") is None else scene["conf"][i].cpu().numpy()
+        ref = orc.fuse_views([orc.densify_view_script(d, params[i], E[i], mask=m, normal=nm, rgb=c, conf=cf, conf_threshold=cfg.get("conf"))])
+        lo, hi = int(offs[i]), int(offs[i + 1])
+        assert hi - lo == len(ref.points), f"view {i}: {hi - lo} points, oracle {len(ref.points)}"
+        # an untimed pass of this one view with pixel_index on: the rows must be the timed cloud's rows
+        vb = dd.ViewBatch(scene["depth"][i:i + 1], params[i:i + 1], E[i:i + 1], mask=None if scene["mask"] is None else scene["mask"][i:i + 1],
+                          normal=None if scene["normal"] is None else scene["normal"][i:i + 1], rgb=None if scene["rgb"] is None else scene["rgb"][i:i + 1],
+                          conf=None if scene.get("conf") is None else scene["conf"][i:i + 1], conf_threshold=cfg.get("conf"), device=device)
+        b = dd.CloudBuilder(vb.max_points, normals=nm is not None, colors=c is not None, pixel_index=True, device=device, placement="first")
+        b.append(vb)
+        one = b.finish()
+        assert np.array_equal(one.pixel_index.cpu().numpy(), ref.pixel_index), f"view {i}: pixel_index order differs from the oracle"
+        for name, timed, again in (("points", cloud["points"], one.points), ("normals", cloud.get("normals"), one.normals), ("colors", cloud.get("colors"), one.colors)):
+            if timed is not None:
+                assert torch.equal(timed[lo:hi], again), f"view {i}: {name} of the timed cloud differ from the untimed pass"
+        if c is not None:
+            assert np.array_equal(one.colors.cpu().numpy(), ref.colors), f"view {i}: colours differ from the oracle"
+        if nm is not None:
+            assert np.array_equal(one.normals.cpu().numpy(), ref.normals), f"view {i}: normals differ from the oracle"
+        if len(ref.points):
+            scale = np.abs(ref.points).max()
+            err = float(np.abs(one.points.cpu().numpy().astype(np.float64) - ref.points).max() / scale)
+            assert err <= 1e-4, f"view {i}: xyz relative error {err:.3e} > 1e-4"
+            worst = max(worst, err)
+        n_pts += hi - lo
+    return {"views": len(list(views)), "points": n_pts, "xyz_max_rel": float(f"{worst:.3e}"), "tolerance": 1e-4,
+            "bit_exact": "per-view counts, pixel_index order, colours, pass-through normals; timed rows == untimed re-run"}
+
+
 def strong_scaling_record(args, dd, D, dist, use_dist, rank, world, device, fence) -> dict:
     """BASELINE configs[2] on the N ranks of this job: `--strong-views` (2000) synthetic 1080p views, rank r holds the
     contiguous shard shard_views(V, N, r), inputs resident in HBM.  Timed three ways (max over ranks, mean of the timed
@@ -222,7 +267,8 @@ def strong_scaling_record(args, dd, D, dist, use_dist, rank, world, device, fenc
         return dt, out
 
     # -- sharded fuse: the cloud stays distributed; max capacity, no sizing pass
-    builder = dd.CloudBuilder(batch.max_points, normals=True, colors=True, pixel_index=False, device=device)
+    builder = dd.CloudBuilder(batch.max_points, normals=True, colors=True, pixel_index=False, device=device, placement=args.placement)
+    rec["placement"] = None if builder.placement is None else builder.placement.mode
 
     def sharded():
         builder.reset()
@@ -232,6 +278,19 @@ def strong_scaling_record(args, dd, D, dist, use_dist, rank, world, device, fenc
 
     dt, goffs = timed(sharded, args.strong_steps)
     builder.check()
+    if len(ids) and not args.no_verify:      # the last view of this rank's shard of the TIMED cloud against the oracle
+        try:
+            local_offs = builder._offsets[-1]
+            v = verify_views(dd, cfg, scene, params, ring_poses(ids, V_total), [len(ids) - 1], local_offs,
+                             {"points": builder.xyz, "normals": builder.normal, "colors": builder.rgb}, device)
+            ok = 1
+        except AssertionError as e:
+            v, ok = {"error": str(e)[:300]}, 0
+        if use_dist:
+            flag = torch.tensor([ok], dtype=torch.int64, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        rec["verified"] = dict(v, what="last view of every rank's shard of the timed sharded cloud vs the oracle", all_ranks_ok=bool(ok))
     n_total = int(goffs[-1].item())
     n_own = int((goffs[hi] - goffs[lo]).item())
     pixels = V_total * H * W
@@ -397,7 +456,15 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="garden185", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: garden185 at N = 1 (BASELINE configs[1]), scene2000 at N > 1 (configs[2], strong scaling)")
+    ap.add_argument("--placement", default="probed", choices=("probed", "first"),
+                    help="probed: the cloud's points / normals / colours built from different classes of HBM address ranges (the arena of "
+                         "depthdensifier_amd/placement.py); first: as the allocator returns them (rounds 1-2)")
+    ap.add_argument("--alloc-rounds", type=int, default=5, help="fresh allocations of the cloud the kernel is re-timed on (roofline.frac_min / median / max); 0 = skip")
+    ap.add_argument("--no-verify", action="store_true", help="skip the comparison of the timed cloud with the oracle")
+    ap.add_argument("--verify-views", type=int, default=4, help="leading views of the timed cloud compared with the oracle (the last view is always added)")
+    ap.add_argument("--n1-strong-mpix", type=float, default=0.0, help="N = 1 strong2000 sharded Mpixels/s of an earlier run: speedup_vs_n1 is computed against it")
     ap.add_argument("--views", type=int, default=0, help="override views per GPU (garden185) / total views (scene2000)")
     ap.add_argument("--pixel-index", action="store_true", help="also emit the int32 pixel index per point")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
@@ -423,6 +490,10 @@ def main() -> None:
             sys.exit("bench.py --gpus N>1 must be launched with: python -m torch.distributed.run --nnodes=1 "
                      "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         args.gpus = world
+    if args.workload is None:
+        args.workload = "garden185" if world == 1 else "scene2000"
+    if os.environ.get("DD_BENCH_SHARE_GPU") == "1":
+        args.placement = "first"         # rehearsal ranks share one GPU: no scouting of its memory by several processes at once
     real_out = _claim_stdout()
     guard = None
     if rank == 0 and args.strong_views > 0 and (world > 1 or os.environ.get("DD_BENCH_FORCE_DIST") == "1"):
@@ -514,7 +585,7 @@ def main() -> None:
         # capacity = every visited pixel: no sizing pass exists anywhere, timed or not (SURVEY.md 8d defines the metric over
         # count + scan + unproject + compact, which the fused kernel does in its one pass)
         builder = dd.CloudBuilder(batch.max_points, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index,
-                                  device=device)
+                                  device=device, placement=args.placement)
 
     ev = []
     state = {"plan": None}
@@ -529,7 +600,8 @@ def main() -> None:
             e[0].record()
         n = 0
         for b in batches:
-            cloud = dd.CloudBuilder(b.max_points, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index, device=device)
+            cloud = dd.CloudBuilder(b.max_points, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index, device=device,
+                                    placement="first")       # a fresh cloud per scene inside the timed region: no probing there
             cloud.append(b)
             n += cloud.check()
             del cloud
@@ -604,6 +676,53 @@ def main() -> None:
     if single_pass:
         plan_ms = 0.0
 
+    # ---- the timed cloud against the oracle (untimed; every rank checks views of its own shard)
+    verified = None
+    if not multi and not args.no_verify and V > 0:
+        views = sorted(set(list(range(min(V, args.verify_views))) + [V - 1]))
+        try:
+            verified = verify_views(dd, cfg, scene, params, E, views, builder._offsets[-1],
+                                    {"points": builder.xyz, "normals": builder.normal, "colors": builder.rgb}, device, lo)
+            ok = 1
+        except AssertionError as e:
+            verified, ok = {"error": str(e)[:300]}, 0
+        if use_dist:
+            flag = torch.tensor([ok], dtype=torch.int64, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        verified["all_ranks_ok"] = bool(ok)
+        verified["what"] = "rows of the TIMED cloud (last timed step) vs oracle/densify_oracle.py on this rank's first views and its last one"
+
+    # ---- the same kernel on fresh allocations of the cloud (the placement of the output arrays is the one thing that moves it)
+    alloc_ms = []
+    if not multi and single_pass and args.alloc_rounds > 0 and V > 0:
+        keep = []
+        for r in range(args.alloc_rounds):
+            b2 = dd.CloudBuilder(batch.max_points, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index, device=device,
+                                 placement=args.placement)
+            for _ in range(2):
+                b2.reset(); b2.append(batch)
+            ts = []
+            for _ in range(5):
+                b2.reset()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); b2.append(batch); e1.record()
+                torch.cuda.synchronize(device)
+                ts.append(e0.elapsed_time(e1))
+            alloc_ms.append(float(np.median(ts)))
+            if args.placement == "first":
+                keep.append(torch.empty((r + 1) << 30, dtype=torch.uint8, device=device))    # the next allocation starts elsewhere
+            del b2
+            torch.cuda.empty_cache()
+        del keep
+
+    devices = None
+    if use_dist:
+        props_r = torch.cuda.get_device_properties(device)
+        mine = f"rank {rank}: {torch.cuda.get_device_name(device)} pci {getattr(props_r, 'pci_bus_id', 0):02x}:{getattr(props_r, 'pci_device_id', 0):02x} uuid {getattr(props_r, 'uuid', '?')}"
+        devices = [None] * world
+        dist.all_gather_object(devices, mine)
+
     if rank == 0:
         props = torch.cuda.get_device_properties(device)
         ms_per_step = elapsed / args.steps * 1e3
@@ -661,6 +780,24 @@ def main() -> None:
                          "pass1_note": "two-pass mode only: count_lean + scan kernels re-read depth+mask (not credited)",
                          "whole_step_frac": round(alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
         }
+        rf = line["roofline"]
+        rf["placement"] = args.placement if (builder is not None and builder.placement is not None and builder.placement.mode == "probed") else \
+            ("first" if builder is None or builder.placement is None else builder.placement.mode)
+        rf["placement_report"] = None if builder is None or builder.placement is None else builder.placement.as_dict()
+        if alloc_ms:
+            fr = [alg / (t * 1e-3) / 1e9 / HBM_PEAK_GBPS for t in alloc_ms]
+            rf.update({"frac_min": round(min(fr), 4), "frac_median": round(float(np.median(fr)), 4), "frac_max": round(max(fr), 4),
+                       "alloc_rounds": len(fr), "kernel_ms_per_allocation": [round(t, 4) for t in alloc_ms],
+                       "frac_note": "frac is the driver's timed run; frac_min / median / max re-time the same kernel on this many FRESH allocations "
+                                    "of the cloud in the same process (placement as above), median of 5 launches each"})
+        if verified is not None:
+            line["verified"] = verified
+        if devices is not None:
+            line["devices"] = devices
+            line["rccl_world_size"] = dist.get_world_size()
+            line["collective_backend"] = dist.get_backend()
+        if strong and args.n1_strong_mpix > 0:
+            line["speedup_vs_n1"] = round(line["value"] / args.n1_strong_mpix, 3)
         if multi:
             line["config"]["rank0_scenes"] = cfg_scenes["scenes"]
             line["roofline"]["kernel"] += f"; {len(batches)} launches, the events also bracket the per-scene allocation and host read"
@@ -718,9 +855,14 @@ def main() -> None:
         print(json.dumps(line), file=real_out, flush=True)
         _release_line_guard(guard)
 
+    failed = verified is not None and not verified.get("all_ranks_ok", True)
+    if isinstance(strong, dict) and isinstance(strong.get("verified"), dict) and not strong["verified"].get("all_ranks_ok", True):
+        failed = True
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        sys.exit("bench.py: the timed cloud does NOT match the oracle (see the \"verified\" records of the line)")
 
 
 if __name__ == "__main__":

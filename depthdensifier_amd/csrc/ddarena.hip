@@ -9,6 +9,14 @@
 // all its memory from one end of the device, i.e. from one class.  The relation is an equivalence (pairwise table in
 // profiles/r03_zone_probe.txt), so a chunk's class is found by timing it against one anchor chunk per class.
 //
+// Measured and NOT adopted (profiles/r03_zone_interleave.txt): arrays whose consecutive 32-64 MiB pieces alternate between the
+// three classes serve even a SINGLE row-store stream at 7.1 instead of 5.7-6.0 TB/s (128 MiB pieces: 6.6-7.0), which would
+// lift the xyz-only workloads as well.  But hipMemMap takes no offset into a handle on this runtime, so every piece must be
+// a handle of its own; pieces that small cannot be timed alone, and runs of consecutively created small handles are pure
+// only on an untouched device -- after torch has allocated and freed they are mixtures (profiles/
+// r03_arena_runs_of_32MiB_pieces_are_mixed_after_torch.txt), and re-mapping scouting ranges piece by piece makes
+// hipMemSetAccess fail intermittently.  Handles of 1 GiB always come from ONE class, in every process state seen.
+//
 // What it does.  Physical memory is taken in chunks (default 1 GiB) through the virtual-memory API (hipMemCreate), every
 // new chunk is mapped into a scouting range and classified with the two-stream store probe below against the anchors;
 // an allocation request names a GROUP per array, arrays of different groups are built from chunks of different classes
@@ -20,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -100,6 +109,7 @@ struct DDArena {
     std::mutex mu;
     // statistics
     int64_t created, released, probes;
+    bool debug;                 // DD_ARENA_DEBUG: one line per classified chunk on stderr
     double seconds;
     int32_t degraded;           // allocations that could not be given distinct classes
 };
@@ -187,6 +197,7 @@ int scout_one(DDArena *A, int *chunk_out) {
         if ((rc = probe_pair(A, w, reinterpret_cast<float *>(slot_ptr(A, slot) + A->chunk / 2), &ms)) != DD_OK) return rc;
         A->same_ms = ms;
         A->fast_ms = ms;
+        if (A->debug) fprintf(stderr, "[ddarena] chunk %d: the first, its two halves %.4f ms -> anchor of class 0\n", ci, ms);
         A->chunks[ci].cls = 0;
         A->chunks[ci].anchor = true;
         A->anchors[0] = ci;
@@ -214,6 +225,11 @@ int scout_one(DDArena *A, int *chunk_out) {
         }
     }
     A->chunks[ci].cls = cls;
+    if (A->debug) {
+        fprintf(stderr, "[ddarena] chunk %d:", ci);
+        for (int k = 0; k < A->n_classes; ++k) if (A->anchors[k] != ci) fprintf(stderr, " vs anchor %d %.4f ms", k, t[k]);
+        fprintf(stderr, " -> class %d%s   (same %.4f, fast %.4f)\n", cls, A->chunks[ci].anchor ? " (its anchor)" : "", A->same_ms, A->fast_ms);
+    }
     *chunk_out = ci;
     return DD_OK;
 }
@@ -274,6 +290,7 @@ int dd_arena_create(int32_t device, int64_t chunk_bytes, DDArena **arena_out) {
     A->n_classes = 0;
     A->same_ms = A->fast_ms = 0.f;
     A->created = A->released = A->probes = 0;
+    A->debug = getenv("DD_ARENA_DEBUG") != nullptr;
     A->seconds = 0.0;
     A->degraded = 0;
     for (int k = 0; k < MAX_CLASSES; ++k) A->anchors[k] = A->group_class[k] = -1;

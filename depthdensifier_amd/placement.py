@@ -103,8 +103,10 @@ class ZoneArena:
         if any(b <= 0 for b in nbytes):
             raise ValueError("arena arrays must not be empty")
         if max_scout_bytes is None:
+            # a class is a third of the memory and an idle device hands out long stretches of one class (64 GiB seen): finding
+            # all three may take a look at ~100 GiB.  Everything scouted and not used is back with the driver when alloc returns.
             free = torch.cuda.mem_get_info(self.device)[0]
-            max_scout_bytes = int(min(64 * GIB, max(0, free - sum(nbytes)) // 2))
+            max_scout_bytes = int(min(128 * GIB, 0.8 * max(0, free - sum(nbytes))))
         sizes = (C.c_int64 * n)(*nbytes)
         groups = (C.c_int32 * n)(*[int(specs[k][2]) for k in names])
         ptrs = (C.c_void_p * n)()

@@ -42,7 +42,7 @@ def _check(line, n_gpus, steps, warmup):
 
 def test_single_gpu_line():
     line = _run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--views", "6", "--strong-views", "8", "--strong-steps", "1",
-                 "--cpu-seconds", "1", "--cpu-procs", "2"])
+                 "--cpu-seconds", "1", "--cpu-procs", "2", "--alloc-rounds", "2"])
     _check(line, 1, 3, 1)
     assert line["scaling"] == "weak" and line["config"]["workload"] == "garden185"
     cpu = line["cpu_baseline"]
@@ -50,18 +50,39 @@ def test_single_gpu_line():
     assert cpu["reference_formulation"]["value"] > 0
     s = line["strong2000"]
     assert s["views_total"] == 8 and all(s[k]["ms"] > 0 for k in ("sharded", "gathered", "gathered_compact")), s
+    # round 3: the timed cloud is checked against the oracle inside the bench, and the kernel is re-timed on fresh allocations
+    v = line["verified"]
+    assert v["all_ranks_ok"] and v["views"] >= 2 and v["points"] > 0 and v["xyz_max_rel"] <= 1e-4, v
+    assert s["verified"]["all_ranks_ok"], s["verified"]
+    r = line["roofline"]
+    assert r["placement"] in ("probed", "first") or r["placement"].startswith(("skipped", "degraded")), r["placement"]
+    assert r["alloc_rounds"] == 2 and r["frac_min"] <= r["frac_median"] <= r["frac_max"] and len(r["kernel_ms_per_allocation"]) == 2
 
 
 def test_two_ranks_sharing_the_gpu():
+    """N > 1: the default workload is the north-star curve (2000-view scene, strong scaling; here 8 views over 2 ranks)."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29655", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--views", "4", "--strong-views", "9",
-           "--strong-steps", "1", "--chunks", "2"]
+           "--master-port", "29655", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--views", "8", "--strong-views", "9",
+           "--strong-steps", "1", "--chunks", "2", "--alloc-rounds", "0", "--n1-strong-mpix", "1000"]
     line = _run(cmd, {"DD_BENCH_SHARE_GPU": "1", "DD_ALLGATHERV": "broadcast"})
     _check(line, 2, 2, 1)
-    assert line["config"]["views_total"] == 8 and "cpu_baseline" not in line
+    assert line["config"]["workload"] == "scene2000" and line["scaling"] == "strong"
+    assert line["config"]["views_total"] == 8 and line["config"]["views_per_gpu"] == 4 and "cpu_baseline" not in line
+    assert len(line["devices"]) == 2 and all(d.startswith(f"rank {i}:") for i, d in enumerate(line["devices"])) and line["rccl_world_size"] == 2
+    assert line["speedup_vs_n1"] == round(line["value"] / 1000, 3)
+    assert line["verified"]["all_ranks_ok"], line["verified"]
     s = line["strong2000"]
     assert s["views_per_gpu"] in (4, 5) and all(s[k]["ms"] > 0 for k in ("sharded", "gathered", "gathered_compact")), s
-    assert s["gathered"]["bytes_received_per_rank"] > 0
+    assert s["gathered"]["bytes_received_per_rank"] > 0 and s["verified"]["all_ranks_ok"]
+
+
+def test_weak_scaling_variant_still_runs_on_two_ranks():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29657", "bench.py", "--gpus", "2", "--workload", "garden185", "--steps", "2", "--warmup", "1", "--views", "4",
+           "--strong-views", "0", "--alloc-rounds", "0"]
+    line = _run(cmd, {"DD_BENCH_SHARE_GPU": "1"})
+    _check(line, 2, 2, 1)
+    assert line["scaling"] == "weak" and line["config"]["views_total"] == 8 and line["verified"]["all_ranks_ok"]
 
 
 def test_scene_set_workload_on_three_ranks():

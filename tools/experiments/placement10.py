@@ -43,30 +43,20 @@ batch = mk_batch(scene)
 P = batch.max_points
 print(f"{wl}: {V} views, cloud capacity {P} rows", flush=True)
 for r in range(R):
-    for mode in ("first", "probed"):
+    for mode, layout in (("first", ""), ("probed", "separated"), ("probed", "interleaved")):
+        import os
+        os.environ["DD_PLACEMENT_LAYOUT"] = layout
         t0 = time.perf_counter()
         b = dd.CloudBuilder(P, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=False, device=dev, placement=mode)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         t = time_it(batch, b)
         rep = b.placement.as_dict() if b.placement is not None else None
-        print(f"round {r} {mode:7s}: kernel {t:.3f} ms   builder {dt:.2f} s   {rep}", flush=True)
-        if mode == "probed" and r == 0 and b.placement is not None and b.placement.mode == "probed":
-            n0 = b.cloud_check() if hasattr(b, "cloud_check") else None
-            a = pl.get_arena(dev)
-            print(f"   probe points|normals {a.probe_ms(b.xyz, b.normal):.4f} ms; points|points+half {a.probe_ms(b.xyz, b.xyz[P // 2:]):.4f} ms", flush=True)
+        alg = bench.algorithmic_bytes(cfg, V, int(b.cursor.item()), False)
+        print(f"round {r} {mode:7s} {layout:11s}: kernel {t:.3f} ms  frac {alg / t / 1e6 / 8000:.3f}   builder {dt:.2f} s   {rep}", flush=True)
+        if rep is not None:
+            pass
         del b
         torch.cuda.empty_cache()
     ballast = torch.empty((r + 1) * 3 * 2**30, dtype=torch.uint8, device=dev)      # the next round starts somewhere else
-del ballast
-if cfg["normal"]:
-    print("inputs moved into the arena (all in the group of the colours = the class neither points nor normals use):", flush=True)
-    b = dd.CloudBuilder(P, normals=True, colors=cfg["rgb"], pixel_index=False, device=dev, placement="probed")
-    t_before = time_it(batch, b)
-    specs = {k: (tuple(v.shape), torch.uint8 if v.dtype == torch.bool else v.dtype, pl.GROUP_OTHER) for k, v in scene.items() if v is not None}
-    placed, rep = pl.place_arrays(specs, dev)
-    for k, v in placed.items():
-        v.copy_(scene[k].view(torch.uint8) if scene[k].dtype == torch.bool else scene[k])
-    sc2 = {k: (placed[k].view(torch.bool) if (k in placed and scene[k].dtype == torch.bool) else placed.get(k)) for k in scene}
-    t_after = time_it(mk_batch(sc2), b)
-    print(f"   kernel {t_before:.3f} -> {t_after:.3f} ms   {rep.as_dict()}", flush=True)
+print(pl.get_arena(dev).stats(), flush=True)
