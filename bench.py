@@ -697,7 +697,9 @@ def main() -> None:
     alloc_ms = []
     if not multi and single_pass and args.alloc_rounds > 0 and V > 0:
         keep = []
+        from depthdensifier_amd import placement as _pl
         for r in range(args.alloc_rounds):
+            _pl.trim(device)              # no spare chunks from the last round: every round scouts the device's memory anew
             b2 = dd.CloudBuilder(batch.max_points, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index, device=device,
                                  placement=args.placement)
             for _ in range(2):

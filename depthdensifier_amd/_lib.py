@@ -55,6 +55,7 @@ EXPORTS = (
     "dd_arena_create",
     "dd_arena_alloc",
     "dd_arena_free",
+    "dd_arena_trim",
     "dd_arena_classes",
     "dd_arena_probe",
     "dd_arena_stats",
@@ -116,6 +117,9 @@ class DDFilterViews(C.Structure):
     ]
 
 
+DD_ARENA_ROTATED = 8
+
+
 class DDArenaStats(C.Structure):
     _fields_ = [
         ("chunk_bytes", C.c_int64),
@@ -126,6 +130,7 @@ class DDArenaStats(C.Structure):
         ("chunks_released", C.c_int64),
         ("probes", C.c_int64),
         ("chunks_held", C.c_int64 * 3),
+        ("chunks_pooled", C.c_int64 * 3),
         ("same_class_ms", C.c_float),
         ("cross_class_ms", C.c_float),
         ("seconds", C.c_double),
@@ -198,6 +203,8 @@ def _load() -> C.CDLL:
     lib.dd_arena_alloc.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_void_p)]
     lib.dd_arena_free.restype = C.c_int
     lib.dd_arena_free.argtypes = [C.c_void_p, C.c_void_p]
+    lib.dd_arena_trim.restype = C.c_int
+    lib.dd_arena_trim.argtypes = [C.c_void_p, C.c_int32]
     lib.dd_arena_classes.restype = C.c_int
     lib.dd_arena_classes.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int32]
     lib.dd_arena_probe.restype = C.c_int

@@ -110,6 +110,8 @@ struct DDArena {
     // statistics
     int64_t created, released, probes;
     bool debug;                 // DD_ARENA_DEBUG: one line per classified chunk on stderr
+    int pool_per_class;         // classified chunks of each class kept (unmapped) when arrays are freed or scouting leaves
+                                // spares, so that the next allocation need not scout again; dd_arena_trim gives them back
     double seconds;
     int32_t degraded;           // allocations that could not be given distinct classes
 };
@@ -234,6 +236,23 @@ int scout_one(DDArena *A, int *chunk_out) {
     return DD_OK;
 }
 
+// a chunk nobody uses: into the pool (unmapped, its class remembered) while the pool of its class has room, else to the driver
+int pool_or_release(DDArena *A, int ci) {
+    Chunk &c = A->chunks[ci];
+    if (!c.live || c.used || c.anchor) return DD_OK;
+    int pooled = 0;
+    for (const Chunk &o : A->chunks) if (o.live && !o.used && !o.anchor && o.slot < 0 && o.cls == c.cls) ++pooled;
+    if (c.cls >= 0 && pooled < A->pool_per_class) {
+        if (c.slot >= 0) {
+            AHIP(hipMemUnmap(slot_ptr(A, c.slot), A->chunk), "hipMemUnmap(scout)");
+            A->slot_owner[c.slot] = -1;
+            c.slot = -1;
+        }
+        return DD_OK;
+    }
+    return release_chunk(A, ci);
+}
+
 int free_count(const DDArena *A, int cls) {
     int n = 0;
     for (const Chunk &c : A->chunks) if (c.live && !c.used && !c.anchor && c.cls == cls) ++n;
@@ -242,7 +261,8 @@ int free_count(const DDArena *A, int cls) {
 
 // best assignment of groups to classes for the chunks at hand: maximise the chunks served from a group's own class;
 // groups that were given a class by an earlier call keep it
-int best_assignment(const DDArena *A, const int need[MAX_CLASSES], int perm_out[MAX_CLASSES]) {
+// (`fixed[c]`: chunks the rotated arrays of the request want from class c, whatever the assignment)
+int best_assignment(const DDArena *A, const int need[MAX_CLASSES], const int fixed[MAX_CLASSES], int perm_out[MAX_CLASSES]) {
     int avail[MAX_CLASSES];
     for (int k = 0; k < MAX_CLASSES; ++k) avail[k] = free_count(A, k);
     int p[MAX_CLASSES] = {0, 1, 2}, best = -1;
@@ -250,8 +270,11 @@ int best_assignment(const DDArena *A, const int need[MAX_CLASSES], int perm_out[
         bool ok = true;
         for (int g = 0; g < MAX_CLASSES; ++g) if (A->group_class[g] >= 0 && A->group_class[g] != p[g]) ok = false;
         if (!ok) continue;
+        int want[MAX_CLASSES];
+        for (int c = 0; c < MAX_CLASSES; ++c) want[c] = fixed[c];
+        for (int g = 0; g < MAX_CLASSES; ++g) want[p[g]] += need[g];
         int served = 0;
-        for (int g = 0; g < MAX_CLASSES; ++g) served += std::min(need[g], avail[p[g]]);
+        for (int c = 0; c < MAX_CLASSES; ++c) served += std::min(want[c], avail[c]);
         if (served > best) { best = served; memcpy(perm_out, p, sizeof(p)); }
     } while (std::next_permutation(p, p + MAX_CLASSES));
     return best;
@@ -291,6 +314,7 @@ int dd_arena_create(int32_t device, int64_t chunk_bytes, DDArena **arena_out) {
     A->same_ms = A->fast_ms = 0.f;
     A->created = A->released = A->probes = 0;
     A->debug = getenv("DD_ARENA_DEBUG") != nullptr;
+    A->pool_per_class = 4;
     A->seconds = 0.0;
     A->degraded = 0;
     for (int k = 0; k < MAX_CLASSES; ++k) A->anchors[k] = A->group_class[k] = -1;
@@ -323,13 +347,16 @@ int dd_arena_alloc(DDArena *A, int32_t n, const int64_t *sizes, const int32_t *g
     if (!A || !sizes || !groups || !ptrs_out || n <= 0 || n > 64) return afail(DD_ERR_INVALID_ARG, "arena / sizes / groups / ptrs_out is NULL or n outside 1..64");
     std::lock_guard<std::mutex> lock(A->mu);
     const double t_start = now_s();
-    int need[MAX_CLASSES] = {0, 0, 0};
+    int need[MAX_CLASSES] = {0, 0, 0}, fixed[MAX_CLASSES] = {0, 0, 0};
     std::vector<int> nch(n);
     for (int i = 0; i < n; ++i) {
         if (sizes[i] <= 0) return afail(DD_ERR_INVALID_ARG, "sizes must be positive");
-        if (groups[i] < 0 || groups[i] >= MAX_CLASSES) return afail(DD_ERR_INVALID_ARG, "groups must be 0, 1 or 2");
+        const int L = groups[i];
+        const bool pure = L >= 0 && L < MAX_CLASSES, rotated = L >= DD_ARENA_ROTATED && L < DD_ARENA_ROTATED + MAX_CLASSES;
+        if (!pure && !rotated) return afail(DD_ERR_INVALID_ARG, "layouts must be a group 0..2 or DD_ARENA_ROTATED + phase 0..2");
         nch[i] = (int)(((size_t)sizes[i] + A->chunk - 1) / A->chunk);
-        need[groups[i]] += nch[i];
+        if (pure) need[L] += nch[i];
+        else for (int k = 0; k < nch[i]; ++k) fixed[(L - DD_ARENA_ROTATED + k) % MAX_CLASSES] += 1;
         ptrs_out[i] = nullptr;
     }
     int prev = 0;
@@ -337,14 +364,14 @@ int dd_arena_alloc(DDArena *A, int32_t n, const int64_t *sizes, const int32_t *g
     AHIP(hipSetDevice(A->device), "hipSetDevice");
     struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{prev};
     AHIP(hipDeviceSynchronize(), "hipDeviceSynchronize");          // probes are timed: nothing else should be running
-    const int total_need = need[0] + need[1] + need[2];
+    const int total_need = need[0] + need[1] + need[2] + fixed[0] + fixed[1] + fixed[2];
     int perm[MAX_CLASSES] = {0, 1, 2};
     int64_t scouted = 0;
     bool oom = false;
     int rc = DD_OK;
     // scout until every group can be served from a class of its own, or the budget / the memory is spent
     for (;;) {
-        if (best_assignment(A, need, perm) >= total_need) break;
+        if (best_assignment(A, need, fixed, perm) >= total_need) break;
         if (oom) break;
         int live_free = 0;
         for (const Chunk &c : A->chunks) if (c.live && !c.used && !c.anchor) ++live_free;
@@ -358,14 +385,15 @@ int dd_arena_alloc(DDArena *A, int32_t n, const int64_t *sizes, const int32_t *g
             scouted += (int64_t)A->chunk;
         }
     }
-    best_assignment(A, need, perm);
+    best_assignment(A, need, fixed, perm);
     for (int g = 0; g < MAX_CLASSES; ++g) if (need[g] > 0) A->group_class[g] = perm[g];
     // choose the chunks: own class first, then whatever is left (degraded)
     std::vector<std::vector<int>> chosen(n);
     bool degraded = false;
     for (int i = 0; i < n && rc == DD_OK; ++i) {
         for (int k = 0; k < nch[i]; ++k) {
-            int ci = take_chunk(A, perm[groups[i]]);
+            const int L = groups[i];
+            int ci = take_chunk(A, L < MAX_CLASSES ? perm[L] : (L - DD_ARENA_ROTATED + k) % MAX_CLASSES);
             if (ci < 0) {
                 degraded = true;
                 for (int c2 = 0; c2 < MAX_CLASSES && ci < 0; ++c2) ci = take_chunk(A, c2);
@@ -392,9 +420,11 @@ int dd_arena_alloc(DDArena *A, int32_t n, const int64_t *sizes, const int32_t *g
         AHIP(hipMemAddressReserve(reinterpret_cast<void **>(&m.va), m.bytes, 0, nullptr, 0), "hipMemAddressReserve(array)");
         for (int k = 0; k < nch[i]; ++k) {
             Chunk &c = A->chunks[chosen[i][k]];
-            AHIP(hipMemUnmap(slot_ptr(A, c.slot), A->chunk), "hipMemUnmap(scout)");
-            A->slot_owner[c.slot] = -1;
-            c.slot = -1;
+            if (c.slot >= 0) {              // fresh from scouting (a pooled chunk is not mapped anywhere)
+                AHIP(hipMemUnmap(slot_ptr(A, c.slot), A->chunk), "hipMemUnmap(scout)");
+                A->slot_owner[c.slot] = -1;
+                c.slot = -1;
+            }
             AHIP(hipMemMap(m.va + (size_t)k * A->chunk, A->chunk, 0, c.h, 0), "hipMemMap(array)");
         }
         AHIP(hipMemSetAccess(m.va, m.bytes, &acc, 1), "hipMemSetAccess(array)");
@@ -402,10 +432,10 @@ int dd_arena_alloc(DDArena *A, int32_t n, const int64_t *sizes, const int32_t *g
         A->maps.push_back(m);
         ptrs_out[i] = m.va;
     }
-    // what was scouted and not needed goes back to the driver (the anchors stay)
+    // what was scouted and not needed goes back to the driver, but for a few spares per class (the anchors stay)
     for (size_t ci = 0; ci < A->chunks.size(); ++ci)
         if (A->chunks[ci].live && !A->chunks[ci].used && !A->chunks[ci].anchor) {
-            if ((rc = release_chunk(A, (int)ci)) != DD_OK) return rc;
+            if ((rc = pool_or_release(A, (int)ci)) != DD_OK) return rc;
         }
     if (degraded) A->degraded += 1;
     A->seconds += now_s() - t_start;
@@ -426,16 +456,32 @@ int dd_arena_free(DDArena *A, void *ptr) {
         A->maps.erase(A->maps.begin() + (long)i);
         AHIP(hipMemUnmap(m.va, m.bytes), "hipMemUnmap(array)");
         for (int ci : m.chunks) {
-            Chunk &c = A->chunks[ci];
-            c.used = false;
-            AHIP(hipMemRelease(c.h), "hipMemRelease");
-            c.live = false;
-            A->released += 1;
+            A->chunks[ci].used = false;
+            int rc = pool_or_release(A, ci);
+            if (rc != DD_OK) return rc;
         }
         AHIP(hipMemAddressFree(m.va, m.bytes), "hipMemAddressFree(array)");
         return DD_OK;
     }
     return afail(DD_ERR_INVALID_ARG, "ptr was not allocated by this arena");
+}
+
+int dd_arena_trim(DDArena *A, int32_t pool_chunks_per_class) {
+    if (!A) return afail(DD_ERR_INVALID_ARG, "arena is NULL");
+    std::lock_guard<std::mutex> lock(A->mu);
+    if (pool_chunks_per_class >= 0) A->pool_per_class = pool_chunks_per_class;
+    int prev = 0;
+    AHIP(hipGetDevice(&prev), "hipGetDevice");
+    AHIP(hipSetDevice(A->device), "hipSetDevice");
+    struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{prev};
+    for (size_t ci = 0; ci < A->chunks.size(); ++ci) {
+        Chunk &c = A->chunks[ci];
+        if (c.live && !c.used && !c.anchor) {
+            int rc = release_chunk(A, (int)ci);
+            if (rc != DD_OK) return rc;
+        }
+    }
+    return DD_OK;
 }
 
 int dd_arena_classes(DDArena *A, const void *ptr, int32_t *classes_out, int32_t capacity) {
@@ -476,7 +522,10 @@ int dd_arena_stats(DDArena *A, DDArenaStats *out) {
     out->seconds = A->seconds;
     out->degraded_allocs = A->degraded;
     for (const Chunk &c : A->chunks)
-        if (c.live && c.cls >= 0 && c.cls < MAX_CLASSES) out->chunks_held[c.cls] += 1;
+        if (c.live && c.cls >= 0 && c.cls < MAX_CLASSES) {
+            out->chunks_held[c.cls] += 1;
+            if (!c.used && !c.anchor) out->chunks_pooled[c.cls] += 1;
+        }
     return DD_OK;
 }
 

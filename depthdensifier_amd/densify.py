@@ -451,9 +451,9 @@ class CloudBuilder:
             raise ValueError("a cloud needs points or the packed record")
         self.placement = None
         if buffers is None and points and normals:
-            # the two lock-step row streams of the kernel: allocate them where they do not share an HBM class
+            # the kernel is bound by its row stores: the row arrays are built from chunks spread over the three classes of HBM
             from . import placement as _placement
-            p_xyz, p_nrm, p_rgb, self.placement = _placement.place_outputs(n, colors=colors, device=dev, mode=placement)
+            p_xyz, p_nrm, p_rgb, self.placement = _placement.place_outputs(n, colors=colors, normals=normals, device=dev, mode=placement)
             placed = {"points": p_xyz, "normals": p_nrm, "colors": p_rgb}
         else:
             placed = {}

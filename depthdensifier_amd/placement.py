@@ -32,7 +32,19 @@ from ._lib import lib
 
 GIB = 1 << 30
 MIN_ROWS = 32 << 20            # clouds below 32 Mi rows (384 MiB of points) are left where they land: small streams do not care
-GROUP_POINTS, GROUP_NORMALS, GROUP_OTHER = 0, 1, 2
+GROUP_POINTS, GROUP_NORMALS, GROUP_OTHER = 0, 1, 2        # class-pure layouts: arrays of different groups in different classes
+
+
+def rotated(phase: int = 0) -> int:
+    """Layout code of an array whose consecutive chunks come from classes ``(phase + k) mod 3``."""
+    return _lib.DD_ARENA_ROTATED + int(phase) % 3
+
+
+def default_layout() -> str:
+    """``DD_PLACEMENT_LAYOUT`` = ``rotated`` (default: chunk k of every array from class (phase + k) mod 3, the phases of
+    points / normals / colours differ) or ``separated`` (points, normals and colours class-pure in three different classes)."""
+    m = os.environ.get("DD_PLACEMENT_LAYOUT", "rotated").lower()
+    return m if m in ("rotated", "separated") else "rotated"
 
 
 def default_mode() -> str:
@@ -45,12 +57,13 @@ def default_mode() -> str:
 class PlacementReport:
     """What ``place_outputs`` did -- kept on the ``CloudBuilder`` as ``.placement`` and printed by ``bench.py``."""
     mode: str                                   # "probed" | "first" | "skipped: <why>" | "degraded: <why>"
-    classes: Optional[Dict[str, list]] = None   # per array: the distinct classes of its chunks
+    classes: Optional[Dict[str, list]] = None   # per array: the classes of its chunks
     seconds: float = 0.0
     stats: Optional[dict] = None
+    layout: Optional[str] = None                # "rotated" | "separated"
 
     def as_dict(self) -> dict:
-        return {"mode": self.mode, "classes": self.classes, "seconds": round(self.seconds, 3), "arena": self.stats}
+        return {"mode": self.mode, "layout": self.layout, "classes": self.classes, "seconds": round(self.seconds, 3), "arena": self.stats}
 
 
 class ArenaError(RuntimeError):
@@ -134,12 +147,18 @@ class ZoneArena:
         _acheck(lib.dd_arena_probe(self._handle, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.byref(ms)))
         return float(ms.value)
 
+    def trim(self, pool_chunks_per_class: int = -1) -> None:
+        """Give the spare classified chunks back to the driver (``pool_chunks_per_class`` >= 0: and keep that many per class
+        from now on; the default is 4, i.e. up to 12 GiB idle between allocations)."""
+        _acheck(lib.dd_arena_trim(self._handle, int(pool_chunks_per_class)))
+
     def stats(self) -> dict:
         s = _lib.DDArenaStats()
         _acheck(lib.dd_arena_stats(self._handle, C.byref(s)))
         return {"chunk_bytes": int(s.chunk_bytes), "probe_bytes": int(s.probe_bytes), "num_classes": int(s.num_classes),
                 "degraded_allocs": int(s.degraded_allocs), "chunks_created": int(s.chunks_created), "chunks_released": int(s.chunks_released),
-                "probes": int(s.probes), "chunks_held": [int(x) for x in s.chunks_held], "same_class_ms": round(float(s.same_class_ms), 4),
+                "probes": int(s.probes), "chunks_held": [int(x) for x in s.chunks_held], "chunks_pooled": [int(x) for x in s.chunks_pooled],
+                "same_class_ms": round(float(s.same_class_ms), 4),
                 "cross_class_ms": round(float(s.cross_class_ms), 4), "seconds": round(float(s.seconds), 3)}
 
 
@@ -153,8 +172,16 @@ def get_arena(device) -> ZoneArena:
     with _arenas_lock:
         a = _arenas.get(idx)
         if a is None:
-            a = _arenas[idx] = ZoneArena(torch.device("cuda", idx), int(os.environ.get("DD_ARENA_CHUNK_MIB", "0")) << 20)
+            a = _arenas[idx] = ZoneArena(torch.device("cuda", idx), int(os.environ.get("DD_ARENA_CHUNK_MIB", "0")) << 20)      # 0 = the library's default
         return a
+
+
+def trim(device=None) -> None:
+    """Give the spare chunks of the device's arena (if one exists) back to the driver, e.g. before a large plain allocation."""
+    with _arenas_lock:
+        arenas = list(_arenas.values()) if device is None else [a for i, a in _arenas.items() if i == (torch.device(device).index or 0)]
+    for a in arenas:
+        a.trim()
 
 
 def place_arrays(specs: Dict[str, Tuple[Sequence[int], torch.dtype, int]], device, mode: Optional[str] = None) -> Tuple[Dict[str, torch.Tensor], PlacementReport]:
@@ -173,21 +200,39 @@ def place_arrays(specs: Dict[str, Tuple[Sequence[int], torch.dtype, int]], devic
     except (ArenaError, RuntimeError) as e:          # the virtual-memory API is missing or out of memory: carry on unplaced
         return plain(), PlacementReport(f"skipped: {e}"[:200])
     rep = PlacementReport("degraded: some arrays share a class" if degraded else "probed", seconds=time.perf_counter() - t0)
-    rep.classes = {k: sorted(set(arena.classes_of(t))) for k, t in tensors.items()}
+    rep.classes = {k: _summary(arena.classes_of(t)) for k, t in tensors.items()}
     rep.stats = arena.stats()
     return tensors, rep
 
 
-def place_outputs(capacity: int, *, colors: bool, device, mode: Optional[str] = None) -> tuple:
-    """(points, normals, colors | None, PlacementReport) for a cloud of ``capacity`` rows that carries normals."""
+def _summary(classes: list) -> list:
+    """Class sequence of an array's chunks, condensed: [0, 1, 2, 0] stays, long ones become a description."""
+    if len(classes) <= 6:
+        return classes
+    if all(classes[k] == (classes[0] + k) % 3 for k in range(len(classes))):
+        return [f"{len(classes)} chunks rotating from class {classes[0]}"]
+    if len(set(classes)) == 1:
+        return [f"{len(classes)} chunks of class {classes[0]}"]
+    return classes
+
+
+def place_outputs(capacity: int, *, colors: bool, device, mode: Optional[str] = None, normals: bool = True,
+                  layout: Optional[str] = None) -> tuple:
+    """(points, normals | None, colors | None, PlacementReport) for the row arrays of a cloud of ``capacity`` rows."""
     n = max(int(capacity), 1)
-    specs = {"points": ((n, 3), torch.float32, GROUP_POINTS), "normals": ((n, 3), torch.float32, GROUP_NORMALS)}
+    layout = layout or default_layout()
+    codes = (GROUP_POINTS, GROUP_NORMALS, GROUP_OTHER) if layout == "separated" else (rotated(0), rotated(1), rotated(2))
+    specs = {"points": ((n, 3), torch.float32, codes[0])}
+    if normals:
+        specs["normals"] = ((n, 3), torch.float32, codes[1])
     if colors:
-        specs["colors"] = ((n, 3), torch.uint8, GROUP_OTHER)
+        specs["colors"] = ((n, 3), torch.uint8, codes[2])
     mode = mode or default_mode()
     if mode != "first" and n < MIN_ROWS:
         t, rep = place_arrays(specs, device, "first")
         rep.mode = f"skipped: {n} rows < {MIN_ROWS} (small streams do not care)"
     else:
         t, rep = place_arrays(specs, device, mode)
-    return t["points"], t["normals"], t.get("colors"), rep
+    if rep.mode == "probed":
+        rep.layout = layout
+    return t["points"], t.get("normals"), t.get("colors"), rep

@@ -305,6 +305,13 @@ const char *dd_model_last_error(void);
  * ------------------------------------------------------------------------------------------- */
 typedef struct DDArena DDArena;
 
+/* layout of one array of dd_arena_alloc (the `groups` argument): 0, 1, 2 = class-pure, in the class of that GROUP (arrays
+ * of one group share a class, different groups get different classes; a group keeps its class over later calls);
+ * DD_ARENA_ROTATED + phase (phase 0..2) = chunk k of the array comes from class (phase + k) mod 3: a single store stream
+ * then alternates between the classes (5.7 -> 6.1 / 6.7 TB/s with 1 GiB / 512 MiB chunks), and two arrays of different
+ * phase written in lock step never share a class (7.1 TB/s, like two pure arrays of different groups) */
+#define DD_ARENA_ROTATED 8
+
 typedef struct DDArenaStats {
     int64_t chunk_bytes;
     int64_t probe_bytes;        /* bytes each of the two probe streams writes */
@@ -313,7 +320,8 @@ typedef struct DDArenaStats {
     int64_t chunks_created;
     int64_t chunks_released;
     int64_t probes;
-    int64_t chunks_held[3];     /* live chunks per class (anchors and allocations) */
+    int64_t chunks_held[3];     /* live chunks per class (anchors, allocations, pool) */
+    int64_t chunks_pooled[3];   /* of those: spare classified chunks kept for the next allocation (see dd_arena_trim) */
     float same_class_ms;        /* probe level inside one chunk */
     float cross_class_ms;       /* fastest pair seen */
     double seconds;             /* time spent inside dd_arena_alloc */
@@ -327,8 +335,12 @@ int dd_arena_create(int32_t device, int64_t chunk_bytes, DDArena **arena_out);
  * the device (the probes are timed).  Returns DD_OK, 1 = allocated but some group had to share a class (budget or memory
  * too small), or a negative error (DD_ERR_WORKSPACE = out of device memory). */
 int dd_arena_alloc(DDArena *arena, int32_t n, const int64_t *sizes, const int32_t *groups, int64_t max_scout_bytes, void **ptrs_out);
-/* Unmaps and releases one array of dd_arena_alloc; synchronises the device first. */
+/* Unmaps one array of dd_arena_alloc; synchronises the device first.  Its chunks go back to the driver, except that up to
+ * 4 chunks per class (dd_arena_trim changes that) are kept as classified spares so that the next allocation need not
+ * scout again (scouting costs ~27 ms per GiB looked at). */
 int dd_arena_free(DDArena *arena, void *ptr);
+/* Gives every spare chunk back to the driver; pool_chunks_per_class >= 0 also sets how many are kept from now on. */
+int dd_arena_trim(DDArena *arena, int32_t pool_chunks_per_class);
 /* Class of every chunk behind an array: returns the number of chunks, writes min(that, capacity) entries. */
 int dd_arena_classes(DDArena *arena, const void *ptr, int32_t *classes_out, int32_t capacity);
 /* The probe on two windows (probe_bytes each) chosen by the caller, milliseconds (diagnostics, tests). */

@@ -21,7 +21,8 @@ def test_arena_entry_points_validate_without_a_gpu():
     assert L.dd_arena_free(None, None) == -1 and L.dd_arena_stats(None, None) == -1
     assert L.dd_arena_classes(None, None, None, 0) == -1 and L.dd_arena_probe(None, None, None, None) == -1
     assert L.dd_arena_destroy(None) == 0
-    assert C.sizeof(_lib.DDArenaStats) == 8 + 8 + 4 + 4 + 3 * 8 + 3 * 8 + 4 + 4 + 8
+    assert L.dd_arena_trim(None, 0) == -1
+    assert C.sizeof(_lib.DDArenaStats) == 8 + 8 + 4 + 4 + 3 * 8 + 3 * 8 + 3 * 8 + 4 + 4 + 8
 
 
 def test_placement_mode_from_environment(monkeypatch):
@@ -70,10 +71,21 @@ def test_arena_gives_every_group_its_own_class(gpu):
     # a later call keeps the groups where they are
     t2, _ = arena.alloc({"d": ((rows, 3), torch.float32, 1)})
     assert set(arena.classes_of(t2["d"])) == cls["b"]
+    # rotated layout: chunk k from class (phase + k) mod 3 -- two arrays of different phase never share a class at equal rows
+    big = 3 * (st["chunk_bytes"] // 12) + 1000                                # a little more than three chunks of float32 rows
+    t3, deg3 = arena.alloc({"p": ((big, 3), torch.float32, pl.rotated(0)), "q": ((big, 3), torch.float32, pl.rotated(1))})
+    cp, cq = arena.classes_of(t3["p"]), arena.classes_of(t3["q"])
+    assert not deg3 and len(cp) == 4 and cp == [k % 3 for k in range(4)] and cq == [(1 + k) % 3 for k in range(4)], (cp, cq)
+    t3["p"][-1].fill_(2.0)                                                     # the last row lies in the fourth chunk
+    assert float(t3["p"][-1].sum()) == 6.0
     held = sum(arena.stats()["chunks_held"])
-    del t, t2
+    del t, t2, t3
     gc.collect()
-    assert sum(arena.stats()["chunks_held"]) < held                         # the arrays went back to the driver
+    st2 = arena.stats()
+    assert sum(st2["chunks_pooled"]) > 0 and sum(st2["chunks_held"]) < held   # a few spares are kept, the rest went back
+    arena.trim()
+    st3 = arena.stats()
+    assert sum(st3["chunks_pooled"]) == 0 and sum(st3["chunks_held"]) == 3    # only the three anchors stay
 
 
 @pytest.mark.gpu
@@ -95,7 +107,7 @@ def test_placed_cloud_equals_unplaced_cloud(gpu):
         clouds[mode] = b.finish()
         if mode == "probed":
             cl = b.placement.classes
-            assert cl["points"] != cl["normals"] and len(cl["points"]) == 1 and len(cl["normals"]) == 1, cl
+            assert b.placement.layout == "rotated" and cl["points"][0] != cl["normals"][0], b.placement.as_dict()
         del b
     gc.collect()
     a, p = clouds["first"], clouds["probed"]

@@ -43,7 +43,7 @@ batch = mk_batch(scene)
 P = batch.max_points
 print(f"{wl}: {V} views, cloud capacity {P} rows", flush=True)
 for r in range(R):
-    for mode, layout in (("first", ""), ("probed", "separated"), ("probed", "interleaved")):
+    for mode, layout in (("first", ""), ("probed", "separated"), ("probed", "rotated")):
         import os
         os.environ["DD_PLACEMENT_LAYOUT"] = layout
         t0 = time.perf_counter()
