@@ -90,6 +90,7 @@ struct KArgs {
     int view_base;
     int sp_static;                // diagnostic: single-pass without tickets (tile = blockIdx.x)
     int align_runs;               // lean kernels: shift the sweeps so that wave runs start on 128-byte lines (default on)
+    unsigned spin_limit;          // look-back polls before a tile gives up (SPIN_LIMIT; 0 with the fault-injection tuning bit 64)
 };
 
 
@@ -555,7 +556,7 @@ constexpr int LB_K = DD_LB_K;
 constexpr int LB_LANES = DD_LB_LANES;   // lanes that actually poll (window = LB_LANES * LB_K tiles)
 
 __device__ __forceinline__ long long lookback13(unsigned long long *state, unsigned t, unsigned agg,
-                                                long long base, int lane, int *err) {
+                                                long long base, int lane, int *err, const unsigned spin_limit) {
     long long excl = 0;
     long long look = (long long)t - 1;        // nearest predecessor = lane 0, k 0
     unsigned spins = 0;
@@ -588,7 +589,7 @@ __device__ __forceinline__ long long lookback13(unsigned long long *state, unsig
         const int L = incl_b ? __builtin_ctzll(incl_b) : 64;
         const unsigned long long need = (L >= 63) ? ~0ull : ((2ull << L) - 1ull);   // lanes 0..L
         if (__ballot(empty_before) & need) {
-            if (++spins > SPIN_LIMIT) {
+            if (++spins > spin_limit) {
                 if (lane == 0) atomicExch(err, 1);
                 break;
             }
@@ -892,7 +893,11 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
         // after this barrier; neither the list nor the gathers need the tile's first row).
         __syncthreads();
         if (wave == 0) {
-            const long long e = lookback13(a.tile_state, t, n, *a.cursor, lane, &a.hdr->error);
+            long long e = lookback13(a.tile_state, t, n, *a.cursor, lane, &a.hdr->error, a.spin_limit);
+            if (a.spin_limit == 0u && (t & 7u) == 1u) {      // fault injection (tuning bit 64): what a give-up leaves behind --
+                e += 977;                                    // a wrong first row for this tile and the error word set
+                if (lane == 0) atomicExch(&a.hdr->error, 1);
+            }
             if (lane == 0) {
                 s_excl = e;
                 if (tv == 0) a.view_offsets[v] = e;
@@ -1156,6 +1161,9 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
     p.single = (b->tuning & TUNE_SINGLE_PASS) != 0 || (p.lean && !(b->tuning & TUNE_TWO_PASS));
     a.sp_static = (b->tuning & 16u) != 0;   // diagnostic only: relies on in-order dispatch
     a.align_runs = (b->tuning & 32u) == 0;  // tuning bit 32: rows in list order (A/B of the line-aligned sweeps)
+    a.spin_limit = (b->tuning & 64u) ? 0u : SPIN_LIMIT;   // tuning bit 64: fault injection -- a tile that would have to wait for a
+                                                          // predecessor gives up at once, and every eighth tile behaves as if it had:
+                                                          // wrong rows, the workspace's error word set (tests of the caller's recovery)
     p.tile = p.lean ? L_TILE : G_TILE;      // tiling of the two-pass kernels (count / plan / scatter)
     a.tiles_per_view = (a.P + p.tile - 1) / p.tile;
     const unsigned long long nt = (unsigned long long)a.tiles_per_view * (unsigned)a.V;

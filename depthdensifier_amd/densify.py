@@ -481,6 +481,13 @@ class CloudBuilder:
         self._offsets: list[torch.Tensor] = []
         self._workspaces: list[torch.Tensor] = []
         self._ws_cache: Optional[torch.Tensor] = None
+        # batches appended since the last reset, kept so that they can be redone if an in-kernel scan gives up (see
+        # _check_status); a batch holds its maps alive, so retention stops at a quarter of the device's free memory
+        self._retained: list = []
+        self._retained_bytes = 0
+        self._retain_limit = torch.cuda.mem_get_info(dev)[0] // 4
+        self._retain_complete = True
+        self.healed = 0
 
     def _set_start(self) -> None:
         if self._start is None:
@@ -494,6 +501,22 @@ class CloudBuilder:
         self._set_start()
         self._offsets.clear()
         self._workspaces.clear()
+        self._retained.clear()
+        self._retained_bytes = 0
+        self._retain_complete = True
+
+    def _retain(self, batch: "ViewBatch", offsets: torch.Tensor) -> None:
+        if not self._retain_complete:
+            return
+        nbytes = sum(t.numel() * t.element_size() for t in (batch.depth, batch.mask, batch.conf, batch.normal, batch.rgb) if t is not None)
+        if self._retained and self._retained[-1][0] is batch:          # the same batch again (a timing loop): nothing new is held
+            nbytes = 0
+        if self._retained_bytes + nbytes > self._retain_limit:
+            self._retain_complete = False
+            self._retained.clear()
+            return
+        self._retained.append((batch, offsets))
+        self._retained_bytes += nbytes
 
     def _offsets_slice(self, n: int) -> torch.Tensor:
         """(n,) int64 device slice from a pooled tensor (one allocation per ~4096 offsets, not per append)."""
@@ -513,26 +536,31 @@ class CloudBuilder:
                 self._ws_cache[:16].copy_(old[:16])          # carry a pending error over to the larger buffer
         return self._ws_cache
 
-    def append(self, batch: ViewBatch) -> torch.Tensor:
+    def append(self, batch: ViewBatch, _offsets: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Enqueue one batch; returns its (V+1,) absolute view offsets (device, valid once the
         stream has run)."""
         if self.normal is not None and batch.normal is None:
             raise ValueError("this cloud carries normals but the batch has no normal map")
         if self.rgb is not None and batch.rgb is None:
             raise ValueError("this cloud carries colours but the batch has no rgb image")
+        redo = _offsets is not None
         if batch.num_views == 0:                       # an empty chunk of views: nothing to enqueue, the cursor stays
-            offsets = self._offsets_slice(1)
+            offsets = _offsets if redo else self._offsets_slice(1)
             offsets.copy_(self.cursor, non_blocking=True)
-            self._offsets.append(offsets)
+            if not redo:
+                self._offsets.append(offsets)
+                self._retain(batch, offsets)
             return offsets
         cb = batch.c_struct()
         ws = self._workspace(batch.workspace_bytes())
         out = self._out_struct()
-        offsets = self._offsets_slice(batch.num_views + 1)
+        offsets = _offsets if redo else self._offsets_slice(batch.num_views + 1)
         check(lib.dd_unproject_compact(C.byref(cb), C.byref(out), offsets.data_ptr(), self.cursor.data_ptr(),
                                        ws.data_ptr(), ws.numel(), _stream(self.device)))
-        self._offsets.append(offsets)
-        self._workspaces.append(ws)
+        if not redo:
+            self._offsets.append(offsets)
+            self._workspaces.append(ws)
+            self._retain(batch, offsets)
         return offsets
 
     def _out_struct(self) -> DDCloudOut:
@@ -557,10 +585,15 @@ class CloudBuilder:
         return plan.view_offsets
 
     def check(self) -> int:
-        """Synchronise once: the row after the last appended point; raises if an in-kernel scan gave up or the
-        cloud overflowed."""
+        """Synchronise once: the row after the last appended point.  If an in-kernel scan gave up in one of the appended
+        batches, the batches are redone once with the dependency-free two-pass kernels (``self.healed`` counts that);
+        raises if that is not possible, or if the cloud overflowed."""
         total = int(self.cursor.item())
-        self._check_status(total)
+        if self._scan_gave_up():
+            total = self._heal()
+        if total > self.capacity:
+            raise OverflowError(f"cloud capacity {self.capacity} < {total} valid points; "
+                                "allocate with capacity=batch.max_points or count_valid() first")
         return total
 
     def finish(self, name: str = "Dense Cloud") -> FusedCloud:
@@ -577,15 +610,35 @@ class CloudBuilder:
         return FusedCloud(points=cut(self.xyz), colors=cut(self.rgb), normals=cut(self.normal),
                           pixel_index=cut(self.pix), view_index=cut(self.view), view_offsets=offs, name=name, packed=cut(self.packed))
 
-    def _check_status(self, total: int) -> None:
+    def _scan_gave_up(self) -> bool:
+        bad = False
         for ws in {id(w): w for w in self._workspaces}.values():
             if int(ws[:8].view(torch.int32)[1].item()) != 0:
-                ws[:16].zero_()                              # sticky word: cleared only here, once reported
-                raise RuntimeError("libddcore: in-kernel scan timed out in one of the appended batches "
-                                   "(workspace error word set); rows are invalid -- redo with tuning=4")
-        if total > self.capacity:
-            raise OverflowError(f"cloud capacity {self.capacity} < {total} valid points; "
-                                "allocate with capacity=batch.max_points or count_valid() first")
+                ws[:16].zero_()                              # sticky word: cleared only here, once seen
+                bad = True
+        return bad
+
+    def _heal(self) -> int:
+        """A look-back of the single-pass kernel timed out (a workgroup was parked for ~2 s: another tenant, ranks sharing
+        the GPU): every batch appended since the last reset is run again through dd_plan + dd_scatter (``tuning`` bit 4),
+        whose workgroups do not depend on each other, writing the same rows and the same offset tensors."""
+        if not self._retain_complete or not self._retained:
+            raise RuntimeError("libddcore: in-kernel scan timed out in one of the appended batches (workspace error word set) "
+                               "and the batches are no longer held (more than a quarter of the device's memory): rows are "
+                               "invalid -- append the batches again with tuning=4")
+        self._set_start()
+        for batch, offsets in self._retained:
+            saved = batch.tuning
+            batch.tuning = (saved | 4) & ~(8 | 64)
+            try:
+                self.append(batch, _offsets=offsets)
+            finally:
+                batch.tuning = saved
+        self.healed += 1
+        total = int(self.cursor.item())
+        if self._scan_gave_up():                             # cannot happen: the two-pass kernels have no look-back
+            raise RuntimeError("libddcore: the two-pass redo reported a scan time-out")
+        return total
 
 
 # --------------------------------------------------------------------------------------

@@ -564,6 +564,73 @@ def test_per_gpu_share_of_the_2000_view_scene_with_normals(dd, orc):
     assert torch.equal(packed.colors, rows.colors)
 
 
+def test_12mp_f16_dense_beyond_2_31_rows(dd, orc):
+    """BASELINE configs[4] at scale in its OWN instantiation (f16 depth, no mask, no normals, no colours, xyz out): 180 views
+    of 4032 x 3024 = 2.19 G rows (> 2^31), 26 GB of points.  Every pixel is valid, so the cloud is the pixel grid: length,
+    per-view offsets, pixel_index of a late view == arange, and the LAST view against the oracle."""
+    import torch
+    V, H, W = 180, 3024, 4032
+    P = H * W
+    assert V * P > 2 ** 31
+    g = torch.Generator(device="cuda").manual_seed(12)
+    depth = torch.empty((V, H, W), dtype=torch.float16, device="cuda")
+    for v in range(V):
+        depth[v] = torch.rand((H, W), device="cuda", generator=g) * 7.0 + 1.0          # 1 .. 8 m, all > 0
+    params = np.tile([0.8 * W, 0.8 * W, W / 2, H / 2], (V, 1))
+    E = _ring_poses(V)
+    batch = dd.ViewBatch(depth, params, E)
+    b = dd.CloudBuilder(batch.max_points, pixel_index=True)
+    b.append(batch)
+    cloud = b.finish()
+    assert len(cloud) == V * P and b.healed == 0
+    offs = cloud.view_offsets
+    assert torch.equal(offs, torch.arange(V + 1, device="cuda", dtype=torch.int64) * P)
+    for v in (0, V // 2, V - 3, V - 1):                                                # rows beyond 2^31 included
+        assert torch.equal(cloud.pixel_index[v * P:(v + 1) * P], torch.arange(P, device="cuda", dtype=torch.int32)), v
+    v = V - 1
+    ref = orc.densify_view_script(depth[v].cpu().numpy(), params[v], E[v])
+    assert len(ref["points"]) == P
+    assert_xyz(cloud.points[v * P:].double().cpu().numpy(), ref["points"], scene_radius(E, np.array([8.0])))
+    # a sample of rows across the whole cloud: finite and inside the scene
+    idx = torch.randint(0, V * P, (1 << 20,), device="cuda", generator=g)
+    assert bool(torch.isfinite(cloud.points[idx]).all()) and float(cloud.points[idx].abs().max()) < 20.0
+
+
+@pytest.mark.parametrize("fields", ("all", "xyz"))
+def test_scan_timeout_is_healed_by_a_two_pass_redo(dd, fields):
+    """tuning bit 64 makes every look-back of the single-pass kernel give up at its first wait (what a workgroup parked for
+    ~2 s would cause): the error word is set, rows are garbage.  finish() must notice, redo the retained batches with the
+    dependency-free two-pass kernels into the SAME rows and offset tensors, and report it in `healed`."""
+    import torch
+    V, H, W = 5, 540, 960
+    depth, mask, normal, rgb = _device_stack(V, H, W, 99)
+    params = np.tile([0.8 * W, 0.8 * W, W / 2, H / 2], (V, 1))
+    E = _ring_poses(V)
+    kw = dict(mask=mask, normal=normal, rgb=rgb) if fields == "all" else dict(mask=mask)
+    good = dd.ViewBatch(depth, params, E, **kw)
+    want_b = dd.CloudBuilder(good.max_points, normals=fields == "all", colors=fields == "all", pixel_index=True)
+    want_b.append(good)
+    want = want_b.finish()
+    assert want_b.healed == 0
+    # two chained batches, the second one sabotaged
+    first = dd.ViewBatch(depth[:2], params[:2], E[:2], **{k: t[:2] for k, t in kw.items()})
+    second = dd.ViewBatch(depth[2:], params[2:], E[2:], view_index_base=2, tuning=64, **{k: t[2:] for k, t in kw.items()})
+    b = dd.CloudBuilder(good.max_points, normals=fields == "all", colors=fields == "all", pixel_index=True)
+    o1 = b.append(first)
+    o2 = b.append(second)
+    got = b.finish()
+    assert b.healed == 1 and second.tuning == 64
+    assert len(got) == len(want) and torch.equal(got.view_offsets, want.view_offsets)
+    assert int(o1[-1]) == int(o2[0]) == int(want.view_offsets[2])                     # the offset tensors handed out were rewritten
+    for name in ("points", "normals", "colors", "pixel_index"):
+        a, w = getattr(got, name), getattr(want, name)
+        assert (a is None and w is None) or torch.equal(a, w), name
+    # and the builder is usable afterwards
+    b.reset()
+    b.append(good)
+    assert torch.equal(b.finish().points, want.points) and b.healed == 1
+
+
 @pytest.mark.parametrize("rho", (0.05, 0.5, 0.97))
 def test_every_row_alignment_of_the_first_row(dd, rho):
     """The lean kernel shifts its sweeps so that wave runs start on 128-byte lines of the outputs (32-row period); the
