@@ -53,9 +53,6 @@ struct FArgs {
     int accumulate;
     float depth_threshold;
     double grazing_cos;
-    int diag;                   // timing experiments only (DDFilterViews.reserved): 1 no depth gather, 2 stop after the bounds test, 4 after the depth sign
-    const float *tab;           // float32 first pass: (V, 32) per-view table built by votes_prepare
-    unsigned long long *stats;  // V_SHARDS x VoteStats: pairs the float32 pass could not decide, verify mismatches
 };
 
 // A camera block whose first 12 doubles ([R|t]) were fetched ahead of time into scalar registers (see the view loop of
@@ -554,327 +551,10 @@ __global__ __launch_bounds__(256) void floater_votes_kernel_cull(const FArgs a, 
     if (live) a.votes[i] = votes;
 }
 
-// ==================================================================================================
-// Float32 first pass with rigorous error bounds (default when the caller provides DDFilterViews.workspace).
-//
-// The float64 kernel above is VALU-bound (~75 instructions per wave and view).  NOTE (measured after this pass was
-// built, tools/experiments/ubench_fma.hip): on gfx950 v_fma_f64 issues at 0.88x the rate of a scalar-per-lane v_fma_f32 -- only the
-// PACKED float32 form is twice as fast -- so a float32 evaluation that needs about twice the instructions for its error
-// bounds has no arithmetic advantage to collect; that is why this pass measures slower.  Every (point, view) pair is first evaluated in float32
-// together with an upper bound of the distance between each float32 quantity and the value the float64 formulation
-// computes; a comparison is accepted only when the float32 value is farther from its threshold than that bound --
-// then the float64 formulation takes the same branch.  Pairs with any comparison inside its band (about 1-2 % of
-// those that reach the depth lookup: the truncation of u, w to a pixel is the sensitive one) are queued in LDS and
-// resolved by pair_votes() in float64, spread evenly over the workgroup.  Votes are therefore those of the float64
-// kernel, bit for bit (tests: oracle equality, the reference's own vote loop fixture, and a verify build that checks
-// every confident float32 decision of a run against float64).
-//
-// Error model (eps = 2^-24; p = (x,y,z) float32 exact; c = float64 camera block, cf = its float32 rounding):
-//   Xc = c0 x + c1 y + c2 z + c3:  |xc32 - Xc| <= 4 eps A_x (1 + O(eps)),  A_x = |c0||x|+|c1||y|+|c2||z|+|c3|
-//        <= rho_x |p|_2 + |c3|   (Cauchy-Schwarz; rho_x = |(c0,c1,c2)|_2)          -> E_x = ax P + bx, ax = 6 eps rho_x, bx = 6 eps |c3|
-//        <= M S, M = max|c0..11|, S = |x|+|y|+|z|+1                                  (crude form for the bounds tests)
-//   NU = c12 Xc + c13 Yc + c14 Zc:  E_nu = |k12| E_x + |k13| E_y + |k14| E_z + 5 eps (|k12 xc| + |k13 yc| + |k14 zc|)
-//   DEN = Zc + 1e-8:                E_den = E_z + 2 eps den
-//   bounds  0 <= NU, NU - W DEN < 0 (DEN > 0):  band gB S,  gB = 1.25 eps M (12 max(Ku,Kw) + 9 max(W,H)),  K. = sum |k|
-//   grazing  t = -(n.d) > g |d|  <=>  t > 0 and t^2 > g^2 |d|^2,  d = p - centre:
-//        E_d <= eps (|centre_i| + |d_i|);  E_t = N1 eps (5 Cn + 4 S);  E_len2 = eps Dm (6 Cn + 15 Dm),  Dm = S + Cn
-//   pixel  u = NU / DEN:  E_u = 1.01 (E_nu + u E_den) / den + 4 eps u   (needs 128 E_den <= den);  floor(u) is certain
-//        when frac(u) is farther than E_u from 0 and 1
-//   depth  Zc < limit (limit = float32 product, the same operation as in the float64 path):  |limit - zc| > 1.001 E_z
-// Every bound constant is rounded up; the float64 path's own rounding (1e-16) disappears in the slack of the bounds.
-// ==================================================================================================
-constexpr float F_EPS = 5.9604645e-8f;          // 2^-24
-constexpr int VQ_CAP = 4096;                    // ambiguous pairs queued per workgroup between flushes
-constexpr int VQ_CHUNK = 1024;                  // views between flushes
-
-__device__ __forceinline__ float round_up(double v) {       // v >= 0: smallest float >= v, then a few ulps of slack
-    float f = (float)v;
-    if ((double)f < v) f = __uint_as_float(__float_as_uint(f) + 1u);      // next float above a non-negative finite f
-    return f * (1.0f + 4.0f * F_EPS);
-}
-
-// one thread per view: the float32 table of the first pass
-__global__ __launch_bounds__(64) void votes_prepare(const double *cams, float *tab, int V, int H, int W) {
-    const int v = blockIdx.x * 64 + threadIdx.x;
-    if (v >= V) return;
-    const double *c = cams + (size_t)v * 24;
-    float *t = tab + (size_t)v * 32;
-    for (int k = 0; k < 21; ++k) t[k] = (float)c[k];
-    const double eps = 5.9604644775390625e-8;
-    double M = 0.0, Cn = 0.0;
-    for (int k = 0; k < 12; ++k) M = fmax(M, fabs(c[k]));
-    for (int k = 18; k < 21; ++k) Cn = fmax(Cn, fabs(c[k]));
-    const double rx = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]), ry = sqrt(c[4] * c[4] + c[5] * c[5] + c[6] * c[6]);
-    const double rz = sqrt(c[8] * c[8] + c[9] * c[9] + c[10] * c[10]);
-    const double Ku = fabs(c[12]) + fabs(c[13]) + fabs(c[14]), Kw = fabs(c[15]) + fabs(c[16]) + fabs(c[17]);
-    // (+1e-30: an absolute floor so that a degenerate all-zero geometry cannot make a band narrower than float32 underflow)
-    t[21] = round_up(6 * eps * rz); t[22] = round_up(6 * eps * fabs(c[11])) + 1e-30f;     // az, bz
-    t[23] = round_up(6 * eps * rx); t[24] = round_up(6 * eps * fabs(c[3])) + 1e-30f;      // ax, bx
-    t[25] = round_up(6 * eps * ry); t[26] = round_up(6 * eps * fabs(c[7])) + 1e-30f;      // ay, by
-    t[27] = round_up(1.25 * eps * M * (12.0 * fmax(Ku, Kw) + 9.0 * fmax((double)W, (double)H)));     // gB
-    t[28] = round_up(Cn);
-    t[29] = round_up(5.0 * 1.25 * eps * Cn);                                      // e5c: the centre's share of E_t / N1
-    t[30] = 0.0f; t[31] = 0.0f;
-}
-
-// 0: no vote, 1: vote, 2: undecided (float64 decides).  `c` is the view's float32 table row (wave-uniform -> scalar loads).
-// The table row is read through the CONSTANT address space: the table is written by votes_prepare before this kernel
-// starts and never during it, and only loads the compiler may treat as invariant become scalar loads (s_load) -- with
-// the barriers and atomics of the queue in the same loop, plain global loads of it were emitted as per-lane vector loads.
-typedef const float __attribute__((address_space(4))) tab_float;
-// The row is fetched with two 16-dword scalar loads at the top of the pair: left to itself the compiler sinks each
-// element's load into the branch (stage) that first uses it, and every stage then starts with an exposed scalar-memory
-// round trip -- four per view instead of one.
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef const f32x16 __attribute__((address_space(4))) tab_row;
-struct VRow {
-    f32x16 lo, hi;
-    __device__ __forceinline__ float operator[](int k) const { return k < 16 ? lo[k] : hi[k - 16]; }
-};
-
-// Stage a: everything up to the address of the depth lookup.  0: no vote, 2: undecided (float64 decides), 3: look up
-// pixel `off` of the view and finish with votes32_finish().  The lookup is split off so that the caller can keep the
-// loads of several views in flight: the float32 arithmetic of one pair (~200 cycles per wave) is far too short to hide
-// a 1-2 us depth gather behind the other waves of the SIMD the way the float64 kernel's ~470 cycles did.
-__device__ __forceinline__ int votes32_project(const VRow &c, const float x, const float y,
-                                               const float z, const float nx, const float ny, const float nz, const float P,
-                                               const float S, const float N1, const float s4, const float g2,
-                                               const float wlim, const float hlim, const int W, unsigned &off, float &zc_out, float &ez_out,
-                                               const int diag) {
-    // One state per lane and ONE nested branch per stage (bitwise, not short-circuit, logic inside a stage): a version
-    // with an early `return` per comparison spent more scalar instructions on exec-mask bookkeeping (18 branches per
-    // view) than vector instructions on arithmetic.  NaN anywhere compares false on both sides -> undecided.
-    // depth sign
-    const float zc = fmaf(c[8], x, fmaf(c[9], y, fmaf(c[10], z, c[11])));
-    const float Ez = fmaf(c[21], P, c[22]);
-    int st = (zc < -Ez) ? 0 : ((zc > Ez) ? 3 : 2);
-    if (diag & 4) return st == 3 ? 0 : st;
-    if (st == 3) {
-        // image bounds, division-free, crude band
-        const float xc = fmaf(c[0], x, fmaf(c[1], y, fmaf(c[2], z, c[3])));
-        const float yc = fmaf(c[4], x, fmaf(c[5], y, fmaf(c[6], z, c[7])));
-        const float den = zc + 1e-8f;
-        const float nu = fmaf(c[12], xc, fmaf(c[13], yc, c[14] * zc));
-        const float nw = fmaf(c[15], xc, fmaf(c[16], yc, c[17] * zc));
-        const float Eb = c[27] * S;
-        const float ru = fmaf(-wlim, den, nu), rw = fmaf(-hlim, den, nw);
-        const bool out = (nu < -Eb) | (nw < -Eb) | (ru > Eb) | (rw > Eb);
-        const bool in = (nu > Eb) & (nw > Eb) & (ru < -Eb) & (rw < -Eb);
-        st = out ? 0 : (in ? 3 : 2);
-        if (diag & 2) return st == 3 ? 0 : st;
-        if (st == 3) {
-            // grazing angle, squared comparison (g > 0 is checked by the host)
-            const float dx = x - c[18], dy = y - c[19], dz = z - c[20];
-            const float t = -fmaf(nx, dx, fmaf(ny, dy, nz * dz));
-            const float Et = N1 * (c[29] + s4);
-            const float len2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
-            const float Dm = S + c[28];
-            const float El2 = (1.25f * F_EPS) * Dm * fmaf(15.0f, Dm, 6.0f * c[28]);
-            const float s = t * t, q = g2 * len2;
-            const float Es = fmaf(2.0f * t, Et, Et * Et) + fmaf(g2, El2, (4.0f * F_EPS) * q) + (2.0f * F_EPS) * s;
-            const float diff = s - q, Ed = Es + F_EPS * (s + q);
-            const bool facing = (t > Et) & (diff > Ed);
-            const bool away = (t < -Et) | ((t > Et) & (diff < -Ed));
-            st = away ? 0 : (facing ? 3 : 2);
-            if (st == 3) {
-                // pixel of the lookup: tight bounds
-                const float Ex = fmaf(c[23], P, c[24]), Ey = fmaf(c[25], P, c[26]);
-                const float Eden = fmaf(2.0f * F_EPS, den, Ez);
-                const float axc = fabsf(xc), ayc = fabsf(yc);
-                const float Enu = fmaf(fabsf(c[12]), Ex, fmaf(fabsf(c[13]), Ey, fabsf(c[14]) * Ez))
-                                + (5.0f * F_EPS) * fmaf(fabsf(c[12]), axc, fmaf(fabsf(c[13]), ayc, fabsf(c[14]) * zc));
-                const float Enw = fmaf(fabsf(c[15]), Ex, fmaf(fabsf(c[16]), Ey, fabsf(c[17]) * Ez))
-                                + (5.0f * F_EPS) * fmaf(fabsf(c[15]), axc, fmaf(fabsf(c[16]), ayc, fabsf(c[17]) * zc));
-                const float rden = __builtin_amdgcn_rcpf(den);
-                const float u = nu * rden, w = nw * rden;
-                const float Eu = fmaf(fmaf(u, Eden, Enu), 1.01f * rden, (4.0f * F_EPS) * u);
-                const float Ew = fmaf(fmaf(w, Eden, Enw), 1.01f * rden, (4.0f * F_EPS) * w);
-                const float fu = floorf(u), fw = floorf(w);
-                const float du = u - fu, dw = w - fw;
-                const bool sure = (Eden * 128.0f <= den) & (du > Eu) & (1.0f - du > Eu) & (dw > Ew) & (1.0f - dw > Ew)
-                                & (fu < wlim) & (fw < hlim) & (fu >= 0.0f) & (fw >= 0.0f);     // the last four: address in range whatever happens
-                st = sure ? 3 : 2;
-                off = sure ? (unsigned)(int)fw * (unsigned)W + (unsigned)(int)fu : 0u;
-                zc_out = zc;
-                ez_out = Ez;
-            }
-        }
-    }
-    return st;
-}
-
-// Stage b: the (mask-zeroed) depth the view holds at the pixel against the point's depth in that view.
-__device__ __forceinline__ int votes32_finish(const float seen, const float zc, const float Ez, const float depth_threshold) {
-    if (!(seen > 0.0f)) return 0;
-    const float limit = depth_threshold * seen;         // the same float32 product as the float64 path (NEP 50, scripts/test.py:320)
-    const float d = limit - zc, Em = 1.001f * Ez;
-    if (d > Em) return 1;
-    if (d < -Em) return 0;
-    return 2;
-}
-
-// Pairs the float32 pass cannot decide travel to a second kernel through a global queue, so that the hot loop carries
-// no float64 code at all (inlined or called, the float64 resolver took the kernel from 52 to 99-116 VGPRs and its loads
-// to the flat address space: 5x slower than the float64 kernel it was meant to beat).  Per chunk of VQ_CHUNK views a
-// workgroup collects its undecided pairs in LDS and moves them to the global queue with ONE reservation; if the queue
-// (or the LDS staging area) is full, or one of its points is not plainly finite, the workgroup withholds the chunk's
-// votes and flags (workgroup, chunk) in a bitmap instead: votes_redo then recomputes exactly those pairs in float64.
-// Counters that every workgroup touches are SHARDED, one 128-byte line per shard: a single word takes ~11 ns per
-// returning atomic (about 88 per microsecond, MI355X_MICROARCH.md "dequeue"), i.e. 2.4 ms for the 220 000 workgroups of a
-// 56 M-point launch and 10 ms for one atomic per wave -- more than the whole float64 kernel.
-constexpr int V_SHARDS = 64;
-struct VoteQueue {                  // one per shard; shard s owns entries [s * shard_capacity, (s + 1) * shard_capacity)
-    unsigned long long count;       // entries reserved so far (may exceed the shard's capacity: the surplus was flagged for redo)
-    unsigned long long pad[15];
-};
-struct VoteStats {                  // one per shard
-    unsigned long long undecided, mismatch;
-    unsigned long long pad[14];
-};
-
-template <bool VERIFY>
-__global__ __launch_bounds__(256) void floater_votes_kernel32(const FArgs a, const int view0, const int view1, VoteQueue *gq,
-                                                              unsigned long long *entries, const unsigned long long capacity,
-                                                              unsigned *redo, const int chunks_total) {
-    __shared__ unsigned s_q[VQ_CAP];
-    __shared__ unsigned s_qn;
-    __shared__ unsigned long long s_gbase;
-    __shared__ int s_wild;
-    const int tid = threadIdx.x;
-    const long long base = (long long)blockIdx.x * 256;
-    const long long i = base + tid;
-    const bool live = i < a.n;
-    const float wlim = (float)a.W, hlim = (float)a.H;
-    float x = 0, y = 0, z = 0, nx = 0, ny = 0, nz = 0;
-    if (live) { x = a.xyz[3 * i]; y = a.xyz[3 * i + 1]; z = a.xyz[3 * i + 2]; nx = a.normal[3 * i]; ny = a.normal[3 * i + 1]; nz = a.normal[3 * i + 2]; }
-    const float up = 1.0f + 16.0f * F_EPS;
-    const float P = __builtin_sqrtf(fmaf(x, x, fmaf(y, y, z * z))) * up;
-    const float S = (fabsf(x) + fabsf(y) + fabsf(z) + 1.0f) * up;
-    const float N1 = (fabsf(nx) + fabsf(ny) + fabsf(nz)) * up;
-    const float s4 = (4.0f * 1.25f * F_EPS) * S;
-    const float g32 = (float)a.grazing_cos, g2 = g32 * g32;
-    const bool tame = S < 1e12f && N1 < 1e12f;          // NaN compares false: a point that is not plainly finite and moderate
-    if (tid == 0) { s_qn = 0; s_wild = 0; }
-    __syncthreads();
-    if (live && !tame) s_wild = 1;
-    __syncthreads();
-    const bool wild = s_wild != 0;                      // then float64 decides every pair of this workgroup (votes_redo)
-    int votes = (live && a.accumulate) ? a.votes[i] : 0;
-    unsigned long long undecided = 0, mismatch = 0;
-    for (int v0 = view0, chunk = 0; v0 < view1; v0 += VQ_CHUNK, ++chunk) {
-        const int v1 = v0 + VQ_CHUNK < view1 ? v0 + VQ_CHUNK : view1;
-        int cv = 0;
-        if (live && !wild) {
-            constexpr int INFL = 4;                             // views whose depth lookups are in flight together
-            for (int vb = v0; vb < v1; vb += INFL) {
-                int st[INFL];
-                unsigned off[INFL];
-                float zc[INFL], ez[INFL], seen[INFL];
-#pragma unroll
-                for (int k = 0; k < INFL; ++k) {
-                    st[k] = 0; off[k] = 0; zc[k] = 0.0f; ez[k] = 0.0f;
-                    if (vb + k < v1) {                                  // wave-uniform
-                        tab_row *rp = (tab_row *)(a.tab + (size_t)(vb + k) * 32);
-                        VRow row;
-                        row.lo = rp[0];
-                        row.hi = rp[1];
-                        st[k] = votes32_project(row, x, y, z, nx, ny, nz, P, S, N1, s4, g2, wlim, hlim, a.W, off[k], zc[k], ez[k], a.diag);
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < INFL; ++k) {
-                    seen[k] = 0.0f;
-                    if (a.diag & 1) { seen[k] = 1.0f; continue; }
-                    if (st[k] == 3) {
-                        const long long pix = (long long)(vb + k) * a.hw + off[k];
-                        seen[k] = a.depth[pix];
-                        if (a.mask && a.mask[pix] == 0) seen[k] = 0.0f;
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < INFL; ++k) {
-                    const int v = vb + k;
-                    const int r = st[k] == 3 ? votes32_finish(seen[k], zc[k], ez[k], a.depth_threshold) : st[k];
-                    if (VERIFY && r != 2 && v < v1) {
-                        const bool e = pair_votes(a, a.cams + (size_t)v * 24, v, x, y, z, nx, ny, nz, (double)a.W, (double)a.H);
-                        if ((r == 1) != e) ++mismatch;
-                    }
-                    if (r == 1) ++cv;
-                    else if (r == 2) {
-                        const unsigned slot = atomicAdd(&s_qn, 1u);
-                        if (slot < VQ_CAP) s_q[slot] = ((unsigned)tid << 20) | (unsigned)(v - v0);
-                        ++undecided;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        const unsigned qn = s_qn;
-        const unsigned shard = blockIdx.x % V_SHARDS;
-        if (tid == 0) s_gbase = (wild || qn > VQ_CAP) ? ~0ull : (qn ? atomicAdd(&gq[shard].count, (unsigned long long)qn) : 0ull);
-        __syncthreads();
-        const unsigned long long gb = s_gbase;
-        const bool fits = gb != ~0ull && gb + qn <= capacity;          // capacity: entries per shard
-        if (fits) {
-            unsigned long long *dst = entries + (unsigned long long)shard * capacity + gb;
-            for (unsigned e = tid; e < qn; e += 256) {
-                const unsigned ent = s_q[e];
-                dst[e] = ((unsigned long long)(base + (ent >> 20)) << 20) | (unsigned long long)(v0 + (int)(ent & 0xfffffu));
-            }
-            votes += cv;
-        } else if (tid == 0) {
-            const unsigned bit = blockIdx.x * (unsigned)chunks_total + (unsigned)chunk;     // < 2^32: checked by the host
-            atomicOr(&redo[bit >> 5], 1u << (bit & 31u));
-        }
-        __syncthreads();
-        if (tid == 0) s_qn = 0;
-        __syncthreads();
-    }
-    if (live) a.votes[i] = votes;
-    if (a.stats) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { undecided += __shfl_xor(undecided, o); mismatch += __shfl_xor(mismatch, o); }
-        VoteStats *st = reinterpret_cast<VoteStats *>(a.stats) + (blockIdx.x * 4 + (tid >> 6)) % V_SHARDS;
-        if ((tid & 63) == 0) {
-            if (undecided) atomicAdd(&st->undecided, undecided);
-            if (VERIFY && mismatch) atomicAdd(&st->mismatch, mismatch);
-        }
-    }
-}
-
-// the queued pairs, one per lane, in float64
-__global__ __launch_bounds__(256) void votes_resolve(const FArgs a, const VoteQueue *gq, const unsigned long long *entries,
-                                                     const unsigned long long capacity) {
-    // blockIdx.y = shard; the shard's blocks stride over its entries
-    const unsigned shard = blockIdx.y;
-    const unsigned long long cnt = gq[shard].count;
-    const unsigned long long n = cnt < capacity ? cnt : capacity;
-    const unsigned long long *src = entries + (unsigned long long)shard * capacity;
-    for (unsigned long long e = (unsigned long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (unsigned long long)gridDim.x * 256) {
-        const unsigned long long ent = src[e];
-        const long long j = (long long)(ent >> 20);
-        const int v = (int)(ent & 0xfffffull);
-        const double px = a.xyz[3 * j], py = a.xyz[3 * j + 1], pz = a.xyz[3 * j + 2];
-        const double qx = a.normal[3 * j], qy = a.normal[3 * j + 1], qz = a.normal[3 * j + 2];
-        if (pair_votes(a, a.cams + (size_t)v * 24, v, px, py, pz, qx, qy, qz, (double)a.W, (double)a.H)) atomicAdd(&a.votes[j], 1);
-    }
-}
-
-// (workgroup, chunk) cells the first pass gave up on: every pair of the cell in float64
-__global__ __launch_bounds__(256) void votes_redo(const FArgs a, const int view0, const int view1, const unsigned *redo, const int chunks_total) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    int add = 0;
-    for (int v0 = view0, chunk = 0; v0 < view1; v0 += VQ_CHUNK, ++chunk) {
-        const unsigned bit = blockIdx.x * (unsigned)chunks_total + (unsigned)chunk;
-        if (!((redo[bit >> 5] >> (bit & 31u)) & 1u)) continue;          // wave-uniform
-        if (i >= a.n) continue;
-        const int v1 = v0 + VQ_CHUNK < view1 ? v0 + VQ_CHUNK : view1;
-        const double x = a.xyz[3 * i], y = a.xyz[3 * i + 1], z = a.xyz[3 * i + 2];
-        const double nx = a.normal[3 * i], ny = a.normal[3 * i + 1], nz = a.normal[3 * i + 2];
-        for (int v = v0; v < v1; ++v) add += pair_votes(a, a.cams + (size_t)v * 24, v, x, y, z, nx, ny, nz, (double)a.W, (double)a.H) ? 1 : 0;
-    }
-    if (add) a.votes[i] += add;
-}
+// (Round 2 also carried a float32 first pass with rigorous error bounds whose undecided pairs were resolved in float64: the same
+// votes bit for bit, but 0.7-0.8x the rate of the float64 kernels -- on gfx950 v_fma_f64 issues at 0.88x the rate of a scalar-
+// per-lane v_fma_f32, so an evaluation that needs twice the instructions for its bounds has nothing to collect
+// (tools/experiments/ubench_fma.hip).  Removed in round 3; the history is in git, the measurements in DESIGN.md section 7.)
 
 // ==================================================================================================
 // Stable compaction of the fused cloud by the vote test (scripts/test.py:330-332:
@@ -1055,16 +735,9 @@ const char *dd_filter_last_error(void) { return g_ferr; }
 
 int64_t dd_votes_workspace_bytes(int32_t num_views, int64_t n_points) {
     if (num_views <= 0 || n_points < 0) return DD_ERR_INVALID_ARG;
-    const int64_t blocks = (n_points + 255) / 256, chunks = (num_views + VQ_CHUNK - 1) / VQ_CHUNK;
-    const int64_t fixed = 2 * (int64_t)V_SHARDS * 128 + (int64_t)num_views * 128, bitmap = ((blocks * chunks + 31) / 32 * 4 + 15) & ~(int64_t)15;
-    // queue: room for 3 % of the pairs, between 8 MiB and 256 MiB (larger inputs are processed in rounds of views)
-    double q = 0.03 * (double)n_points * (double)num_views * 8.0;
-    if (q < 8.0 * 1048576) q = 8.0 * 1048576;
-    if (q > 256.0 * 1048576) q = 256.0 * 1048576;
-    const int64_t first_pass = fixed + bitmap + ((int64_t)q & ~(int64_t)15);
-    // modes 3 / 4: two 256-byte tables per view, the decision counters, one mask of V bits per 65 536 points
-    const int64_t cull = (int64_t)num_views * 512 + 64 + ((blocks + SUPER - 1) / SUPER) * (int64_t)((num_views + 63) / 64) * 8;
-    return first_pass > cull ? first_pass : cull;
+    const int64_t blocks = (n_points + 255) / 256;
+    // two 256-byte tables per view, the decision counters, one mask of V bits per 65 536 points (level 1 of the cull)
+    return (int64_t)num_views * 512 + 64 + ((blocks + SUPER - 1) / SUPER) * (int64_t)((num_views + 63) / 64) * 8;
 }
 
 int dd_floater_votes(const DDFilterViews *views, const float *xyz, const float *normal, int64_t n,
@@ -1075,59 +748,23 @@ int dd_floater_votes(const DDFilterViews *views, const float *xyz, const float *
     if (!views->depth || !views->cams) return fail("depth / cams is NULL");
     if (n < 0) return fail("n is negative");
     if (views->mode < 0 || views->mode > 4) return fail("mode must be 0 .. 4");
+    if (views->mode == 2) return fail("mode 2 (the float32 first pass and its verify build) was removed in ABI 9");
     if (n > 0 && (!xyz || !normal || !votes_dev)) return fail("xyz / normal / votes_dev is NULL");
     if (n == 0) return DD_OK;
     FArgs a;
     a.xyz = xyz; a.normal = normal; a.depth = views->depth; a.mask = views->mask; a.cams = views->cams;
     a.votes = votes_dev; a.n = n; a.hw = (long long)views->height * views->width;
     a.V = views->num_views; a.H = views->height; a.W = views->width; a.accumulate = accumulate;
-    a.depth_threshold = views->depth_threshold; a.grazing_cos = views->grazing_cos; a.diag = views->reserved;
+    a.depth_threshold = views->depth_threshold; a.grazing_cos = views->grazing_cos;
     const long long blocks = (n + 255) / 256;
     if (blocks > 0x7fffffffll) return fail("too many points for one launch; split the call");
-    a.tab = nullptr; a.stats = nullptr;
     hipStream_t s = (hipStream_t)stream;
     const int V = views->num_views;
-    const long long chunks_total = (V + VQ_CHUNK - 1) / VQ_CHUNK;
-    const size_t hdr = (size_t)V_SHARDS * 128;
-    const size_t fixed = hdr + (size_t)V * 128 + hdr;                                  // stats shards | table | queue counters
-    const size_t bitmap = (((size_t)blocks * (size_t)chunks_total + 31) / 32 * 4 + 15) & ~(size_t)15;
-    const bool usable = views->workspace && views->workspace_bytes >= (int64_t)(fixed + bitmap + 8 * 4096 * V_SHARDS) &&
-                        (unsigned long long)blocks * (unsigned long long)chunks_total < (1ull << 32) && V < (1 << 20) && n < (1ll << 43);
-    const bool first_pass = (views->mode == 0 || views->mode == 2) && usable && views->grazing_cos > 0.0 && views->grazing_cos < 1e6 &&
-                            views->height < (1 << 23) && views->width < (1 << 23) && (long long)views->height * views->width < (1ll << 31);
-    if (views->mode == 2 && !first_pass) return fail("mode 2 (verify) needs the workspace of dd_votes_workspace_bytes()");
-    if (first_pass) {
-        if (((uintptr_t)views->workspace % 16) != 0) return fail("workspace must be 16-byte aligned");
-        char *w = reinterpret_cast<char *>(views->workspace);
-        a.stats = reinterpret_cast<unsigned long long *>(w);
-        a.tab = reinterpret_cast<const float *>(w + hdr);
-        VoteQueue *gq = reinterpret_cast<VoteQueue *>(w + hdr + (size_t)V * 128);
-        unsigned *redo = reinterpret_cast<unsigned *>(w + fixed);
-        unsigned long long *entries = reinterpret_cast<unsigned long long *>(w + fixed + bitmap);
-        const unsigned long long total_entries = ((size_t)views->workspace_bytes - fixed - bitmap) / 8;
-        const unsigned long long capacity = total_entries / V_SHARDS;                   // per shard
-        if (hipMemsetAsync(w, 0, hdr, s) != hipSuccess) { snprintf(g_ferr, sizeof(g_ferr), "hipMemsetAsync(stats) failed"); return DD_ERR_LAUNCH; }
-        hipLaunchKernelGGL(votes_prepare, dim3((unsigned)((V + 63) / 64)), dim3(64), 0, s, views->cams, const_cast<float *>(a.tab), V,
-                           views->height, views->width);
-        // views in rounds sized so that the undecided pairs of a round (~3 % at worst in practice) fit the queue; an
-        // overflow is still exact (redo bitmap), only slower
-        long long per_round = (long long)((double)total_entries / (0.03 * (double)n + 1.0));
-        if (per_round < 1) per_round = 1;
-        if (per_round >= V) per_round = V;
-        else if (per_round > VQ_CHUNK) per_round = per_round / VQ_CHUNK * VQ_CHUNK;
-        const unsigned long long want = (capacity + 255) / 256;
-        const unsigned resolve_blocks = (unsigned)(want < 1 ? 1 : (want > 1024 ? 1024 : want));        // per shard
-        FArgs r = a;
-        for (int v0 = 0; v0 < V; v0 += (int)per_round) {
-            const int v1 = v0 + per_round < V ? v0 + (int)per_round : V;
-            if (hipMemsetAsync(gq, 0, hdr + bitmap, s) != hipSuccess) { snprintf(g_ferr, sizeof(g_ferr), "hipMemsetAsync(queue) failed"); return DD_ERR_LAUNCH; }
-            r.accumulate = (v0 == 0) ? a.accumulate : 1;
-            if (views->mode == 2) hipLaunchKernelGGL(floater_votes_kernel32<true>, dim3((unsigned)blocks), dim3(256), 0, s, r, v0, v1, gq, entries, capacity, redo, (int)chunks_total);
-            else hipLaunchKernelGGL(floater_votes_kernel32<false>, dim3((unsigned)blocks), dim3(256), 0, s, r, v0, v1, gq, entries, capacity, redo, (int)chunks_total);
-            hipLaunchKernelGGL(votes_resolve, dim3(resolve_blocks, V_SHARDS), dim3(256), 0, s, r, gq, entries, capacity);
-            hipLaunchKernelGGL(votes_redo, dim3((unsigned)blocks), dim3(256), 0, s, r, v0, v1, redo, (int)chunks_total);
-        }
-    } else if (views->mode == 3 || views->mode == 4) {
+    // mode 0 (a zero-initialised struct) = the best the workspace allows: 4 (culling chosen on the device) with
+    // 512 * V + 64 bytes, 1 (table kernel) with 256 * V, the table-free kernel without a workspace
+    int mode = views->mode;
+    if (mode == 0) mode = (views->workspace && views->workspace_bytes >= (int64_t)V * 512 + 64) ? 4 : 1;
+    if (mode == 3 || mode == 4) {
         // float64 with per-workgroup view culling: 3 = always, 4 = chosen on the device from a sample of the workgroups
         if (!views->workspace || views->workspace_bytes < (int64_t)V * 512 + 64) return fail("modes 3 / 4 need a workspace of 512 * num_views + 64 bytes");
         if (((uintptr_t)views->workspace % 32) != 0) return fail("workspace must be 32-byte aligned");
@@ -1141,7 +778,7 @@ int dd_floater_votes(const DDFilterViews *views, const float *xyz, const float *
         const bool two_level = views->workspace_bytes >= (int64_t)V * 512 + 64 + supers * words * 8;
         hipLaunchKernelGGL(votes_prepare64, dim3((unsigned)((V + 63) / 64)), dim3(64), 0, s, views->cams, tab, V, views->height, views->width);
         hipLaunchKernelGGL(votes_prepare_planes, dim3((unsigned)((V + 63) / 64)), dim3(64), 0, s, views->cams, planes, V, views->height, views->width);
-        if (views->mode == 4) {
+        if (mode == 4) {
             if (hipMemsetAsync(decide, 0, 16, s) != hipSuccess) { snprintf(g_ferr, sizeof(g_ferr), "hipMemsetAsync(decide) failed"); return DD_ERR_LAUNCH; }
             const long long sample = blocks < 512 ? blocks : 512, stride = blocks / sample;
             hipLaunchKernelGGL(votes_cull_estimate, dim3((unsigned)sample), dim3(256), 0, s, a, (const double *)planes, decide, stride);
@@ -1151,13 +788,13 @@ int dd_floater_votes(const DDFilterViews *views, const float *xyz, const float *
                                           (const unsigned long long *)decide);
         hipLaunchKernelGGL(floater_votes_kernel_cull, dim3((unsigned)blocks), dim3(256), 0, s, a, (const double *)tab, (const double *)planes,
                            (const unsigned long long *)decide, (const unsigned long long *)(two_level ? masks : nullptr), words);
-    } else if (views->mode == 1 && views->workspace && views->workspace_bytes >= (int64_t)V * 256) {
+    } else if (views->workspace && views->workspace_bytes >= (int64_t)V * 256) {
         if (((uintptr_t)views->workspace % 32) != 0) return fail("workspace must be 32-byte aligned");
         double *tab = reinterpret_cast<double *>(views->workspace);
         hipLaunchKernelGGL(votes_prepare64, dim3((unsigned)((V + 63) / 64)), dim3(64), 0, s, views->cams, tab, V, views->height, views->width);
         hipLaunchKernelGGL(floater_votes_kernel2, dim3((unsigned)blocks), dim3(256), 0, s, a, (const double *)tab, (const unsigned long long *)nullptr);
     } else
-    hipLaunchKernelGGL(floater_votes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(floater_votes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
     if (hipGetLastError() != hipSuccess) { snprintf(g_ferr, sizeof(g_ferr), "floater_votes launch failed"); return DD_ERR_LAUNCH; }
     return DD_OK;
 }

@@ -260,14 +260,18 @@ __global__ __launch_bounds__(FIT_T) void refine_fit_kernel(const FitArgs a) {
     if (tid == 0) { a.meta[0] = s_cnt; a.meta[1] = m1; a.meta[2] = m; a.meta[3] = removed; a.meta[4] = (int)__float_as_uint(scale); }
 }
 
-// Sort the knots by x (torch.argsort at :149-151) in one workgroup: bitonic network in LDS, up to 4096 knots.
+// Sort the knots by x (torch.argsort at :149-151) in one workgroup: bitonic network in LDS, up to 4096 knots.  The key is
+// the pair (x, input index): equal x keep their input order (a stable sort), and the padding to a power of two
+// (+inf, index >= n) sorts strictly behind every real knot -- a real correspondence whose sampled depth is +inf (a bilinear
+// sample that touches an inf pixel passes the "> 0" test) stays inside the first n outputs with its own y.
 constexpr int SORT_MAX = 4096;
 __global__ __launch_bounds__(1024) void sort_knots_kernel(const float *x, const float *y, int n, float *xs, float *ys) {
     __shared__ float s_x[SORT_MAX], s_y[SORT_MAX];
+    __shared__ unsigned short s_i[SORT_MAX];
     const int tid = threadIdx.x;
     int np2 = 1;
     while (np2 < n) np2 <<= 1;
-    for (int i = tid; i < np2; i += 1024) { s_x[i] = i < n ? x[i] : __builtin_inff(); s_y[i] = i < n ? y[i] : 0.0f; }
+    for (int i = tid; i < np2; i += 1024) { s_x[i] = i < n ? x[i] : __builtin_inff(); s_y[i] = i < n ? y[i] : 0.0f; s_i[i] = (unsigned short)i; }
     __syncthreads();
     for (int k = 2; k <= np2; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -276,7 +280,13 @@ __global__ __launch_bounds__(1024) void sort_knots_kernel(const float *x, const 
                 if (p > i) {
                     const bool up = (i & k) == 0;
                     const float a0 = s_x[i], a1 = s_x[p];
-                    if ((a0 > a1) == up && a0 != a1) { s_x[i] = a1; s_x[p] = a0; const float t = s_y[i]; s_y[i] = s_y[p]; s_y[p] = t; }
+                    const unsigned short i0 = s_i[i], i1 = s_i[p];
+                    const bool greater = a0 > a1 || (a0 == a1 && i0 > i1);          // (x, index) order; indices are distinct
+                    if (greater == up) {
+                        s_x[i] = a1; s_x[p] = a0;
+                        s_i[i] = i1; s_i[p] = i0;
+                        const float t = s_y[i]; s_y[i] = s_y[p]; s_y[p] = t;
+                    }
                 }
             }
             __syncthreads();

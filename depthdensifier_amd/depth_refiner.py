@@ -205,11 +205,11 @@ class DepthRefiner:
             raise DDCoreError(rc, lib.dd_refine_last_error().decode())
         if also is not None:
             meta[5] = also.to(torch.int32)
-        if not hasattr(self, "_meta_slots"):
-            self._meta_slots = [torch.empty(8, dtype=torch.int32, pin_memory=True) for _ in range(8)]
-            self._meta_next = 0
-        host = self._meta_slots[self._meta_next % len(self._meta_slots)]      # a few page-locked result slots, round-robin
-        self._meta_next += 1
+        # page-locked result slots: a handle OWNS its slot from here until _fit_finish hands it back, so any number of
+        # begun handles may be open at once (the free list grows on demand; the pipeline's one-view lag uses two)
+        if not hasattr(self, "_meta_free"):
+            self._meta_free = []
+        host = self._meta_free.pop() if self._meta_free else torch.empty(8, dtype=torch.int32, pin_memory=True)
         host.copy_(meta, non_blocking=True)
         ready = torch.cuda.Event()
         ready.record(stream)
@@ -217,8 +217,12 @@ class DepthRefiner:
 
     def _fit_finish(self, fit: dict):
         """``(z_mono, z_metric, in_bounds, positive, kept, removed, scale, extra)``: the one synchronisation of the fit."""
+        if fit.get("host") is None:
+            raise RuntimeError("finish_refine: this handle has been finished already")
         fit["ready"].synchronize()
         inb, pos, kept, removed, scale_bits, extra = fit["host"][:6].tolist()
+        self._meta_free.append(fit["host"])                      # the slot is free for the next begun handle
+        fit["host"] = None
         scale = float(np.array([scale_bits], dtype=np.int32).view(np.float32)[0])
         buf = fit["buf"]
         return buf[0][:kept], buf[1][:kept], inb, pos, kept, removed, scale, extra
@@ -294,7 +298,13 @@ class DepthRefiner:
                 # the kernel's LDS table; otherwise the caller gets the refined map as usual.
                 if 2 <= n_corr <= 512 and n_masked >= 4:
                     kx, ky = self._sorted_knots(z_mono, z_metric)
-                    # scale_factor: a float, or (adaptive subsample) a 0-dim device tensor -- no second synchronisation here
+                    if self.verbose > 0:                       # the reference's messages (:317-321); float(scale) synchronises, so only when asked
+                        print(f"[DepthRefiner] Refined using {n_corr} correspondences")
+                        if removed > 0:
+                            print(f"[DepthRefiner] Removed {removed} outliers")
+                        print(f"[DepthRefiner] Effective scale: {float(scale):.3f}")
+                    # scale_factor: a float, or (adaptive subsample) a 0-dim device tensor -- no second synchronisation here;
+                    # float(result["scale_factor"]) gives the number in either case
                     return {"refined_depth": None, "curve": (kx, ky, bool(self.skip_smoothing)), "raw_depth": depth,
                             "num_correspondences": n_corr, "outliers_removed": removed, "scale_factor": scale}
             scale = float(scale)

@@ -52,7 +52,7 @@ def filter_cameras(intrinsics: ArrayLike, cam_from_world: ArrayLike) -> np.ndarr
     return cams
 
 
-VOTE_MODES = {"auto": 4, "float64": 1, "float64_classic": 1, "float64_cull": 3, "float64_cull1": 3, "float32_first": 0, "verify": 2}
+VOTE_MODES = {"auto": 4, "float64": 1, "float64_classic": 1, "float64_cull": 3, "float64_cull1": 3}
 
 
 def floater_votes(points: torch.Tensor, normals: torch.Tensor, depth: ArrayLike, intrinsics: ArrayLike,
@@ -70,12 +70,9 @@ def floater_votes(points: torch.Tensor, normals: torch.Tensor, depth: ArrayLike,
     ``"float64"`` = every decision in float64, the fastest un-culled form on MI355X (division-free image-bounds
     test first, grazing second, reciprocal only for pairs that reach the lookup; a 256-byte table per view is built in a
     scratch buffer); ``"float64_classic"`` = the round-1 kernel (projection with a reciprocal for every pair in front of
-    the camera; needs no scratch -- what a C caller gets with ``workspace = NULL``);
-    ``"float32_first"`` = a float32 first pass with rigorous error bounds whose undecided pairs (~1 %) are resolved in
-    float64 -- the same votes bit for bit, but measured SLOWER here (240-280 Gpairs/s: the float64 kernel's time is mostly
-    cheap early exits, not float64 arithmetic), kept as a checked experiment; ``"verify"`` = that first
-    pass with every confident decision cross-checked in float64.  ``stats`` (a dict) receives ``pairs``,
-    ``resolved_in_float64`` and, in verify mode, ``mismatches`` (one host synchronisation)."""
+    the camera; needs no scratch -- what a C caller gets with ``workspace = NULL``).  (The float32 first pass of round 2 --
+    same votes, 0.7-0.8x the rate -- was removed in round 3.)  ``stats`` (a dict) receives ``pairs`` and, in auto mode, the
+    counters of the on-device choice (one host synchronisation)."""
     if mode not in VOTE_MODES:
         raise ValueError(f"mode must be one of {sorted(VOTE_MODES)}")
     dev = _require_gpu(points.device if isinstance(points, torch.Tensor) and points.is_cuda else None)
@@ -107,8 +104,7 @@ def floater_votes(points: torch.Tensor, normals: torch.Tensor, depth: ArrayLike,
     V, H, W = d.shape
     # culling modes: two 256-byte tables per view, the decision counters, one mask of V bits per 65 536 points (level 1)
     cull_bytes = 512 * V + 64 + -(-pts.shape[0] // 65536) * (-(-V // 64)) * 8
-    ws_bytes = {"float64": 256 * V, "float64_classic": 16, "float64_cull": cull_bytes, "float64_cull1": 512 * V + 64, "auto": cull_bytes}.get(mode) \
-        or int(lib.dd_votes_workspace_bytes(V, pts.shape[0]))
+    ws_bytes = {"float64": 256 * V, "float64_classic": 16, "float64_cull": cull_bytes, "float64_cull1": 512 * V + 64, "auto": cull_bytes}[mode]
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     fv = DDFilterViews(num_views=V, height=H, width=W, depth=d.data_ptr(), mask=None if m is None else m.data_ptr(),
                        cams=cams.data_ptr(), grazing_cos=GRAZING_COS, depth_threshold=float(depth_threshold),
@@ -121,8 +117,7 @@ def floater_votes(points: torch.Tensor, normals: torch.Tensor, depth: ArrayLike,
         if mode == "auto":          # the two counters of the on-device choice (workgroup x view cells that survive / were sampled)
             d_ = ws[512 * V:512 * V + 16].view(torch.int64).tolist()
             stats.update(cull_sample_survived=int(d_[0]), cull_sample_cells=int(d_[1]), culled=bool(d_[0] * 10 < d_[1] * 9))
-        w = [0, 0] if mode.startswith("float64") or mode == "auto" else ws[:64 * 128].view(torch.int64).view(64, 16)[:, :2].sum(dim=0).tolist()   # 64 shards, a line each
-        stats.update(pairs=int(pts.shape[0]) * V, resolved_in_float64=int(w[0]), mismatches=int(w[1]), mode=mode)
+        stats.update(pairs=int(pts.shape[0]) * V, mode=mode)
     # asynchronous: temporaries freed here are only reused by later work on the same stream
     return votes
 

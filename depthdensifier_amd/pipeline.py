@@ -341,29 +341,40 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
 
     t0 = time.time()
     report.update(dense_points=n_kept, removed=removed, total_points=rec.num_points3D() + n_kept)
+    where, layout_error = None, None
     if ranks.rank == 0:
-        if ranks.world > 1:
-            # The reference rescales the camera of EVERY processed view in place (:172-173) before the model is
-            # written; this rank did so for its own shard only.  Same calls, same order, for the other ranks' views.
-            for im in todo[hi:]:
-                pw, ph = _processing_size(config.paths.image_dir / im.name, f)
-                rec.cameras[im.camera_id].rescale(new_width=pw, new_height=ph)
-        say(f"Adding {n_kept} new dense points...")
-        config.paths.output_model_dir.mkdir(parents=True, exist_ok=True)
-        # :355-358 + :363 -- the dense records are formatted on the GPU and streamed behind the sparse points
-        # (model_writer.py); nothing of the dense cloud is materialised on the host
-        # (sharded write: rank 0 lays the file out -- cameras, images, sparse points, room for every dense record --
-        # and then writes its slice like everybody else)
-        where = rec.write_binary(config.paths.output_model_dir, dense=None if sharded_write else kept, dense_total=n_kept)
+        try:
+            if ranks.world > 1:
+                # The reference rescales the camera of EVERY processed view in place (:172-173) before the model is
+                # written; this rank did so for its own shard only.  Same calls, same order, for the other ranks' views.
+                for im in todo[hi:]:
+                    pw, ph = _processing_size(config.paths.image_dir / im.name, f)
+                    rec.cameras[im.camera_id].rescale(new_width=pw, new_height=ph)
+            say(f"Adding {n_kept} new dense points...")
+            config.paths.output_model_dir.mkdir(parents=True, exist_ok=True)
+            # :355-358 + :363 -- the dense records are formatted on the GPU and streamed behind the sparse points
+            # (model_writer.py); nothing of the dense cloud is materialised on the host
+            # (sharded write: rank 0 lays the file out -- cameras, images, sparse points, room for every dense record --
+            # and then writes its slice like everybody else)
+            where = rec.write_binary(config.paths.output_model_dir, dense=None if sharded_write else kept, dense_total=n_kept)
+        except Exception as e:      # noqa: BLE001  (disk full, permissions ...): the other ranks must not wait for a file that never comes
+            if not sharded_write:
+                raise
+            layout_error = f"{type(e).__name__}: {e}"
     if sharded_write:
         import torch.distributed as dist
         from .model_writer import RECORD_BYTES, write_dense_at
-        box = [where if ranks.rank == 0 else None]
+        box = [(where, layout_error) if ranks.rank == 0 else None]
         dist.broadcast_object_list(box, src=0)          # also orders the writes: the file exists at its full size from here on
-        own_lo = plan.rank_rows[ranks.rank][0]
+        where, layout_error = box[0]
+        if layout_error is not None:                    # every rank raises the same error instead of hanging in a collective
+            raise RuntimeError(f"rank 0 could not lay out the model file: {layout_error}")
+        own_lo, own_hi = plan.rank_rows[ranks.rank]
+        if len(kept) != own_hi - own_lo:                # a rank writing more or fewer records than its slot would corrupt its neighbours'
+            raise RuntimeError(f"rank {ranks.rank} holds {len(kept)} kept points but its slice of the model file has room for {own_hi - own_lo}")
         if len(kept):
-            write_dense_at(config.paths.output_model_dir / "points3D.bin", box[0]["dense_offset"] + own_lo * RECORD_BYTES,
-                           kept, box[0]["first_dense_id"] + own_lo)
+            write_dense_at(config.paths.output_model_dir / "points3D.bin", where["dense_offset"] + own_lo * RECORD_BYTES,
+                           kept, where["first_dense_id"] + own_lo)
         dist.barrier()
     if ranks.rank == 0:
         say(f"COLMAP binary model saved to: {config.paths.output_model_dir}")

@@ -205,7 +205,7 @@ typedef struct DDFilterViews {
     int32_t num_views;
     int32_t height;
     int32_t width;
-    int32_t reserved;       /* 0 (timing experiments of the float32 pass: 1 no gather, 2 / 4 stop after the bounds / sign test) */
+    int32_t reserved;       /* 0 */
     const float *depth;     /* (V,H,W) refined depth */
     const uint8_t *mask;    /* (V,H,W) or NULL; mask == 0 reads as depth 0 (scripts/test.py:194) */
     const double *cams;     /* (V,24) float64 per view: cam_from_world 3x4 row-major [0..11]
@@ -214,23 +214,19 @@ typedef struct DDFilterViews {
     double grazing_cos;     /* 0.087, scripts/test.py:295 */
     float depth_threshold;  /* FilteringConfig.depth_threshold = 0.7, scripts/test.py:45-46, 320 */
     float reserved2;
-    void *workspace;        /* NULL: the float64 kernel of round 1.  With mode = 1 and >= 256 * num_views bytes (32-B aligned):
-                               the float64 kernel builds a per-view table there (K [R|t] and a band coefficient) and tests the
-                               image bounds without the division -- same votes, 5-10 % faster on coherent normal maps.  With
-                               mode = 0 / 2: device scratch
-                               of dd_votes_workspace_bytes(num_views, n) bytes (less is accepted: more rounds of views), 16-B
-                               aligned, for the EXPERIMENTAL float32 first pass: float32 evaluation with rigorous error bounds,
-                               undecided pairs (~1 %) resolved in float64 through a queue -- the same votes bit for bit, measured
-                               0.7-0.8x the float64 kernel's rate.  After the stream has drained the first
-                               8 KiB hold 64 shards of 16 uint64: [0] pairs left undecided, [1] verify disagreements. */
+    void *workspace;        /* device scratch, 32-byte aligned, or NULL.  NULL: the table-free float64 kernel of round 1.
+                               >= 256 * num_views bytes: the float64 kernel builds a per-view table there (K [R|t] and a band
+                               coefficient) and tests the image bounds without the division -- same votes, 5-10 % faster on
+                               coherent normal maps.  >= 512 * num_views + 64 bytes: per-workgroup view culling becomes
+                               possible (a view is skipped for 256 consecutive points when their bounding sphere cannot touch
+                               its frustum -- conservative, same votes); with ceil(n / 65536) * ceil(num_views / 64) * 8 bytes
+                               more (dd_votes_workspace_bytes() covers it) the cull is two-level: a mask of visible views per
+                               65 536 consecutive points first */
     int64_t workspace_bytes;
-    int32_t mode;           /* with a workspace: 0 = float32 first pass; 1 = float64 throughout; 2 = verify: every decision of
-                               the float32 pass is also taken in float64 and disagreements are counted (must be 0);
-                               3 = float64 with per-workgroup view culling (a view is skipped for 256 consecutive points when
-                               their bounding sphere cannot touch its frustum -- conservative, same votes); 4 = 1 or 3, chosen on
-                               the device from a sample of the workgroups.  3 / 4 need 512 * num_views + 64 bytes, 32-B aligned; with
-                               ceil(n / 65536) * ceil(num_views / 64) * 8 bytes more (dd_votes_workspace_bytes() covers it) the cull
-                               is two-level: a mask of visible views per 65 536 consecutive points first */
+    int32_t mode;           /* 0 = the best the workspace allows (4, else 1, else the table-free kernel); 1 = float64 with
+                               the table, no culling; 3 = culling always; 4 = 1 or 3, chosen on the device from a sample of
+                               the workgroups (culling when it removes more than 10 % of the workgroup x view cells);
+                               2 = removed (the float32 first pass of ABI 8) */
     int32_t reserved3;
 } DDFilterViews;
 

@@ -214,11 +214,10 @@ def test_gpu_compact_cloud(n, fields):
 
 
 @pytest.mark.gpu
-def test_float32_first_pass_gives_the_float64_votes():
-    """The optional float32 first pass (rigorous error bounds, undecided pairs resolved in float64): votes equal the
-    float64 kernel's bit for bit, and in verify mode not one confident float32 decision disagrees with float64 -- on a
-    ring scene, on points that reproject exactly onto pixel centres / image borders / the camera centre, on huge and
-    non-finite coordinates, and with the queue squeezed into a small workspace (several rounds, overflow -> redo)."""
+def test_every_vote_kernel_gives_the_oracle_votes_on_special_points():
+    """The float64 kernels (round-1 form, division-free bounds test, culling, the on-device choice, and what a zero-initialised
+    C struct selects): the same votes on a ring scene, on points that reproject exactly onto pixel centres / image borders /
+    the camera centre, on huge and non-finite coordinates -- and the oracle's votes on every finite point."""
     import ctypes as C
     import torch
     if not torch.cuda.is_available():
@@ -234,38 +233,30 @@ def test_float32_first_pass_gives_the_float64_votes():
     cloud = dd.unproject_views(depth_in, d["params"], E, mask=d["mask"], normal=d["normal"])      # points ON pixel centres of their own view
     pts, nrm = cloud.points.clone(), cloud.normals.clone()
     n = len(pts)
-    rng = np.random.default_rng(0)
     centres = torch.as_tensor(np.stack([-E[v, :, :3].T @ E[v, :, 3] for v in range(9)]), dtype=torch.float32, device="cuda")
     pts[:9] = centres                                                          # exactly at a camera centre
     pts[100:110] = float("nan"); pts[110:120] = float("inf"); pts[120:130] = 3e30; nrm[130:140] = float("nan")
     pts[140:150] *= 1e-30                                                      # underflow territory
-    st64, st32, stv = {}, {}, {}
-    v64 = dd.floater_votes(pts, nrm, depth_in, K, E, mask=d["mask"], mode="float64", stats=st64)
-    v32 = dd.floater_votes(pts, nrm, depth_in, K, E, mask=d["mask"], mode="float32_first", stats=st32)
-    vv = dd.floater_votes(pts, nrm, depth_in, K, E, mask=d["mask"], mode="verify", stats=stv)
-    assert torch.equal(v32, v64) and torch.equal(vv, v64)
-    vc = dd.floater_votes(pts, nrm, depth_in, K, E, mask=d["mask"], mode="float64_classic")
-    assert torch.equal(vc, v64)                                                # division-free bounds test vs the round-1 kernel
+    v64 = dd.floater_votes(pts, nrm, depth_in, K, E, mask=d["mask"], mode="float64")
+    for mode in ("float64_classic", "float64_cull", "float64_cull1", "auto"):
+        assert torch.equal(dd.floater_votes(pts, nrm, depth_in, K, E, mask=d["mask"], mode=mode), v64), mode
     fin = torch.isfinite(pts).all(dim=1).cpu().numpy()                         # and the oracle on every finite point
     culled = np.where(d["mask"], depth_in, 0).astype(np.float32)
     ref = forc.floater_votes(pts.cpu().numpy()[fin], nrm.cpu().numpy()[fin], culled, K, E)
     assert np.array_equal(v64.cpu().numpy()[fin], ref)
-    assert stv["mismatches"] == 0
-    assert 0 < st32["resolved_in_float64"] < 0.2 * st32["pairs"]              # own-view pairs sit on integers: undecided by design
     assert int(v64.max()) >= 3
-    # a workspace with room for only a few hundred queue entries per shard: rounds of views + redo cells, same votes
+    # mode 0 -- a zero-initialised C struct -- is the best the workspace allows: all three sizes, same votes
     V, H, W = depth_in.shape
     cams = torch.from_numpy(filter_cameras(K, E)).cuda()
     dz = torch.where(torch.as_tensor(d["mask"]).cuda(), torch.as_tensor(depth_in).cuda(), torch.zeros((), device="cuda")).contiguous()
-    blocks = (n + 255) // 256
-    small = 2 * 64 * 128 + V * 128 + ((blocks + 31) // 32 * 4 + 15) // 16 * 16 + 8 * 4096 * 64 + 4096
-    ws = torch.zeros(small, dtype=torch.uint8, device="cuda")
-    out = torch.zeros(n, dtype=torch.int32, device="cuda")
-    fv = _lib.DDFilterViews(num_views=V, height=H, width=W, depth=dz.data_ptr(), mask=None, cams=cams.data_ptr(), grazing_cos=0.087,
-                            depth_threshold=0.7, workspace=ws.data_ptr(), workspace_bytes=ws.numel(), mode=0)
-    rc = _lib.lib.dd_floater_votes(C.byref(fv), pts.data_ptr(), nrm.data_ptr(), n, out.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
-    assert rc == 0, _lib.lib.dd_filter_last_error()
-    assert torch.equal(out, v64)
+    for nbytes in (0, 256 * V, int(_lib.lib.dd_votes_workspace_bytes(V, n))):
+        ws = torch.zeros(max(nbytes, 32), dtype=torch.uint8, device="cuda")
+        out = torch.zeros(n, dtype=torch.int32, device="cuda")
+        fv = _lib.DDFilterViews(num_views=V, height=H, width=W, depth=dz.data_ptr(), mask=None, cams=cams.data_ptr(), grazing_cos=0.087,
+                                depth_threshold=0.7, workspace=ws.data_ptr() if nbytes else None, workspace_bytes=nbytes, mode=0)
+        rc = _lib.lib.dd_floater_votes(C.byref(fv), pts.data_ptr(), nrm.data_ptr(), n, out.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, _lib.lib.dd_filter_last_error()
+        assert torch.equal(out, v64), nbytes
 
 
 @pytest.mark.gpu
@@ -369,5 +360,5 @@ def test_floater_votes_argument_errors():
     rc, msg = call(cams=None)
     assert rc == -1 and "cams" in msg
     rc, msg = call(mode=2)
-    assert rc == -1 and "verify" in msg
+    assert rc == -1 and "removed" in msg
     torch.cuda.synchronize()

@@ -242,6 +242,35 @@ def test_sort_knots_kernel():
         order = torch.argsort(x)
         assert torch.equal(xs, x[order]) and torch.equal(ys, y[order])
     assert lib.dd_sort_knots(x.data_ptr(), y.data_ptr(), 5000, xs.data_ptr(), ys.data_ptr(), None) == -1
+    # ties and +inf keys: equal x keep their input order, and a real +inf knot is not displaced by the padding
+    x = torch.tensor([3.0, float("inf"), 1.0, 3.0, float("inf"), 0.5, 3.0], device="cuda")      # n = 7 -> one padding slot
+    y = torch.arange(7, dtype=torch.float32, device="cuda") + 10
+    xs, ys = torch.empty_like(x), torch.empty_like(y)
+    assert lib.dd_sort_knots(x.data_ptr(), y.data_ptr(), 7, xs.data_ptr(), ys.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+    order = torch.argsort(x, stable=True)
+    assert torch.equal(xs, x[order]) and torch.equal(ys, y[order]), (xs, ys)
+
+
+@pytest.mark.gpu
+def test_many_begun_handles_keep_their_own_results(g):
+    """begin_refine / finish_refine are public; more than 8 open handles used to share page-locked result slots."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from depthdensifier_amd.depth_refiner import DepthRefiner
+    r = _refiner()
+    assert r.device.type == "cuda"
+    depth, pts, E, K, mask = (g[f"default_in_{k}"] for k in ("depth", "points3D", "cam_from_world", "K", "mask"))
+    handles, want = [], []
+    for k in range(12):                                    # each view sees a different subset of the sparse points
+        sub = pts[: max(40, len(pts) - 60 * k)]
+        want.append(r.refine_depth(depth, None, sub, E[:3], K, mask))
+        handles.append((sub, r.begin_refine(depth, None, sub, E[:3], K, mask)))
+    for (sub, h), w in zip(reversed(handles), reversed(want)):          # finished in another order than begun
+        got = r.finish_refine(h)
+        assert got["num_correspondences"] == w["num_correspondences"] and got.get("outliers_removed") == w.get("outliers_removed")
+        assert np.array_equal(got["refined_depth"], w["refined_depth"])
+    with pytest.raises(RuntimeError):
+        r.finish_refine(handles[0][1])
 
 
 @pytest.mark.gpu
