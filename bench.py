@@ -249,6 +249,7 @@ def strong_scaling_record(args, dd, D, dist, use_dist, rank, world, device, fenc
     torch.cuda.synchronize(device)
     t_gen = time.perf_counter() - t_gen
     rec = {"views_total": V_total, "views_per_gpu": len(ids), "height": H, "width": W, "scaling": "strong", "chunks": args.chunks,
+           "gather_dst": args.gather_dst, "allgatherv": os.environ.get("DD_ALLGATHERV", "p2p"),
            "mask_kind": args.mask_kind,
            "scene_generation_s": round(t_gen, 2)}
 
@@ -319,7 +320,8 @@ def strong_scaling_record(args, dd, D, dist, use_dist, rank, world, device, fenc
 
         def replicated():
             if use_dist:
-                return D.fuse_replicated(batch, V_total, record=record, chunks=args.chunks, buffers=bufs)
+                return D.fuse_replicated(batch, V_total, record=record, chunks=args.chunks, buffers=bufs,
+                                         dst=None if args.gather_dst == "all" else int(args.gather_dst))
             counts = dd.count_valid(batch)              # N = 1: the same steps minus the wire
             b = dd.CloudBuilder(n_total, points=record == "rows", normals=record == "rows", colors=record == "rows", pixel_index=False,
                                 packed=record != "rows", buffers=bufs, device=device)
@@ -473,6 +475,7 @@ def main() -> None:
     ap.add_argument("--strong-views", type=int, default=2000, help="views of the strong-scaling sub-record (BASELINE configs[2]); 0 = skip")
     ap.add_argument("--strong-steps", type=int, default=3, help="timed passes per leg of the strong-scaling sub-record")
     ap.add_argument("--chunks", type=int, default=5, help="view chunks per rank whose exchange overlaps the next chunk's kernel")
+    ap.add_argument("--gather-dst", default="all", choices=("all", "0"), help="gathered legs: every rank receives the whole cloud (all) or only rank 0 does")
     ap.add_argument("--gather-timeout", type=float, default=240.0, help="watchdog for the strong-scaling leg, seconds")
     ap.add_argument("--mask-kind", default="blob", choices=("blob", "bernoulli"),
                     help="blob: smooth regions (default); bernoulli: independent per-pixel cull, worst case for compaction")

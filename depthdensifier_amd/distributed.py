@@ -307,7 +307,8 @@ def fuse_replicated(batch, num_views_total: int, *, normals: bool = True, colors
     cap = total if receives else own_hi - own_lo
     rows = record == "rows"
     builder = CloudBuilder(cap, points=rows, normals=normals and rows, colors=colors and rows, pixel_index=pixel_index,
-                           view_index=view_index, packed=not rows, buffers=buffers, start=own_lo - base, device=batch.device)
+                           view_index=view_index, packed=not rows, buffers=buffers, start=own_lo - base, device=batch.device,
+                           placement="first")      # these arrays go over RCCL: plain allocations (arena memory is not IPC-exportable)
     moved = [t for t in (builder.xyz, builder.normal, builder.rgb, builder.pix, builder.view, builder.packed) if t is not None]
     work = []
     for (lo, hi), ranges in zip(plan.chunk_views, plan.chunk_rows):
