@@ -108,7 +108,7 @@ struct DDArena {
     hipMemAllocationProp prop;
     std::mutex mu;
     // statistics
-    int64_t created, released, probes;
+    int64_t created, released, probes, mixed;
     bool debug;                 // DD_ARENA_DEBUG: one line per classified chunk on stderr
     int pool_per_class;         // classified chunks of each class kept (unmapped) when arrays are freed or scouting leaves
                                 // spares, so that the next allocation need not scout again; dd_arena_trim gives them back
@@ -216,6 +216,17 @@ int scout_one(DDArena *A, int *chunk_out) {
     }
     for (int k = 0; k < A->n_classes; ++k)          // decided after all probes: fast_ms may have moved
         if (is_same_class(A, t[k]) && (cls < 0 || t[k] > t[cls])) cls = k;
+    // The probes above saw the chunk's first window only.  The classes meet at two places of the physical memory that
+    // are not chunk-aligned, so a chunk can change class inside: its first against its last window must be a same-class pair.
+    float t_self = 0.f;
+    if ((rc = probe_pair(A, w, reinterpret_cast<float *>(slot_ptr(A, slot) + A->chunk - A->rows * 12), &t_self)) != DD_OK) return rc;
+    if (!is_same_class(A, t_self)) {
+        A->chunks[ci].cls = -1;                      // mixed: never handed out, goes back to the driver with the other spares
+        A->mixed += 1;
+        if (A->debug) fprintf(stderr, "[ddarena] chunk %d: first vs last window %.4f ms -> two classes inside, not used\n", ci, t_self);
+        *chunk_out = ci;
+        return DD_OK;
+    }
     if (cls < 0) {
         if (A->n_classes < MAX_CLASSES) {            // differs from every anchor: a new class, this chunk anchors it
             cls = A->n_classes++;
@@ -312,7 +323,7 @@ int dd_arena_create(int32_t device, int64_t chunk_bytes, DDArena **arena_out) {
     A->rows = std::min<size_t>((size_t)32 << 20, A->chunk / 24);      // two windows fit one chunk (the same-class reference)
     A->n_classes = 0;
     A->same_ms = A->fast_ms = 0.f;
-    A->created = A->released = A->probes = 0;
+    A->created = A->released = A->probes = A->mixed = 0;
     A->debug = getenv("DD_ARENA_DEBUG") != nullptr;
     A->pool_per_class = 4;
     A->seconds = 0.0;

@@ -43,7 +43,7 @@ batch = mk_batch(scene)
 P = batch.max_points
 print(f"{wl}: {V} views, cloud capacity {P} rows", flush=True)
 for r in range(R):
-    for mode, layout in (("first", ""), ("probed", "separated"), ("probed", "rotated")):
+    for mode, layout in (("first", ""), ("probed", "rotated")):
         import os
         os.environ["DD_PLACEMENT_LAYOUT"] = layout
         t0 = time.perf_counter()
@@ -58,5 +58,6 @@ for r in range(R):
             pass
         del b
         torch.cuda.empty_cache()
+        pl.trim(dev)
     ballast = torch.empty((r + 1) * 3 * 2**30, dtype=torch.uint8, device=dev)      # the next round starts somewhere else
 print(pl.get_arena(dev).stats(), flush=True)
