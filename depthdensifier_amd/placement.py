@@ -1,16 +1,17 @@
-"""Where the cloud's large arrays live in HBM (round 3; measurements in ``profiles/r03_placement_*.txt``).
+"""Where the cloud's large arrays live in HBM (round 3; DESIGN.md section 3, measurements in ``profiles/r03_placement_*.txt``,
+``r03_zone_*.txt``).
 
-The densify kernel writes two large row streams in lock step -- ``points`` and ``normals``, 12 bytes per point each, the
-same row of both at the same moment (the two list appends of ``scripts/test.py:238-240``, fused).  On MI355X the 288 GB of
-HBM fall into three classes of physical address ranges of about a third of the memory each.  Two such streams inside ONE
-class run 20-26 % slower than in two different classes, which costs 4-11 % of the densify kernel (2.94 vs 2.60 ms on the
-185-view 1080p workload).  A fresh process is handed memory from one end of the device, so everything it owns starts in
-one class -- the "box state" lottery of rounds 1 and 2.
+The densify kernel is bound by its row stores: ``points`` and ``normals``, 12 bytes per point each, the same row of both at the
+same moment (the two list appends of ``scripts/test.py:238-240``, fused).  On MI355X the 288 GB of HBM fall into three classes
+of physical address ranges of about a third of the memory each; two lock-step store streams inside ONE class run at 5.8 TB/s,
+in two classes at 7.1-7.2 TB/s -- 2.94 vs 2.60 ms for the 185-view 1080p workload.  A fresh process is handed memory from one
+end of the device, i.e. from one class: the "box state" lottery of rounds 1 and 2.
 
-``ZoneArena`` (``csrc/ddarena.hip`` behind ``dd_arena_*``) takes physical chunks through the virtual-memory API,
-classifies them with a two-stream store probe and builds each requested array from chunks of one class, arrays of different
-groups from different classes.  ``place_outputs`` is what ``CloudBuilder`` calls: points in one class, normals in another,
-colours in the third.  Nothing here changes a result: it only chooses physical pages.
+``ZoneArena`` (``csrc/ddarena.hip`` behind ``dd_arena_*``) takes physical memory in 1 GiB chunks through the virtual-memory API,
+classifies every chunk with a two-stream store probe against one anchor chunk per class, and maps each requested array from
+chunks of the classes its layout names: ``rotated(phase)`` -- chunk k from class (phase + k) mod 3 -- or class-pure per group.
+``place_outputs`` is what ``CloudBuilder`` calls: points / normals / colours rotated with phases 0 / 1 / 2, so rows written in lock
+step never share a class.  Nothing here changes a result: it only chooses physical pages.
 
 Arrays from the arena are ordinary device tensors for every kernel, but their memory is not IPC-exportable: buffers that
 RCCL sends or receives (``distributed.fuse_replicated``) are allocated normally and handed to ``CloudBuilder(buffers=...)``.

@@ -295,7 +295,7 @@ const char *dd_model_last_error(void);
  * HBM zone arena (ABI 9): where the large arrays of the fused cloud (scripts/test.py:264-266 final_point_cloud /
  * final_normals / final_colors) and of the per-view maps (:166-168) live in the 288 GB of an MI355X.  The physical memory
  * falls into three classes of about a third each; the densify kernel's two lock-step row streams (points + normals) cost
- * 4-11 % of the kernel's time when they share a class (DESIGN.md section 4, profiles/r03_placement_*.txt).  The arena takes
+ * 4-11 % of the kernel's time when they share a class (DESIGN.md section 3, profiles/r03_placement_*.txt).  The arena takes
  * physical chunks through the virtual-memory API, classifies each with a two-stream store probe against one anchor chunk
  * per class, and builds every requested array from chunks of ONE class, arrays of different groups from different
  * classes.  Host-side memory management: it changes addresses, never results.  Not for buffers handed to RCCL
