@@ -366,48 +366,165 @@ def allgather_views(local: torch.Tensor, num_views_total: int, group=None) -> to
     return allgatherv_rows(local.contiguous(), shard_sizes(num_views_total, world), group=group)
 
 
+def views_in_reach(points: torch.Tensor, K: "np.ndarray", E: "np.ndarray", sizes: Sequence[tuple], chunk: int = 65536) -> torch.Tensor:
+    """(V,) bool on the points' device: views whose image at least one of ``points`` COULD project into, in front of the
+    camera -- conservative (bounding spheres of runs of ``chunk`` consecutive points against the five half-spaces "in front of
+    the camera, inside the image", the same linear forms as the vote kernel's culling, ``csrc/ddfilter.hip``): a view outside
+    the result cannot vote on any of the points (``scripts/test.py:297-312`` never reaches the depth lookup), so leaving it
+    out of ``floater_votes`` changes no vote.  Points that are not finite put every view in reach."""
+    import numpy as np
+    V = len(sizes)
+    dev = points.device
+    n = points.shape[0]
+    if n == 0 or V == 0:
+        return torch.zeros(V, dtype=torch.bool, device=dev)
+    p = points.to(torch.float64)
+    finite = bool(torch.isfinite(p).all())
+    if not finite:
+        return torch.ones(V, dtype=torch.bool, device=dev)
+    pad = (-n) % chunk
+    if pad:
+        p = torch.cat([p, p[-1:].expand(pad, 3)])
+    p = p.view(-1, chunk, 3)
+    lo, hi = p.amin(dim=1), p.amax(dim=1)
+    c = 0.5 * (lo + hi)                                                     # (S,3) sphere centres
+    r = 0.5 * torch.linalg.vector_norm(hi - lo, dim=1) * (1.0 + 1e-6) + 1e-9     # (S,) half diagonals: every point is inside
+    Kt = torch.as_tensor(np.asarray(K, dtype=np.float64), device=dev)       # (V,3,3)
+    Et = torch.as_tensor(np.asarray(E, dtype=np.float64)[:, :3, :4], device=dev)      # (V,3,4)
+    M = Kt[:, :2, :] @ Et                                                   # (V,2,4): rows nu, nw of K [R|t]
+    Z = Et[:, 2, :]                                                         # (V,4): depth in the camera frame
+    W = torch.as_tensor([float(sz[1]) for sz in sizes], dtype=torch.float64, device=dev)[:, None]
+    H = torch.as_tensor([float(sz[0]) for sz in sizes], dtype=torch.float64, device=dev)[:, None]
+    planes = torch.stack([Z, M[:, 0], W * Z - M[:, 0], M[:, 1], H * Z - M[:, 1]], dim=1)      # (V,5,4): f(p) = a.p + b must be > 0 (>= 0)
+    csum = (1.0 + c.abs().sum(dim=1))[None, None, :]
+    out = torch.zeros(V, dtype=torch.bool, device=dev)
+    for v0 in range(0, V, 128):                                             # blocks of views: (128, 5, S) float64 temporaries
+        a, b = planes[v0:v0 + 128, :, :3], planes[v0:v0 + 128, :, 3]        # (v,5,3), (v,5)
+        f = torch.einsum("vki,si->vks", a, c) + b[..., None]                # value at the sphere centres
+        reach = f + torch.linalg.vector_norm(a, dim=2)[..., None] * r[None, None, :]      # the largest value inside the sphere
+        # slack: 1e-6 relative on every term (the float64 rounding of either formulation is 1e-16), plus the W * 1e-8 of den = zc + 1e-8
+        slack = 1e-6 * (a.abs().sum(dim=2) + b.abs())[..., None] * csum + 1e-7 * torch.maximum(W, H)[v0:v0 + 128, :, None]
+        out[v0:v0 + 128] = (reach + slack > 0).all(dim=1).any(dim=1)        # some sphere touches all five half-spaces
+    return out
+
+
+def _exchange_selected(local_stack: torch.Tensor, own_ids: Sequence[int], need_by_rank: Sequence[Sequence[int]], owner_of, group=None) -> torch.Tensor:
+    """Rows of a view-sharded stack sent only where they are needed: this rank holds the rows of ``own_ids`` (ascending global
+    view ids) in ``local_stack``; ``need_by_rank[r]`` (ascending) is what rank r wants.  Returns this rank's wanted rows in
+    that order.  One grouped batch of sends / receives (xGMI is point to point); backends without device send / recv
+    (gloo rehearsals) stage through host memory."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    want = list(need_by_rank[rank])
+    out = torch.empty((len(want),) + tuple(local_stack.shape[1:]), dtype=local_stack.dtype, device=local_stack.device)
+    pos_own = {v: i for i, v in enumerate(own_ids)}
+    pos_out = {v: i for i, v in enumerate(want)}
+    mine = [v for v in want if owner_of(v) == rank]
+    if mine:
+        out[[pos_out[v] for v in mine]] = local_stack[[pos_own[v] for v in mine]]
+    if world == 1:
+        return out
+    host = dist.get_backend(group) != "nccl"
+    glob = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
+    ops, landed, keep = [], [], []
+    for k in range(1, world):                              # peer order staggered per rank
+        to, frm = (rank + k) % world, (rank - k) % world
+        send_ids = [v for v in need_by_rank[to] if owner_of(v) == rank]
+        if send_ids:
+            rows = local_stack[[pos_own[v] for v in send_ids]].contiguous()
+            rows = rows.cpu() if host else rows
+            keep.append(rows)
+            ops.append(dist.P2POp(dist.isend, rows, glob(to), group))
+        recv_ids = [v for v in want if owner_of(v) == frm]
+        if recv_ids:                                       # ownership is contiguous in view order: one slice of `out`
+            a, b_ = pos_out[recv_ids[0]], pos_out[recv_ids[-1]] + 1
+            if host:
+                buf = torch.empty((b_ - a,) + tuple(out.shape[1:]), dtype=out.dtype)
+                landed.append((buf, a, b_))
+                ops.append(dist.P2POp(dist.irecv, buf, glob(frm), group))
+            else:
+                ops.append(dist.P2POp(dist.irecv, out[a:b_], glob(frm), group))
+    for w in (dist.batch_isend_irecv(ops) if ops else []):
+        w.wait()
+    for buf, a, b_ in landed:
+        out[a:b_].copy_(buf)
+    return out
+
+
 def floater_votes_sharded(local_cloud, local_views: Sequence[dict], num_views_total: int, depth_threshold: float = 0.7,
-                          group=None) -> torch.Tensor:
+                          group=None, stats: Optional[dict] = None, selective: Optional[bool] = None) -> torch.Tensor:
     """Votes of this rank's points against ALL views of a view-sharded scan.
 
     ``local_views``: this rank's views in order, each ``{"depth": (H,W) f32 device tensor, "mask": (H,W) bool or None,
-    "K": (3,3), "E": (3,4)}``; sizes may differ between views.  Depth maps, masks and cameras are all-gathered size
-    group by size group (2000 x 1080p = 16.6 GB, small next to 288 GB of HBM), then every rank votes on its own
-    points: the O(N*V) work splits by points and no point moves.  Votes are counts over the same set of views, so
-    they equal the one-GPU votes."""
+    "K": (3,3), "E": (3,4)}``; sizes may differ between views.  The cameras of all views are all-gathered (168 bytes per
+    view); every rank then works out which views its own points can reach at all (``views_in_reach``), the ranks exchange
+    these lists, and each depth map / mask travels only to the ranks that asked for it (round 3; an inward-facing ring
+    degrades to the all-gather of rounds 1-2, a corridor scan moves a few views per rank instead of 2000 x 1080p = 20 GB).
+    Every rank votes on its own points: the O(N*V) work splits by points and no point moves.  A view outside a rank's list
+    cannot vote on its points, so the votes equal the one-GPU votes.  ``selective=False`` (or ``DD_FILTER_GATHER=all``)
+    forces the all-gather.  ``stats`` receives ``views_total``, ``views_received``, ``bytes_received``."""
     import numpy as np
     from .filtering import floater_votes
 
-    world = dist.get_world_size(group)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = local_cloud.points.device
-    parts: list = [None] * world
-    dist.all_gather_object(parts, [tuple(v["depth"].shape) for v in local_views], group=group)    # control plane
-    all_shapes = [shp for part in parts for shp in part]
-    if len(all_shapes) != num_views_total:
-        raise ValueError(f"ranks hold {len(all_shapes)} views in total, expected {num_views_total}")
+    if selective is None:
+        selective = os.environ.get("DD_FILTER_GATHER", "needed") != "all"
+    f64 = lambda a: np.asarray(a.cpu() if isinstance(a, torch.Tensor) else a, dtype=np.float64)
+    parts: list = [None] * world                                   # control plane: sizes and cameras of every view
+    dist.all_gather_object(parts, [(tuple(v["depth"].shape), f64(v["K"])[:3, :3], f64(v["E"])[:3, :4]) for v in local_views], group=group)
+    flat = [x for part in parts for x in part]
+    if len(flat) != num_views_total:
+        raise ValueError(f"ranks hold {len(flat)} views in total, expected {num_views_total}")
+    all_shapes = [x[0] for x in flat]
+    K_all = np.stack([x[1] for x in flat]) if flat else np.zeros((0, 3, 3))
+    E_all = np.stack([x[2] for x in flat]) if flat else np.zeros((0, 3, 4))
     bounds, start = [], 0
     for part in parts:
         bounds.append((start, start + len(part)))
         start += len(part)
+    owner_of = lambda v: next(r for r, (lo, hi) in enumerate(bounds) if lo <= v < hi)
+    my_lo = bounds[rank][0]
+    if selective:
+        reach = views_in_reach(local_cloud.points, K_all, E_all, all_shapes).cpu().numpy()
+        needs: list = [None] * world
+        dist.all_gather_object(needs, np.nonzero(reach)[0].tolist(), group=group)
+    else:
+        needs = [list(range(num_views_total))] * world
     votes = torch.zeros(len(local_cloud), dtype=torch.int32, device=dev)
+    received = received_bytes = 0
     for shp in dict.fromkeys(all_shapes):                         # distinct sizes, first-seen order (same on all ranks)
-        rows = [sum(1 for k in range(lo, hi) if all_shapes[k] == shp) for lo, hi in bounds]
-        mine = [v for v in local_views if tuple(v["depth"].shape) == shp]
+        group_ids = [k for k in range(num_views_total) if all_shapes[k] == shp]
+        in_group = set(group_ids)
+        need_by_rank = [[v for v in needs[r] if v in in_group] for r in range(world)]
+        own_ids = [k for k in group_ids if bounds[rank][0] <= k < bounds[rank][1]]
+        mine = [local_views[k - my_lo] for k in own_ids]
 
         def stacked(make, tail, dtype):
             if mine:
                 return torch.stack([make(v) for v in mine]).contiguous()
             return torch.empty((0,) + tuple(tail), dtype=dtype, device=dev)
 
-        f64 = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64), device=dev)
-        depth = allgatherv_rows(stacked(lambda v: v["depth"].to(torch.float32), shp, torch.float32), rows, group=group)
         ones = lambda v: torch.ones(shp, dtype=torch.uint8, device=dev)
-        mask = allgatherv_rows(stacked(lambda v: ones(v) if v.get("mask") is None else v["mask"].view(torch.uint8) if v["mask"].dtype == torch.bool
-                                       else (v["mask"] > 0).view(torch.uint8), shp, torch.uint8), rows, group=group)
-        K = allgatherv_rows(stacked(lambda v: f64(v["K"])[:3, :3], (3, 3), torch.float64), rows, group=group)
-        E = allgatherv_rows(stacked(lambda v: f64(v["E"])[:3, :4], (3, 4), torch.float64), rows, group=group)
-        floater_votes(local_cloud.points, local_cloud.normals, depth, K.cpu().numpy(), E.cpu().numpy(), mask=mask,
-                      depth_threshold=depth_threshold, votes=votes)
+        d_loc = stacked(lambda v: v["depth"].to(torch.float32), shp, torch.float32)
+        m_loc = stacked(lambda v: ones(v) if v.get("mask") is None else v["mask"].view(torch.uint8) if v["mask"].dtype == torch.bool
+                        else (v["mask"] > 0).view(torch.uint8), shp, torch.uint8)
+        if selective:
+            depth = _exchange_selected(d_loc, own_ids, need_by_rank, owner_of, group)
+            mask = _exchange_selected(m_loc, own_ids, need_by_rank, owner_of, group)
+            ids = need_by_rank[rank]
+        else:
+            rows = [sum(1 for k in group_ids if lo <= k < hi) for lo, hi in bounds]
+            depth = allgatherv_rows(d_loc, rows, group=group)
+            mask = allgatherv_rows(m_loc, rows, group=group)
+            ids = group_ids
+        got = [v for v in ids if owner_of(v) != rank]
+        received += len(got)
+        received_bytes += len(got) * int(np.prod(shp)) * 5
+        if ids and len(local_cloud):
+            floater_votes(local_cloud.points, local_cloud.normals, depth, K_all[ids], E_all[ids], mask=mask,
+                          depth_threshold=depth_threshold, votes=votes)
+    if stats is not None:
+        stats.update(views_total=num_views_total, views_received=received, bytes_received=received_bytes, selective=bool(selective))
     return votes
 
 

@@ -314,7 +314,11 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
         votes = _votes_single(cloud, cached, config.filtering.depth_threshold)
     else:
         from .distributed import floater_votes_sharded
-        votes = floater_votes_sharded(cloud, cached, num_views, config.filtering.depth_threshold)
+        fstats: dict = {}
+        votes = floater_votes_sharded(cloud, cached, num_views, config.filtering.depth_threshold, stats=fstats)
+        say(f"-> Sharded filter: rank 0 received {fstats['views_received']} of the other ranks' {num_views - (hi - lo)} views "
+            f"({fstats['bytes_received'] / 1e6:.1f} MB of depth maps and masks; only views its points can reach travel)")
+        report["filter_views_received"] = fstats["views_received"]
     plan = None
     sharded_write = ranks.world > 1 and config.processing.sharded_model_write
     if ranks.world == 1:

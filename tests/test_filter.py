@@ -362,3 +362,54 @@ def test_floater_votes_argument_errors():
     rc, msg = call(mode=2)
     assert rc == -1 and "removed" in msg
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks, views, layout", [(2, 12, "corridor"), (3, 13, "corridor"), (2, 9, "ring"), (3, 2, "corridor")])
+def test_sharded_filter_gathers_only_the_views_in_reach(ranks, views, layout):
+    """distributed.floater_votes_sharded with ranks sharing the GPU over gloo: votes equal the one-GPU votes with the selective
+    gather and with the all-gather; on a corridor a rank receives fewer views than there are (tests/filter_worker.py)."""
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, DD_FILTER_VIEWS=str(views), DD_FILTER_LAYOUT=layout, DD_PLACEMENT="first")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(root / "tests" / "filter_worker.py")], capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count(": ok,") == ranks, r.stdout
+
+
+@pytest.mark.gpu
+def test_views_in_reach_is_conservative():
+    """Every view that casts a vote on some point must be in reach of the points' bounding spheres (the converse need not hold)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import depthdensifier_amd as dd
+    from depthdensifier_amd import distributed as D
+    d = _scene(31, 10, 48, 64)
+    E = d["cam_from_world"]
+    for v in range(10):                            # half the cameras turned away from the scene
+        if v % 2:
+            E[v, :, :3] = E[v, :, :3] * np.array([[-1.0], [1.0], [-1.0]])
+            E[v, :, 3] = E[v, :, 3] * np.array([-1.0, 1.0, -1.0])
+    depth = np.where(np.isfinite(d["depth"]) & (d["depth"] > 0), 3.0 + 0.1 * np.sin(d["depth"]), 0).astype(np.float32)   # a surface ~3 m away
+    K = dd.intrinsics_matrix(d["params"])
+    cloud = dd.unproject_views(depth[:3], d["params"][:3], E[:3], mask=d["mask"][:3], normal=d["normal"][:3])
+    fin = torch.isfinite(cloud.points).all(dim=1)          # (the special depths of the scene give a few non-finite points: those put every view in reach)
+    pts, nrm = cloud.points[fin].contiguous(), cloud.normals[fin].contiguous()
+    reach = D.views_in_reach(pts, K, E, [depth.shape[1:]] * 10, chunk=16).cpu().numpy()
+    for v in range(10):
+        votes = dd.floater_votes(pts, nrm, depth[v:v + 1], K[v:v + 1], E[v:v + 1], mask=d["mask"][v:v + 1])
+        if int(votes.sum()) > 0:
+            assert reach[v], v
+    assert not reach.all()                         # something was excluded, or the test says nothing
+    assert D.views_in_reach(torch.full((5, 3), float("nan"), device="cuda"), K, E, [depth.shape[1:]] * 10).all()

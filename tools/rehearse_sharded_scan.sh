@@ -19,7 +19,7 @@ for N in 2 3; do
   DD_DIST_BACKEND=gloo DD_ALLGATHERV=broadcast timeout -k 10 240 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N \
       --master-addr 127.0.0.1 --master-port $((29700 + N)) scripts/test.py $ARGS --paths.output-model-dir $T/out$N > $T/log$N.txt 2>&1 \
       || { tail -30 $T/log$N.txt; exit 1; }
-  grep "Sharding\|Filtering removed\|number of dense" $T/log$N.txt
+  grep "Sharding\|Filtering removed\|number of dense\|Sharded filter" $T/log$N.txt
   for f in cameras.bin images.bin points3D.bin; do cmp $T/out1/$f $T/out$N/$f; done
   echo "world $N: model identical to the single-GPU run (every rank wrote its own slice of points3D.bin)"
   # the same with the kept clouds gathered to rank 0 (xyz + rgba records over the wire), rank 0 writing alone
