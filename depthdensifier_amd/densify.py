@@ -143,7 +143,7 @@ class _PinnedRing:
     bytes.  Here the bytes are put into one of a few page-locked slots first and the copy is enqueued without waiting;
     a slot is reused only after the event recorded behind its copy has passed."""
 
-    def __init__(self, slots: int = 8, nbytes: int = 1 << 18):
+    def __init__(self, slots: int = 64, nbytes: int = 1 << 18):
         self.nbytes, self.slots = nbytes, slots
         self._bufs: list = []
         self._events: list = []

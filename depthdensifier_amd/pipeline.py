@@ -64,6 +64,10 @@ class ProcessingConfig:
     io_threads: int = field(default_factory=lambda: _default_io_threads())
     """Host threads that decode images / read cached maps ahead of the GPU (0 = inline, like the reference).  Default: the
     cores this process may use minus two, between 2 and 16 -- image decoding is what bounds a scan once the maps are cached."""
+    views_per_launch: int = 8
+    """Consecutive equally sized views densified by ONE kernel launch at full density (downsample_density = 1): their fits are
+    enqueued back to back and read in one go, their maps stacked on the device, one ViewBatch / dd_unproject_compact with a
+    transfer curve per view.  1 = a launch per view (rounds 1-2).  Same model either way."""
     shard_views: bool = True
     """Under torchrun (one process per GPU): shard this scan's views over the ranks.  The batch driver turns it
     off because it shards by scan."""
@@ -201,7 +205,8 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
     for im in mine:
         pw, ph = _processing_size(config.paths.image_dir / im.name, f)
         capacity += (-(-ph // s)) * (-(-pw // s))
-    builder = CloudBuilder(capacity, normals=True, colors=True, pixel_index=False, device=device)
+    # (views are appended one at a time here: launches of 26 us whose rows sit in one chunk anyway -- no placement scouting)
+    builder = CloudBuilder(capacity, normals=True, colors=True, pixel_index=False, device=device, placement="first")
     cached = []                                                                 # :128 cached_refinement_data
     stage = {"image_decode": 0.0, "depth_source": 0.0, "refine": 0.0, "densify": 0.0}     # host seconds per stage
     clock = time.perf_counter
@@ -239,6 +244,9 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
         new_h, new_w = rgb.shape[:2]
         t2 = clock()
         maps = source.infer(image.name, rgb, device, prepared=prepared)         # :161-168, stays on device
+        rgb_dev = torch.from_numpy(rgb).to(device, non_blocking=True)           # :215 the colours, uploaded with the maps
+        if slot is not None:
+            slot.release(torch.cuda.current_stream(device))                     # every upload from the slot is enqueued by now
         t3 = clock()
         camera = rec.cameras[image.camera_id]
         camera.rescale(new_width=new_w, new_height=new_h)                       # :172-173 (in place, like the reference)
@@ -255,42 +263,68 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
         t4 = clock()
         stage["image_decode"] += t2 - t1; stage["depth_source"] += t3 - t2; stage["refine"] += t4 - t3
         # (the camera may be rescaled again by the next view before this one is finished: its intrinsics are taken now)
-        return dict(rgb=rgb, slot=slot, maps=maps, normal=normal, E=E, K=K, pinhole=camera.pinhole_params().copy(), handle=handle)
+        return dict(rgb=rgb_dev, maps=maps, normal=normal, E=E, K=K, pinhole=camera.pinhole_params().copy(), handle=handle)
 
-    def finish(v: dict) -> None:
+    def densify_run(run: list) -> None:
+        """Consecutive views whose transfer curves the kernel applies itself, all of one size: ONE ViewBatch, one launch.
+        :194 "refined_depth[~moge_mask] = 0" is the kernels' validity rule (mask AND depth > 0); :203-240 densify + append.
+        Raw depth -> LUT + 3x3 median -> validity -> unprojection in one kernel; the refined maps it writes on the way are the
+        filter's cache (:197-201).  Same bits as dd_refine_apply followed by the plain densify call, view by view."""
+        st = (lambda key: torch.stack([v[key] for v in run])) if len(run) > 1 else (lambda key: run[0][key][None])
+        masks = st("mask")
+        batch = ViewBatch(st("raw"), np.stack([v["pinhole"] for v in run]), np.stack([v["E"] for v in run]), mask=masks, normal=st("normal"),
+                          rgb=st("rgb"), stride=s, view_index_base=lo + len(cached), device=device,
+                          refine=[v["curve"] for v in run], refined_out=True)
+        builder.append(batch)
+        for i, v in enumerate(run):
+            cached.append(dict(depth=batch.refined[i], mask=masks[i], K=v["K"], E=v["E"]))         # :197-201
+
+    def finish(group: list) -> None:
+        """The fits' results (the first read waits for the group's GPU work, the others are there), then the densify launches:
+        runs of consecutive views with a curve and one size go together, anything else (early exits of the refiner, a coarser
+        density, very wide images) view by view.  View order is preserved."""
         t3 = clock()
-        res = refiner.finish_refine(v["handle"])                                # the fit's result: its one synchronisation
-        refined = res["refined_depth"]
-        maps, normal, E, K = v["maps"], v["normal"], v["E"], v["K"]
+        results = [refiner.finish_refine(v["handle"]) for v in group]
         t4 = clock()
-        # :194 "refined_depth[~moge_mask] = 0" is the kernels' validity rule (mask AND depth > 0);
-        # :203-240 densify + append
-        if refined is None:
-            # raw depth -> LUT + 3x3 median -> validity -> unprojection in ONE kernel; the refined map it writes on the way
-            # is the filter's cache (:197-201).  Same bits as dd_refine_apply followed by the plain densify call.
-            batch = ViewBatch(res["raw_depth"], v["pinhole"][None], E[None], mask=maps["mask"], normal=normal, rgb=v["rgb"],
-                              stride=s, view_index_base=lo + len(cached), device=device, refine=res["curve"], refined_out=True)
-            refined = batch.refined[0]
-        else:
+        run: list = []
+        for v, res in zip(group, results):
+            maps = v["maps"]
+            if res["refined_depth"] is None:
+                item = dict(raw=res["raw_depth"], curve=res["curve"], mask=maps["mask"], normal=v["normal"], rgb=v["rgb"], pinhole=v["pinhole"],
+                            E=v["E"], K=v["K"])
+                if run and (tuple(run[0]["raw"].shape) != tuple(item["raw"].shape) or run[0]["raw"].dtype != item["raw"].dtype or len(run) >= max(1, K_LAUNCH)):
+                    densify_run(run); run = []
+                run.append(item)
+                continue
+            if run:
+                densify_run(run); run = []
+            refined = res["refined_depth"]
             refined = refined if isinstance(refined, torch.Tensor) else torch.as_tensor(refined, device=device)
             refined = refined.float()
-            batch = ViewBatch(refined, v["pinhole"][None], E[None], mask=maps["mask"], normal=normal, rgb=v["rgb"],
+            batch = ViewBatch(refined, v["pinhole"][None], v["E"][None], mask=maps["mask"], normal=v["normal"], rgb=v["rgb"],
                               stride=s, view_index_base=lo + len(cached), device=device)
-        builder.append(batch)
-        if v["slot"] is not None:
-            v["slot"].release(torch.cuda.current_stream(device))                # every upload from the slot is enqueued by now
-        cached.append(dict(depth=refined, mask=maps["mask"], K=K, E=E))         # :197-201
+            builder.append(batch)
+            cached.append(dict(depth=refined, mask=maps["mask"], K=v["K"], E=v["E"]))         # :197-201
+        if run:
+            densify_run(run)
         t5 = clock()
         stage["refine"] += t4 - t3; stage["densify"] += t5 - t4
 
-    # One view of lag between the two halves: while the GPU runs view k's uploads and fit, the host starts view k + 1; by
-    # the time it asks for view k's fit the answer is there.  (With refiner messages on, no lag: the log keeps its order.)
+    # Groups of `views_per_launch` views, one group of lag: while the GPU runs group g's uploads and fits, the host starts
+    # group g + 1; by the time it asks for group g's fits the answers are there.  (With refiner messages on: view by view, no
+    # lag, so that the log keeps its order.)
+    K_LAUNCH = 1 if verbose else max(1, int(config.processing.views_per_launch))
     lag = 0 if verbose else 1
     inflight: deque = deque()
+    group: list = []
     for k, image in enumerate(mine):
-        inflight.append(begin(k, image))
-        if len(inflight) > lag:
-            finish(inflight.popleft())
+        group.append(begin(k, image))
+        if len(group) >= K_LAUNCH:
+            inflight.append(group); group = []
+            if len(inflight) > lag:
+                finish(inflight.popleft())
+    if group:
+        inflight.append(group)
     while inflight:
         finish(inflight.popleft())
     if pool:

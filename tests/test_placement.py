@@ -119,7 +119,7 @@ def test_placed_cloud_equals_unplaced_cloud(gpu):
 @pytest.mark.gpu
 def test_small_clouds_are_left_alone(gpu):
     import depthdensifier_amd as dd
-    b = dd.CloudBuilder(1000, normals=True, colors=True, device=gpu)
+    b = dd.CloudBuilder(40 << 20, normals=True, colors=True, device=gpu)          # 40 Mi rows: below the default threshold
     assert b.placement is not None and b.placement.mode.startswith("skipped"), b.placement.as_dict()
     b2 = dd.CloudBuilder(1000, normals=False, colors=False, device=gpu)
     assert b2.placement is None

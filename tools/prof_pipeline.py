@@ -13,6 +13,9 @@ with tempfile.TemporaryDirectory() as tmp:
     cfg = P.ScriptConfig()
     cfg.paths = P.PathsConfig(recon_path=scan / "sparse" / "0", image_dir=scan / "images", output_model_dir=Path(tmp) / "out")
     cfg.moge.cache_dir = npy
+    import os
+    cfg.processing.downsample_density = int(os.environ.get('DD_PROF_STRIDE', '32'))
+    cfg.refiner.verbose = 0
     with contextlib.redirect_stdout(io.StringIO()):
         P.main(cfg)
     pr = cProfile.Profile()
