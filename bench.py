@@ -701,8 +701,11 @@ def main() -> None:
     if not multi and single_pass and args.alloc_rounds > 0 and V > 0:
         keep = []
         from depthdensifier_amd import placement as _pl
+        cloud_bytes = batch.max_points * (12 + (12 if cfg["normal"] else 0) + (3 if cfg["rgb"] else 0) + (4 if args.pixel_index else 0))
         for r in range(args.alloc_rounds):
             _pl.trim(device)              # no spare chunks from the last round: every round scouts the device's memory anew
+            if torch.cuda.mem_get_info(device)[0] < 1.15 * cloud_bytes + (4 << 30):
+                break                     # no room for a second cloud beside the timed one (2000 views on one GPU)
             b2 = dd.CloudBuilder(batch.max_points, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index, device=device,
                                  placement=args.placement)
             for _ in range(2):

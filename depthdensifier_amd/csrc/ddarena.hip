@@ -291,6 +291,57 @@ int best_assignment(const DDArena *A, const int need[MAX_CLASSES], const int fix
     return best;
 }
 
+// Which class every chunk of every array of a request is taken from, given the free chunks at hand.  Class-pure arrays take
+// the class of their group (`perm`).  Rotated arrays are laid out index by index: at chunk index k the arrays, in phase
+// order, each take the class with the most free chunks left that no other rotated array of the request uses at k (ties go to
+// (phase + k) mod 3, so balanced supplies give the exact rotation, and two plentiful classes give two class-pure arrays in
+// different classes).  `missing`: chunks nobody can supply yet; `conflicts`: chunk indices where one of the first TWO rotated
+// arrays (the lock-step store streams) had to share a class -- the third (colours) sharing one is harmless.
+void plan_classes(const DDArena *A, int n, const std::vector<int> &nch, const int32_t *layouts, const int perm[MAX_CLASSES],
+                  std::vector<std::vector<int>> &choice, int *missing, int *conflicts) {
+    int avail[MAX_CLASSES];
+    for (int c = 0; c < MAX_CLASSES; ++c) avail[c] = free_count(A, c);
+    choice.assign(n, std::vector<int>());
+    *missing = 0; *conflicts = 0;
+    auto any_class = [&]() { int b = -1; for (int c = 0; c < MAX_CLASSES; ++c) if (avail[c] > 0 && (b < 0 || avail[c] > avail[b])) b = c; return b; };
+    for (int i = 0; i < n; ++i) {
+        if (layouts[i] >= MAX_CLASSES) continue;
+        for (int k = 0; k < nch[i]; ++k) {
+            int c = perm[layouts[i]];
+            if (avail[c] <= 0) { c = any_class(); if (c >= 0) *conflicts += 1; }
+            if (c < 0) { *missing += 1; choice[i].push_back(-1); continue; }
+            avail[c] -= 1;
+            choice[i].push_back(c);
+        }
+    }
+    std::vector<int> rot;
+    for (int ph = 0; ph < MAX_CLASSES; ++ph) for (int i = 0; i < n; ++i) if (layouts[i] == DD_ARENA_ROTATED + ph) rot.push_back(i);
+    int kmax = 0;
+    for (int i : rot) kmax = std::max(kmax, nch[i]);
+    for (int k = 0; k < kmax; ++k) {
+        bool used[MAX_CLASSES] = {false, false, false};
+        int order = 0;
+        for (int i : rot) {
+            const int my = order++;
+            if (k >= nch[i]) continue;
+            const int pref = (layouts[i] - DD_ARENA_ROTATED + k) % MAX_CLASSES;
+            int c = -1;
+            for (int d = 0; d < MAX_CLASSES; ++d) {
+                const int cand = (pref + d) % MAX_CLASSES;
+                if (avail[cand] > 0 && !used[cand] && (c < 0 || avail[cand] > avail[c])) c = cand;
+            }
+            if (c < 0) {                     // every class that still has chunks is taken at this index
+                c = any_class();
+                if (c >= 0 && my < 2) *conflicts += 1;
+            }
+            if (c < 0) { *missing += 1; choice[i].push_back(-1); continue; }
+            avail[c] -= 1;
+            used[c] = true;
+            choice[i].push_back(c);
+        }
+    }
+}
+
 int take_chunk(DDArena *A, int cls) {      // a free chunk of the class; -1 = none
     for (size_t i = 0; i < A->chunks.size(); ++i) {
         Chunk &c = A->chunks[i];
@@ -377,15 +428,17 @@ int dd_arena_alloc(DDArena *A, int32_t n, const int64_t *sizes, const int32_t *g
     AHIP(hipDeviceSynchronize(), "hipDeviceSynchronize");          // probes are timed: nothing else should be running
     const int total_need = need[0] + need[1] + need[2] + fixed[0] + fixed[1] + fixed[2];
     int perm[MAX_CLASSES] = {0, 1, 2};
-    int64_t scouted = 0;
     bool oom = false;
     int rc = DD_OK;
-    // scout until every group can be served from a class of its own, or the budget / the memory is spent
+    std::vector<std::vector<int>> choice;
+    int missing = 0, conflicts = 0;
+    // scout until every array can be laid out without two lock-step arrays sharing a class, or the budget / the memory is spent
     for (;;) {
-        if (best_assignment(A, need, fixed, perm) >= total_need) break;
-        if (oom) break;
+        best_assignment(A, need, fixed, perm);
+        plan_classes(A, n, nch, groups, perm, choice, &missing, &conflicts);
+        if ((missing == 0 && conflicts == 0) || oom) break;
         int live_free = 0;
-        for (const Chunk &c : A->chunks) if (c.live && !c.used && !c.anchor) ++live_free;
+        for (const Chunk &c : A->chunks) if (c.live && !c.used && !c.anchor && c.cls >= 0) ++live_free;
         // the budget counts chunks beyond what the request itself needs
         if ((int64_t)(live_free - total_need + SCOUT_BATCH) * (int64_t)A->chunk > max_scout_bytes && live_free >= total_need) break;
         for (int b = 0; b < SCOUT_BATCH; ++b) {
@@ -393,22 +446,15 @@ int dd_arena_alloc(DDArena *A, int32_t n, const int64_t *sizes, const int32_t *g
             rc = scout_one(A, &ci);
             if (rc == DD_ERR_WORKSPACE) { oom = true; rc = DD_OK; break; }
             if (rc != DD_OK) return rc;
-            scouted += (int64_t)A->chunk;
         }
     }
-    best_assignment(A, need, fixed, perm);
     for (int g = 0; g < MAX_CLASSES; ++g) if (need[g] > 0) A->group_class[g] = perm[g];
-    // choose the chunks: own class first, then whatever is left (degraded)
+    // take the chunks the plan names
     std::vector<std::vector<int>> chosen(n);
-    bool degraded = false;
+    const bool degraded = conflicts > 0;
     for (int i = 0; i < n && rc == DD_OK; ++i) {
         for (int k = 0; k < nch[i]; ++k) {
-            const int L = groups[i];
-            int ci = take_chunk(A, L < MAX_CLASSES ? perm[L] : (L - DD_ARENA_ROTATED + k) % MAX_CLASSES);
-            if (ci < 0) {
-                degraded = true;
-                for (int c2 = 0; c2 < MAX_CLASSES && ci < 0; ++c2) ci = take_chunk(A, c2);
-            }
+            const int ci = choice[i][k] >= 0 ? take_chunk(A, choice[i][k]) : -1;
             if (ci < 0) { rc = afail(DD_ERR_WORKSPACE, "arena: out of device memory"); break; }
             A->chunks[ci].used = true;
             chosen[i].push_back(ci);

@@ -305,9 +305,11 @@ typedef struct DDArena DDArena;
 
 /* layout of one array of dd_arena_alloc (the `groups` argument): 0, 1, 2 = class-pure, in the class of that GROUP (arrays
  * of one group share a class, different groups get different classes; a group keeps its class over later calls);
- * DD_ARENA_ROTATED + phase (phase 0..2) = chunk k of the array comes from class (phase + k) mod 3: a single store stream
- * then alternates between the classes (5.7 -> 6.1 / 6.7 TB/s with 1 GiB / 512 MiB chunks), and two arrays of different
- * phase written in lock step never share a class (7.1 TB/s, like two pure arrays of different groups) */
+ * DD_ARENA_ROTATED + phase (phase 0..2) = the rotated arrays of ONE request never share a class at equal chunk index (two
+ * arrays written in lock step then run at 7.1 TB/s, like two pure arrays of different groups); chunk k of an array prefers
+ * class (phase + k) mod 3, and takes the class with the most free chunks otherwise -- so an even supply gives the exact
+ * rotation and two plentiful classes give two class-pure arrays.  Phases 0 and 1 are the ones that must differ (the
+ * lock-step store streams); phase 2 (the colours) may share a class when only two are at hand */
 #define DD_ARENA_ROTATED 8
 
 typedef struct DDArenaStats {

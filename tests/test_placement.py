@@ -75,7 +75,7 @@ def test_arena_gives_every_group_its_own_class(gpu):
     big = 3 * (st["chunk_bytes"] // 12) + 1000                                # a little more than three chunks of float32 rows
     t3, deg3 = arena.alloc({"p": ((big, 3), torch.float32, pl.rotated(0)), "q": ((big, 3), torch.float32, pl.rotated(1))})
     cp, cq = arena.classes_of(t3["p"]), arena.classes_of(t3["q"])
-    assert not deg3 and len(cp) == 4 and cp == [k % 3 for k in range(4)] and cq == [(1 + k) % 3 for k in range(4)], (cp, cq)
+    assert not deg3 and len(cp) == len(cq) == 4 and all(a != b for a, b in zip(cp, cq)), (cp, cq)      # (the exact rotation when the supply is even)
     t3["p"][-1].fill_(2.0)                                                     # the last row lies in the fourth chunk
     assert float(t3["p"][-1].sum()) == 6.0
     held = sum(arena.stats()["chunks_held"])
