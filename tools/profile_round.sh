@@ -19,10 +19,10 @@ for tag in $TAGS; do
   D="$OUT/$tag"; mkdir -p "$D"
   python3 "$R/bench.py" $ARGS --cpu-seconds 0 --strong-views 0 > "$D/bench.json" 2> "$D/bench.err" || { echo "$tag: bench failed"; exit 1; }
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/stats" -- \
-      python3 "$R/bench.py" $ARGS --cpu-seconds 0 --strong-views 0 > "$D/bench_under_rocprof.json" 2> "$D/stats.err" || { echo "$tag: stats failed"; exit 1; }
+      python3 "$R/bench.py" $ARGS --cpu-seconds 0 --strong-views 0 --no-verify --alloc-rounds 0 > "$D/bench_under_rocprof.json" 2> "$D/stats.err" || { echo "$tag: stats failed"; exit 1; }
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 300 rocprofv3 --pmc $c --kernel-include-regex "compact_lean|count_lean" --kernel-trace --output-format csv -d "$D/pmc/$c" -- \
-        python3 "$R/bench.py" $ARGS --steps 3 --warmup 1 --cpu-seconds 0 --strong-views 0 > "$D/pmc_$c.json" 2> "$D/pmc_$c.err" || { echo "$tag: pmc $c failed"; exit 1; }
+        python3 "$R/bench.py" $ARGS --steps 3 --warmup 1 --cpu-seconds 0 --strong-views 0 --no-verify --alloc-rounds 0 > "$D/pmc_$c.json" 2> "$D/pmc_$c.err" || { echo "$tag: pmc $c failed"; exit 1; }
   done
   echo "$tag done"
 done
