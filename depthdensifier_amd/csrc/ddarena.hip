@@ -465,29 +465,52 @@ int dd_arena_alloc(DDArena *A, int32_t n, const int64_t *sizes, const int32_t *g
         for (size_t ci = 0; ci < A->chunks.size(); ++ci) if (A->chunks[ci].live && !A->chunks[ci].used && !A->chunks[ci].anchor) (void)release_chunk(A, (int)ci);
         return rc;
     }
-    // build the arrays: chunks leave the scouting range and are mapped back to back into a fresh range
+    // build the arrays: chunks leave the scouting range and are mapped back to back into a fresh range.  On any failure
+    // everything this request has built is undone ("nothing stays allocated").
     hipMemAccessDesc acc;
     memset(&acc, 0, sizeof(acc));
     acc.location = A->prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
-    for (int i = 0; i < n; ++i) {
+    std::vector<Mapping> built;
+    for (int i = 0; i < n && rc == DD_OK; ++i) {
         Mapping m;
         m.bytes = (size_t)nch[i] * A->chunk;
         m.va = nullptr;
-        AHIP(hipMemAddressReserve(reinterpret_cast<void **>(&m.va), m.bytes, 0, nullptr, 0), "hipMemAddressReserve(array)");
-        for (int k = 0; k < nch[i]; ++k) {
+        hipError_t e = hipMemAddressReserve(reinterpret_cast<void **>(&m.va), m.bytes, 0, nullptr, 0);
+        if (e != hipSuccess) { rc = afail_hip("hipMemAddressReserve(array)", e); break; }
+        int mapped = 0;
+        for (int k = 0; k < nch[i] && rc == DD_OK; ++k) {
             Chunk &c = A->chunks[chosen[i][k]];
             if (c.slot >= 0) {              // fresh from scouting (a pooled chunk is not mapped anywhere)
-                AHIP(hipMemUnmap(slot_ptr(A, c.slot), A->chunk), "hipMemUnmap(scout)");
+                if ((e = hipMemUnmap(slot_ptr(A, c.slot), A->chunk)) != hipSuccess) { rc = afail_hip("hipMemUnmap(scout)", e); break; }
                 A->slot_owner[c.slot] = -1;
                 c.slot = -1;
             }
-            AHIP(hipMemMap(m.va + (size_t)k * A->chunk, A->chunk, 0, c.h, 0), "hipMemMap(array)");
+            if ((e = hipMemMap(m.va + (size_t)k * A->chunk, A->chunk, 0, c.h, 0)) != hipSuccess) { rc = afail_hip("hipMemMap(array)", e); break; }
+            ++mapped;
         }
-        AHIP(hipMemSetAccess(m.va, m.bytes, &acc, 1), "hipMemSetAccess(array)");
+        if (rc == DD_OK && (e = hipMemSetAccess(m.va, m.bytes, &acc, 1)) != hipSuccess) rc = afail_hip("hipMemSetAccess(array)", e);
+        if (rc != DD_OK) {
+            if (mapped > 0) (void)hipMemUnmap(m.va, (size_t)mapped * A->chunk);
+            (void)hipMemAddressFree(m.va, m.bytes);
+            break;
+        }
         m.chunks = chosen[i];
-        A->maps.push_back(m);
-        ptrs_out[i] = m.va;
+        built.push_back(m);
+    }
+    if (rc != DD_OK) {
+        char msg[sizeof(g_aerr)];
+        snprintf(msg, sizeof(msg), "%s", g_aerr);
+        for (Mapping &m : built) { (void)hipMemUnmap(m.va, m.bytes); (void)hipMemAddressFree(m.va, m.bytes); }
+        for (auto &v : chosen) for (int ci : v) A->chunks[ci].used = false;
+        for (size_t ci = 0; ci < A->chunks.size(); ++ci) if (A->chunks[ci].live && !A->chunks[ci].used && !A->chunks[ci].anchor) (void)release_chunk(A, (int)ci);
+        (void)hipGetLastError();
+        snprintf(g_aerr, sizeof(g_aerr), "%s", msg);
+        return rc;
+    }
+    for (int i = 0; i < n; ++i) {
+        A->maps.push_back(built[i]);
+        ptrs_out[i] = built[i].va;
     }
     // what was scouted and not needed goes back to the driver, but for a few spares per class (the anchors stay)
     for (size_t ci = 0; ci < A->chunks.size(); ++ci)
