@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Condensed view of one bench.py line: tools/show_bench.py <file.json>"""
-import json, sys
+import json, signal, sys
+signal.signal(signal.SIGPIPE, signal.SIG_DFL)      # piped into head
 d = json.load(open(sys.argv[1]))
 r = d["roofline"]
 print(f"{d['config']['workload']} N={d['n_gpus']}: {d['value']} {d['unit']}  {d['ms_per_step']} ms/step  frac {r['frac']} (kernel {r['kernel_ms']} ms)  device {d.get('device')}")
