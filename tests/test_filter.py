@@ -401,7 +401,8 @@ def test_views_in_reach_is_conservative():
         if v % 2:
             E[v, :, :3] = E[v, :, :3] * np.array([[-1.0], [1.0], [-1.0]])
             E[v, :, 3] = E[v, :, 3] * np.array([-1.0, 1.0, -1.0])
-    depth = np.where(np.isfinite(d["depth"]) & (d["depth"] > 0), 3.0 + 0.1 * np.sin(d["depth"]), 0).astype(np.float32)   # a surface ~3 m away
+    ok = np.isfinite(d["depth"]) & (d["depth"] > 0)
+    depth = np.where(ok, 3.0 + 0.1 * np.sin(np.where(ok, d["depth"], 0.0)), 0).astype(np.float32)      # a surface ~3 m away
     K = dd.intrinsics_matrix(d["params"])
     cloud = dd.unproject_views(depth[:3], d["params"][:3], E[:3], mask=d["mask"][:3], normal=d["normal"][:3])
     fin = torch.isfinite(cloud.points).all(dim=1)          # (the special depths of the scene give a few non-finite points: those put every view in reach)
