@@ -154,20 +154,24 @@ class _PinnedRing:
         if arr.nbytes == 0 or arr.nbytes > self.nbytes:
             return torch.from_numpy(arr).to(device)
         if not self._bufs:
-            self._bufs = [torch.empty(self.nbytes, dtype=torch.uint8, pin_memory=True) for _ in range(self.slots)]
+            # one page-locked block for all slots (a pinned allocation costs ~0.3 ms whatever its size)
+            block = torch.empty(self.slots * self.nbytes, dtype=torch.uint8, pin_memory=True)
+            self._bufs = [block[i * self.nbytes:(i + 1) * self.nbytes] for i in range(self.slots)]
+            self._views = [b.numpy() for b in self._bufs]
             self._events = [None] * self.slots
         k = self._next % self.slots
         self._next += 1
         if self._events[k] is not None:
             self._events[k].synchronize()
-        host = self._bufs[k][:arr.nbytes]
-        host.numpy()[:] = arr.view(np.uint8).reshape(-1)
-        dev = host.to(device, non_blocking=True)
+        self._views[k][:arr.nbytes] = arr.view(np.uint8).reshape(-1)
+        dev = self._bufs[k][:arr.nbytes].to(device, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(device))
         self._events[k] = ev
-        return dev.view(torch.from_numpy(np.empty(0, dtype=arr.dtype)).dtype).view(arr.shape)
+        return dev.view(_TORCH_DTYPE[arr.dtype.name]).view(arr.shape)
 
+
+_TORCH_DTYPE = {n: getattr(torch, n) for n in ("float32", "float64", "float16", "int32", "int64", "int16", "int8", "uint8", "bool")}
 
 _small = _PinnedRing()
 

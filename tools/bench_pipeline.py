@@ -20,7 +20,9 @@ with tempfile.TemporaryDirectory() as tmp:
         with np.load(f) as z:
             for k in z.files:
                 np.save(npy_cache / f"{f.stem}_{k}.npy", z[k])
-    for stride, nio in ((32, 0), (32, 4), (32, 8), (4, 8), (1, 8)):
+    import os
+    ncores = len(os.sched_getaffinity(0))
+    for stride, nio in ((32, 0), (32, 4), (32, 8), (4, 8), (1, 8), (1, max(2, min(16, ncores - 2)))):
       for cache in ("moge_cache", "moge_cache_npy"):
         cfg = P.ScriptConfig()
         cfg.paths = P.PathsConfig(recon_path=scan / "sparse" / "0", image_dir=scan / "images", output_model_dir=Path(tmp) / f"out_s{stride}")
@@ -34,4 +36,5 @@ with tempfile.TemporaryDirectory() as tmp:
             rep = P.main(cfg)
         torch.cuda.synchronize()
         t = {k: round(v, 3) for k, v in rep["timings"].items()}
-        print(json.dumps({"stride": stride, "io_threads": nio, "cache": "npy" if cache.endswith("npy") else "npz", "views": rep["views"], "dense_points": rep["dense_points"], "removed": rep["removed"], "seconds": t}), flush=True)
+        loop = sum(t[k] for k in ("image_decode", "depth_source", "refine", "densify"))
+        print(json.dumps({"stride": stride, "io_threads": nio, "loop_ms_per_view": round(loop / rep["views"] * 1e3, 2), "cache": "npy" if cache.endswith("npy") else "npz", "views": rep["views"], "dense_points": rep["dense_points"], "removed": rep["removed"], "seconds": t}), flush=True)
