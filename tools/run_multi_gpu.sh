@@ -15,12 +15,22 @@ cd "$R"
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 NGPU=$(python3 -c "import torch; print(torch.cuda.device_count())")
 echo "GPUs visible: $NGPU"
+# REHEARSE=1: the script's own plumbing on a ONE-GPU box -- two ranks share the GPU over gloo, tiny workloads, no RCCL tests,
+# no profiler; the numbers mean nothing, the point is that every step runs and every line parses
+REHEARSE=${REHEARSE:-0}
+SMALL=""
+if [ "$REHEARSE" = 1 ]; then
+  NGPU=2; export DD_BENCH_SHARE_GPU=1 DD_ALLGATHERV=broadcast
+  SMALL="--views 8 --strong-views 8 --strong-steps 1 --steps 2 --warmup 1"
+fi
 if [ "$NGPU" -lt 2 ]; then echo "needs at least 2 GPUs"; exit 2; fi
 SUM="$OUT/r03_scale_summary.txt"
 : > "$SUM"
 
 echo "== 1. RCCL tests" | tee -a "$SUM"
+if [ "$REHEARSE" = 1 ]; then echo "(rehearsal: skipped)" | tee -a "$SUM"; else
 timeout -k 10 600 python3 -m pytest tests/test_fuse_gpu.py -q -m gpu -k "two_ranks_over_rccl or c_abi_allgatherv_over_rccl" 2>&1 | tail -5 | tee -a "$SUM"
+fi
 
 line() {   # line <tag> <N> <env assignments...> -- <bench args...>
   local tag=$1 n=$2; shift 2
@@ -48,17 +58,19 @@ PY
 }
 
 echo "== 2. bench lines" | tee -a "$SUM"
-line n1 1 -- --workload scene2000 --cpu-seconds 0 --alloc-rounds 0
+line n1 1 -- --workload scene2000 --cpu-seconds 0 --alloc-rounds 0 $SMALL
 N1=$(python3 -c "import json; print(json.load(open('$OUT/r03_scale_n1.json'))['value'])" 2>/dev/null || echo 0)
 NS=""; for n in 2 4 8; do [ "$n" -le "$NGPU" ] && NS="$NS $n"; done
 for n in $NS; do
-  line "n${n}_default" "$n" -- --n1-strong-mpix "$N1"
+  line "n${n}_default" "$n" -- --n1-strong-mpix "$N1" $SMALL
   for chunks in 1 5 10; do for ag in p2p broadcast; do for dst in all 0; do
     [ "$ag" = broadcast ] && [ "$dst" = 0 ] && continue        # the broadcast flavour replicates by construction
-    line "n${n}_c${chunks}_${ag}_dst${dst}" "$n" "DD_ALLGATHERV=$ag" -- --steps 5 --warmup 2 --chunks "$chunks" --gather-dst "$dst" --n1-strong-mpix "$N1" --alloc-rounds 0
+    [ "$REHEARSE" = 1 ] && [ "$ag" = p2p ] && continue         # gloo has no device send / recv
+    line "n${n}_c${chunks}_${ag}_dst${dst}" "$n" "DD_ALLGATHERV=$ag" -- --steps 5 --warmup 2 --chunks "$chunks" --gather-dst "$dst" --n1-strong-mpix "$N1" --alloc-rounds 0 $SMALL
   done; done; done
 done
 
+if [ "$REHEARSE" = 1 ]; then echo "== 3. (rehearsal: no profiler run)" | tee -a "$SUM"; echo "done; summary in $SUM"; exit 0; fi
 echo "== 3. rank-0 trace at N = $(echo $NS | awk '{print $NF}')" | tee -a "$SUM"
 NMAX=$(echo $NS | awk '{print $NF}')
 export TMPDIR=/tmp
