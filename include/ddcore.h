@@ -293,13 +293,13 @@ const char *dd_model_last_error(void);
 
 /* ---------------------------------------------------------------------------------------------
  * HBM zone arena (ABI 9): where the large arrays of the fused cloud (scripts/test.py:264-266 final_point_cloud /
- * final_normals / final_colors) and of the per-view maps (:166-168) live in the 288 GB of an MI355X.  The physical memory
- * falls into three classes of about a third each; the densify kernel's two lock-step row streams (points + normals) cost
- * 4-11 % of the kernel's time when they share a class (profiles/r03_placement_*.txt).  The arena takes
- * physical chunks through the virtual-memory API, classifies each with a two-stream store probe against one anchor chunk
- * per class, and builds every requested array from chunks of ONE class, arrays of different groups from different
- * classes.  Host-side memory management: it changes addresses, never results.  Not for buffers handed to RCCL
- * (dd_allgatherv): memory from the virtual-memory API is not IPC-exportable -- allocate those normally.
+ * final_normals / final_colors) live in the 288 GB of an MI355X.  The physical memory falls into three classes of about a
+ * third each; two row-store streams written in lock step (points + normals) run at 5.8 TB/s inside one class and at
+ * 7.1 TB/s in two, which is 4-11 % of the densify kernel's time -- and a fresh process gets all its memory from one class
+ * (profiles/r03_placement_*.txt, r03_zone_*.txt).  The arena takes physical chunks (1 GiB) through the
+ * virtual-memory API, classifies each with a two-stream store probe against one anchor chunk per class, and maps every
+ * requested array from chunks of the classes its layout names.  Host-side memory management: it changes addresses, never
+ * results.  Not for buffers handed to RCCL (dd_allgatherv): memory from the virtual-memory API is not IPC-exportable.
  * ------------------------------------------------------------------------------------------- */
 typedef struct DDArena DDArena;
 
@@ -316,7 +316,7 @@ typedef struct DDArenaStats {
     int64_t chunk_bytes;
     int64_t probe_bytes;        /* bytes each of the two probe streams writes */
     int32_t num_classes;        /* classes discovered so far (<= 3) */
-    int32_t degraded_allocs;    /* allocations that could not be given a class of their own per group */
+    int32_t degraded_allocs;    /* allocations in which two lock-step arrays had to share a class somewhere */
     int64_t chunks_created;
     int64_t chunks_released;
     int64_t probes;
@@ -329,11 +329,11 @@ typedef struct DDArenaStats {
 
 /* An empty arena on `device`; chunk_bytes = 0 means 1 GiB (multiple of 2 MiB, >= 64 MiB). */
 int dd_arena_create(int32_t device, int64_t chunk_bytes, DDArena **arena_out);
-/* n arrays at once: sizes[i] bytes (rounded up to whole chunks), groups[i] in {0,1,2} -- arrays of one group share a class,
- * different groups get different classes.  Scouts (creates + classifies) physical chunks until that is possible, holding at
- * most max_scout_bytes beyond the request; chunks not needed go back to the driver before the call returns.  Synchronises
- * the device (the probes are timed).  Returns DD_OK, 1 = allocated but some group had to share a class (budget or memory
- * too small), or a negative error (DD_ERR_WORKSPACE = out of device memory). */
+/* n arrays at once: sizes[i] bytes (rounded up to whole chunks), groups[i] = the layout code of array i (above).  Scouts
+ * (creates + classifies) physical chunks until the layouts can be honoured, holding at most max_scout_bytes beyond the
+ * request; chunks not needed go back to the driver (or the pool) before the call returns.  Synchronises the device (the
+ * probes are timed).  Returns DD_OK, 1 = allocated but two lock-step arrays share a class somewhere (budget or memory too
+ * small), or a negative error (DD_ERR_WORKSPACE = out of device memory; nothing of the request stays allocated). */
 int dd_arena_alloc(DDArena *arena, int32_t n, const int64_t *sizes, const int32_t *groups, int64_t max_scout_bytes, void **ptrs_out);
 /* Unmaps one array of dd_arena_alloc; synchronises the device first.  Its chunks go back to the driver, except that up to
  * 4 chunks per class (dd_arena_trim changes that) are kept as classified spares so that the next allocation need not
