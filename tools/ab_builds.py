@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--views", type=int, default=96)
     ap.add_argument("--rounds", type=int, default=9)
     ap.add_argument("--mask-kind", default="blob")
+    ap.add_argument("--tuning", type=int, default=0, help="DDViewBatch.tuning for every variant (4 = two-pass)")
     ap.add_argument("variants", nargs="+", help="tag:flag,flag,...  (empty flag list = the committed defaults)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -48,7 +49,7 @@ def main():
     H, W = cfg["H"], cfg["W"]
     params = np.tile([0.8 * W, 0.8 * W, W / 2.0, H / 2.0], (a.views, 1))
     batch = dd.ViewBatch(scene["depth"], params, bench.ring_poses(ids, a.views), mask=scene["mask"], normal=scene["normal"], rgb=scene["rgb"],
-                         conf=scene["conf"], conf_threshold=cfg.get("conf"), device=dev)
+                         conf=scene["conf"], conf_threshold=cfg.get("conf"), device=dev, tuning=a.tuning)
     builder = dd.CloudBuilder(batch.max_points, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=False, device=dev)
     cb, out = batch.c_struct(), builder._out_struct()
     ws = torch.zeros(4 * batch.workspace_bytes() + 4096, dtype=torch.uint8, device=dev)      # variants with smaller tiles need more
