@@ -443,9 +443,15 @@ class CloudBuilder:
         (``DDCloudOut.xyz_rgba``).  ``buffers``: caller-owned tensors to write into instead of allocating, keyed like
         ``FIELDS`` -- the multi-GPU fuse hands in the GLOBAL cloud so that every point is written once, at its final
         row.  ``start``: first row (int or (1,) int64 device tensor), e.g. ``rank_offsets[rank]``.  ``placement``:
-        ``"probed"`` (default, or ``DD_PLACEMENT``) puts the points and the normals of a large cloud this builder allocates
-        into different classes of HBM address ranges (``placement.place_outputs``; ``self.placement`` reports what was done),
-        ``"first"`` takes the arrays as the allocator returns them."""
+        ``None`` (default) = ``DD_PLACEMENT`` or ``"probed"`` for clouds of at least 128 Mi rows that carry normals, plain
+        allocation below; ``"probed"`` builds the row arrays from physical chunks spread over the three classes of HBM
+        address ranges whatever the size, so that points and normals -- written in lock step -- never share a class
+        (``placement.place_outputs``; ``self.placement`` reports what was done); ``"first"`` takes the arrays as the
+        allocator returns them.
+
+        The builder keeps the batches it is given (and with them their maps) until ``reset()`` so that it can redo them if
+        an in-kernel scan gives up (``check()`` / ``finish()``, ``self.healed``); it stops keeping them once they exceed a
+        quarter of the device's free memory."""
         dev = _require_gpu(device)
         self.device = dev
         self.capacity = int(capacity)
@@ -583,6 +589,8 @@ class CloudBuilder:
         out = self._out_struct()
         check(lib.dd_scatter(C.byref(cb), C.byref(out), plan.view_offsets.data_ptr(), plan.workspace.data_ptr(),
                              plan.workspace.numel(), _stream(self.device)))
+        self._retain_complete = False               # (a redo replays append() calls only: not with scatter() calls in between)
+        self._retained.clear()
         self.cursor.copy_(plan.view_offsets[-1:], non_blocking=True)
         self._offsets.append(plan.view_offsets)
         self._workspaces.append(plan.workspace)
