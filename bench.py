@@ -219,8 +219,14 @@ def verify_views(dd, cfg: dict, scene: dict, params: np.ndarray, E: np.ndarray, 
         if nm is not None:
             assert np.array_equal(one.normals.cpu().numpy(), ref.normals), f"view {i}: normals differ from the oracle"
         if len(ref.points):
-            scale = np.abs(ref.points).max()
-            err = float(np.abs(one.points.cpu().numpy().astype(np.float64) - ref.points).max() / scale)
+            # per point, |delta|_inf / max(|p_ref|_inf, scene radius); radius = camera centre + deepest finite depth
+            centre = -np.asarray(E[i], dtype=np.float64)[:3, :3].T @ np.asarray(E[i], dtype=np.float64)[:3, 3]
+            dfin = d[np.isfinite(d)].astype(np.float64)
+            radius = float(np.linalg.norm(centre) + (dfin.max() if dfin.size else 0.0))
+            delta = np.abs(one.points.cpu().numpy().astype(np.float64) - ref.points).max(axis=1)
+            denom = np.maximum(np.abs(ref.points).max(axis=1), radius)
+            fin = np.isfinite(ref.points).all(axis=1)
+            err = float((delta[fin] / denom[fin]).max()) if fin.any() else 0.0
             assert err <= 1e-4, f"view {i}: xyz relative error {err:.3e} > 1e-4"
             worst = max(worst, err)
         n_pts += hi - lo
