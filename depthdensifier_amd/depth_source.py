@@ -72,6 +72,11 @@ class StagingSlot:
 
 
 class DepthSource:
+    def cached_rgb(self, image_name: str) -> Optional[np.ndarray]:
+        """The image at processing resolution as (H,W,3) uint8 if the source holds it (``CachedSource`` with ``<stem>_rgb.npy``),
+        else None: the pipeline then decodes and resizes the image file like the reference (``scripts/test.py:145-152``)."""
+        return None
+
     def prepare(self, image_name: str, rgb_u8: np.ndarray, staging: Optional[StagingSlot] = None):
         """Optional host-side stage (file reads, decoding) that the pipeline may run ahead on an I/O thread;
         whatever it returns is handed to ``infer`` as ``prepared``.  Launches nothing on the GPU.  ``staging``: pinned
@@ -104,11 +109,20 @@ class CachedSource(DepthSource):
         if not self.dir.is_dir():
             raise FileNotFoundError(f"depth cache directory not found: {self.dir}")
 
-    def prepare(self, image_name, rgb_u8, staging=None):
+    def _stem(self, image_name: str) -> str:
         # COLMAP image names may carry sub-folders ("cam1/0001.jpg"): a cache laid out the same way wins, so that two
         # cameras' "0001" do not collide; otherwise the flat <stem> files
         nested, flat = str(Path(image_name).with_suffix("")), Path(image_name).stem
-        stem = nested if nested != flat and any((self.dir / (nested + ext)).exists() for ext in (".npz", "_depth.npy")) else flat
+        return nested if nested != flat and any((self.dir / (nested + ext)).exists() for ext in (".npz", "_depth.npy")) else flat
+
+    def cached_rgb(self, image_name):
+        """``<stem>_rgb.npy`` written by ``dump_cache(..., with_rgb=True)``: the image already decoded and resized (decoding a
+        1080p PNG costs 30-40 ms of CPU, reading 6 MB does not) -- memory-mapped, the pipeline copies it into its staging slot."""
+        f = self.dir / (self._stem(image_name) + "_rgb.npy")
+        return np.load(f, mmap_mode="r") if f.exists() else None
+
+    def prepare(self, image_name, rgb_u8, staging=None):
+        stem = self._stem(image_name)
         f = self.dir / (stem + ".npz")
         keep = (lambda k, a: staging.put(k, a)) if staging is not None else (lambda k, a: np.asarray(a))
         if f.exists():
@@ -139,11 +153,12 @@ class CachedSource(DepthSource):
 
 
 def dump_cache(source: DepthSource, image_dir: Path, cache_dir: Path, device: torch.device, factor: int = 1,
-               fp16_depth: bool = False, layout: str = "npy") -> int:
+               fp16_depth: bool = False, layout: str = "npy", with_rgb: bool = False) -> int:
     """Run ``source`` over every image of ``image_dir`` (resized like the pipeline, ``scripts/test.py:145-152``) and
     write the maps ``CachedSource`` reads back; returns the number of images written.  ``layout="npy"`` (default)
     writes ``<stem>_depth.npy`` / ``_mask.npy`` / ``_normal.npy`` -- a plain read, 10x faster to load than the
-    single-file ``layout="npz"`` whose zip container is CRC-checked on every read (4.7 vs 50 ms per 1080p view)."""
+    single-file ``layout="npz"`` whose zip container is CRC-checked on every read (4.7 vs 50 ms per 1080p view).
+    ``with_rgb``: also ``<stem>_rgb.npy``, the image at processing resolution (``CachedSource.cached_rgb``)."""
     if layout not in ("npy", "npz"):
         raise ValueError("layout must be 'npy' or 'npz'")
     from PIL import Image as PILImage
@@ -163,6 +178,8 @@ def dump_cache(source: DepthSource, image_dir: Path, cache_dir: Path, device: to
         else:
             for k, v in out.items():
                 np.save(cache_dir / f"{f.stem}_{k}.npy", v)
+        if with_rgb:            # the resized image itself: a scan run again from the cache then decodes nothing
+            np.save(cache_dir / f"{f.stem}_rgb.npy", rgb)
         n += 1
     return n
 

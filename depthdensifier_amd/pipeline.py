@@ -212,8 +212,11 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
     clock = time.perf_counter
 
     def fetch(im, slot=None):                                                   # no GPU work: safe on an I/O thread
-        rgb = _load_rgb(config.paths.image_dir / im.name, f)                    # :145-152
+        rgb = source.cached_rgb(im.name)                                        # the cache may hold the resized image itself
+        if rgb is None or tuple(rgb.shape[:2]) != _processing_size(config.paths.image_dir / im.name, f)[::-1]:
+            rgb = _load_rgb(config.paths.image_dir / im.name, f)                # :145-152
         if slot is None:
+            rgb = np.array(rgb) if isinstance(rgb, np.memmap) else rgb        # (a private, writable copy of a memory-mapped image)
             return rgb, source.prepare(im.name, rgb), None
         slot.wait()                                                             # the uploads of the slot's previous view are done
         rgb = slot.put("rgb", rgb)

@@ -425,3 +425,37 @@ def test_cached_source_prefers_a_nested_layout(tmp_path):
     assert src.prepare("0001.jpg", rgb)["depth"][0, 0] == 1.0
     with pytest.raises(FileNotFoundError):
         src.prepare("cam1/0002.jpg", rgb)
+
+
+@pytest.mark.gpu
+def test_cached_image_gives_the_same_model(tmp_path):
+    """dump_cache(with_rgb=True) / <stem>_rgb.npy: the pipeline takes the decoded image from the cache instead of decoding the
+    file -- same model, byte for byte; an image cached at another size is ignored."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from PIL import Image as PILImage
+    from scan_factory import make_scan
+    from depthdensifier_amd import pipeline as P
+    scan, cache, _ = make_scan(tmp_path, "s", V=5, H=72, W=96, seed=4)
+    npy = scan / "cache_npy"
+    npy.mkdir()
+    for f in sorted(cache.glob("*.npz")):
+        with np.load(f) as z:
+            for k in z.files:
+                np.save(npy / f"{f.stem}_{k}.npy", z[k])
+    outs = []
+    for with_rgb in (False, True, "wrong size"):
+        if with_rgb:
+            for img in sorted((scan / "images").iterdir()):
+                a = np.array(PILImage.open(img).convert("RGB"))
+                np.save(npy / f"{img.stem}_rgb.npy", a if with_rgb is True else a[:10])
+        cfg = P.ScriptConfig()
+        cfg.paths = P.PathsConfig(recon_path=scan / "sparse" / "0", image_dir=scan / "images", output_model_dir=tmp_path / f"out_{with_rgb}")
+        cfg.moge.cache_dir = npy
+        cfg.processing.downsample_density = 1
+        cfg.refiner.verbose = 0
+        cfg.refiner.adaptive_correspondences = False
+        P.main(cfg)
+        outs.append((tmp_path / f"out_{with_rgb}" / "points3D.bin").read_bytes())
+    assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 1000

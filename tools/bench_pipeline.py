@@ -16,14 +16,20 @@ with tempfile.TemporaryDirectory() as tmp:
     import numpy as np
     npy_cache = scan / "moge_cache_npy"
     npy_cache.mkdir()
+    from PIL import Image as PILImage
+    rgb_cache = scan / "moge_cache_npy_rgb"          # the same maps plus the decoded image (dump_cache(with_rgb=True))
+    rgb_cache.mkdir()
     for f in sorted((scan / "moge_cache").glob("*.npz")):
         with np.load(f) as z:
             for k in z.files:
                 np.save(npy_cache / f"{f.stem}_{k}.npy", z[k])
+                (rgb_cache / f"{f.stem}_{k}.npy").symlink_to(npy_cache / f"{f.stem}_{k}.npy")
+        img = next(p for p in (scan / "images").iterdir() if p.stem == f.stem)
+        np.save(rgb_cache / f"{f.stem}_rgb.npy", np.array(PILImage.open(img).convert("RGB")))
     import os
     ncores = len(os.sched_getaffinity(0))
     for stride, nio in ((32, 0), (32, 4), (32, 8), (4, 8), (1, 8), (1, max(2, min(16, ncores - 2)))):
-      for cache in ("moge_cache", "moge_cache_npy"):
+      for cache in ("moge_cache", "moge_cache_npy") + (("moge_cache_npy_rgb",) if stride == 1 or nio == 8 else ()):
         cfg = P.ScriptConfig()
         cfg.paths = P.PathsConfig(recon_path=scan / "sparse" / "0", image_dir=scan / "images", output_model_dir=Path(tmp) / f"out_s{stride}")
         cfg.moge.cache_dir = scan / cache
@@ -37,4 +43,4 @@ with tempfile.TemporaryDirectory() as tmp:
         torch.cuda.synchronize()
         t = {k: round(v, 3) for k, v in rep["timings"].items()}
         loop = sum(t[k] for k in ("image_decode", "depth_source", "refine", "densify"))
-        print(json.dumps({"stride": stride, "io_threads": nio, "loop_ms_per_view": round(loop / rep["views"] * 1e3, 2), "cache": "npy" if cache.endswith("npy") else "npz", "views": rep["views"], "dense_points": rep["dense_points"], "removed": rep["removed"], "seconds": t}), flush=True)
+        print(json.dumps({"stride": stride, "io_threads": nio, "loop_ms_per_view": round(loop / rep["views"] * 1e3, 2), "cache": "npy+rgb" if cache.endswith("rgb") else "npy" if cache.endswith("npy") else "npz", "views": rep["views"], "dense_points": rep["dense_points"], "removed": rep["removed"], "seconds": t}), flush=True)
