@@ -95,7 +95,23 @@ int main() {
 
     hipStream_t stream; CK(hipStreamCreate(&stream));
     std::vector<float> xyz(N * 3), nrm(N * 3); std::vector<uint8_t> col(N * 3); std::vector<int> pix(N); std::vector<int64_t> off(V + 1);
-    for (int mode = 0; mode < 2; ++mode) {       // 0: dd_plan + dd_scatter, 1: fused dd_unproject_compact
+    // mode 2 writes into arrays handed out by the HBM zone arena (dd_arena_*): ordinary device pointers for every entry point
+    DDArena *arena = NULL;
+    void *aptr[3] = {NULL, NULL, NULL};
+    for (int mode = 0; mode < 3; ++mode) {       // 0: dd_plan + dd_scatter, 1: fused dd_unproject_compact, 2: fused, into arena arrays
+        if (mode == 2) {
+            if (dd_arena_create(0, 0, &arena) != DD_OK) { printf("dd_arena_create: %s\n", dd_arena_last_error()); return 6; }
+            const int64_t sizes[3] = {(int64_t)N * 12, (int64_t)N * 12, (int64_t)N * 3};
+            const int32_t layouts[3] = {DD_ARENA_ROTATED + 0, DD_ARENA_ROTATED + 1, DD_ARENA_ROTATED + 2};
+            const int rc = dd_arena_alloc(arena, 3, sizes, layouts, (int64_t)16 << 30, aptr);
+            if (rc < 0) { printf("dd_arena_alloc: %s\n", dd_arena_last_error()); return 6; }
+            int32_t cls[8]; DDArenaStats st;
+            if (dd_arena_classes(arena, aptr[0], cls, 8) != 1 || dd_arena_stats(arena, &st) != DD_OK || st.chunk_bytes != ((int64_t)1 << 30)) { printf("arena bookkeeping is wrong\n"); return 6; }
+            if (dd_arena_free(arena, d_ws) != DD_ERR_INVALID_ARG) { printf("dd_arena_free accepted a foreign pointer\n"); return 6; }
+            d_xyz = aptr[0]; d_nrm = aptr[1]; d_col = aptr[2];
+            out.xyz = (float *)d_xyz; out.normal = (float *)d_nrm; out.rgb = (uint8_t *)d_col;
+            printf("arena: %s, %lld chunks created, classes found %d\n", rc == 1 ? "allocated (not apart)" : "allocated apart", (long long)st.chunks_created, st.num_classes);
+        }
         CK(hipMemsetAsync(d_cur, 0, 8, stream)); CK(hipMemsetAsync(d_xyz, 0xff, N * 12, stream));
         if (mode == 0) {
             DD(dd_plan(&b, (const int64_t *)d_cur, (int64_t *)d_off, d_ws, wsb, stream));
@@ -123,6 +139,7 @@ int main() {
         if (mode == 1) { int64_t cur; CK(hipMemcpy(&cur, d_cur, 8, hipMemcpyDeviceToHost)); if (cur != n_ref) { printf("cursor %lld != %lld\n", (long long)cur, (long long)n_ref); return 4; } }
         printf("mode %d: %lld points, xyz max rel err %.2e\n", mode, (long long)n_ref, worst);
     }
+    // (the arena's arrays stay in use below: the records are formatted from them)
     // the cloud as points3D.bin records (dd_format_points3d): 51 bytes per point, checked field by field
     {
         void *d_rec;
@@ -147,6 +164,8 @@ int main() {
     // error convention: invalid argument -> negative code + message, nothing thrown
     b.stride = 0;
     if (dd_workspace_bytes(&b) != DD_ERR_INVALID_ARG || strstr(dd_last_error(), "stride") == NULL) { printf("error convention broken\n"); return 5; }
+    for (int k = 0; k < 3; ++k) if (dd_arena_free(arena, aptr[k]) != DD_OK) { printf("dd_arena_free: %s\n", dd_arena_last_error()); return 6; }
+    if (dd_arena_trim(arena, 0) != DD_OK || dd_arena_destroy(arena) != DD_OK) { printf("arena teardown failed\n"); return 6; }
     printf("C ABI OK\n");
     return 0;
 }
