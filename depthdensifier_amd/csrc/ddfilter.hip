@@ -19,8 +19,8 @@
 //   floater_votes_kernel_cull       kernel2's pair test behind a two-level view cull: a mask of visible views per 65 536
 //                                   points, then the workgroup's own bounding sphere (mode 3; mode 4 = default of the host
 //                                   layer: votes_cull_estimate samples the workgroups and kernel2 or the cull runs)
-//   floater_votes_kernel32 + votes_resolve + votes_redo   the float32 first pass with error bounds (modes 0 / 2; an
-//                                   experiment that measured slower -- v_fma_f64 issues as fast as v_fma_f32 on gfx950)
+//   (a float32 first pass with error bounds existed in round 2 and measured slower -- v_fma_f64 issues as fast as a
+//    scalar-per-lane v_fma_f32 on gfx950; removed in round 3, the packed form's ceiling is in tools/experiments)
 //   compact_* kernels               dd_compact_cloud: stable compaction of the cloud by votes < threshold
 
 #include <hip/hip_runtime.h>
