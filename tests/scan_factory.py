@@ -15,11 +15,13 @@ def rot_to_qvec(R):
     return np.array([w, x, y, z])
 
 
-def make_scan(root: Path, name: str, V=5, H=96, W=128, seed=0, floaters=0.02, second_size=None, image_scale=1, second_tail=0):
+def make_scan(root: Path, name: str, V=5, H=96, W=128, seed=0, floaters=0.02, second_size=None, image_scale=1, second_tail=0,
+              image_ext=".png", photo_like=False):
     """``second_size=(H2, W2)``: odd-numbered views use a second camera of that size (mixed resolutions in one scan);
     with ``second_tail=k`` only the LAST k views use it (a camera no early view touches).  ``image_scale=f``: the image
     files and the sparse model's cameras / 2-D observations are f times larger than the cached maps, i.e. a scan meant
-    to be run with ``pipeline_downsample_factor=f`` (``scripts/test.py:145-152, 172-173``)."""
+    to be run with ``pipeline_downsample_factor=f`` (``scripts/test.py:145-152, 172-173``).  ``image_ext=".jpg"`` with
+    ``photo_like=True`` writes smooth pictures as JPEG files (what real scans hold; lossy, so for timing only)."""
     from PIL import Image as PILImage
     rng = np.random.default_rng(seed)
     scan = Path(root) / name
@@ -60,11 +62,14 @@ def make_scan(root: Path, name: str, V=5, H=96, W=128, seed=0, floaters=0.02, se
         normal = np.tile(np.array([0.0, -1.0, 0.0]) @ R.T, (H, W, 1)).astype(np.float32)   # plane normal in the camera frame
         img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
         stem = f"img_{v:03d}"
+        if photo_like:               # low-frequency content: a photograph's share of zero coefficients, not noise
+            small = rng.integers(0, 256, (H // 16 + 1, W // 16 + 1, 3), dtype=np.uint8)
+            img = np.asarray(PILImage.fromarray(small).resize((W, H), PILImage.Resampling.BICUBIC))
         if image_scale > 1:          # a smooth full-resolution picture (so that LANCZOS down-sampling is not pure noise)
             big = np.asarray(PILImage.fromarray(img).resize((W * image_scale, H * image_scale), PILImage.Resampling.BICUBIC))
-            PILImage.fromarray(big).save(scan / "images" / f"{stem}.png")
+            PILImage.fromarray(big).save(scan / "images" / f"{stem}{image_ext}")
         else:
-            PILImage.fromarray(img).save(scan / "images" / f"{stem}.png")
+            PILImage.fromarray(img).save(scan / "images" / f"{stem}{image_ext}", **({"quality": 92} if image_ext != ".png" else {}))
         np.savez(cache / f"{stem}.npz", depth=mono_f, mask=mask, normal=normal)
         # sparse observations on the plane
         n_obs = 300
@@ -77,7 +82,7 @@ def make_scan(root: Path, name: str, V=5, H=96, W=128, seed=0, floaters=0.02, se
         pid = np.arange(next_id, next_id + len(world)); next_id += len(world)
         ids.append(pid); xyz.append(world); rgbs.append(np.full((len(world), 3), 200, np.uint8))
         xys = np.stack([np.floor(pu), np.floor(pv)], -1) * image_scale
-        rec.images[v + 1] = Image(v + 1, rot_to_qvec(R), t, cam_id, f"{stem}.png", xys, pid.astype(np.int64))
+        rec.images[v + 1] = Image(v + 1, rot_to_qvec(R), t, cam_id, f"{stem}{image_ext}", xys, pid.astype(np.int64))
         truth.append(dict(R=R, t=t, depth_true=depth_true, mono=mono_f, mask=mask, normal=normal, rgb=img))
     rec.point_ids = np.concatenate(ids).astype(np.uint64)
     rec.point_xyz = np.concatenate(xyz)

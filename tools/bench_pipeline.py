@@ -9,9 +9,10 @@ import torch
 from scan_factory import make_scan
 from depthdensifier_amd import pipeline as P
 V = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+JPG = "--jpg" in sys.argv      # photograph-like JPEG images (what real scans hold) instead of PNG files of noise
 with tempfile.TemporaryDirectory() as tmp:
     t0 = time.time()
-    scan, _cache, _truth = make_scan(Path(tmp), "scan", V=V, H=1080, W=1920, seed=1)
+    scan, _cache, _truth = make_scan(Path(tmp), "scan", V=V, H=1080, W=1920, seed=1, **({"image_ext": ".jpg", "photo_like": True} if JPG else {}))
     print(f"scan of {V} views generated in {time.time() - t0:.1f}s", flush=True)
     import numpy as np
     npy_cache = scan / "moge_cache_npy"
@@ -43,4 +44,4 @@ with tempfile.TemporaryDirectory() as tmp:
         torch.cuda.synchronize()
         t = {k: round(v, 3) for k, v in rep["timings"].items()}
         loop = sum(t[k] for k in ("image_decode", "depth_source", "refine", "densify"))
-        print(json.dumps({"stride": stride, "io_threads": nio, "loop_ms_per_view": round(loop / rep["views"] * 1e3, 2), "cache": "npy+rgb" if cache.endswith("rgb") else "npy" if cache.endswith("npy") else "npz", "views": rep["views"], "dense_points": rep["dense_points"], "removed": rep["removed"], "seconds": t}), flush=True)
+        print(json.dumps({"stride": stride, "io_threads": nio, "loop_ms_per_view": round(loop / rep["views"] * 1e3, 2), "images": "jpg" if JPG else "png", "cache": "npy+rgb" if cache.endswith("rgb") else "npy" if cache.endswith("npy") else "npz", "views": rep["views"], "dense_points": rep["dense_points"], "removed": rep["removed"], "seconds": t}), flush=True)
