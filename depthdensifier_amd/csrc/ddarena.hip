@@ -37,6 +37,7 @@
 #include <vector>
 
 #include "ddcore.h"
+#include "ddarena_plan.h"
 
 namespace {
 
@@ -68,7 +69,9 @@ __global__ __launch_bounds__(256) void zone_pair_store(float *a, float *b, const
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-constexpr int MAX_CLASSES = 3;
+using ddarena_plan::MAX_CLASSES;
+using ddarena_plan::best_assignment;
+using ddarena_plan::plan_classes;
 constexpr size_t SCOUT_SLOTS = 512;
 constexpr int SCOUT_BATCH = 8;
 
@@ -187,8 +190,10 @@ int scout_one(DDArena *A, int *chunk_out) {
     acc.flags = hipMemAccessFlagsProtReadWrite;
     e = hipMemSetAccess(slot_ptr(A, slot), A->chunk, &acc, 1);
     if (e != hipSuccess) { (void)hipMemUnmap(slot_ptr(A, slot), A->chunk); (void)hipMemRelease(c.h); return afail_hip("hipMemSetAccess(scout)", e); }
-    A->chunks.push_back(c);
-    const int ci = (int)A->chunks.size() - 1;
+    int ci = -1;                                     // entries of released chunks are reused: nothing refers to them any more
+    for (size_t i = 0; i < A->chunks.size() && ci < 0; ++i) if (!A->chunks[i].live) ci = (int)i;
+    if (ci < 0) { A->chunks.push_back(c); ci = (int)A->chunks.size() - 1; }
+    else A->chunks[ci] = c;
     A->slot_owner[slot] = ci;
     A->created += 1;
     float *w = reinterpret_cast<float *>(slot_ptr(A, slot));
@@ -270,76 +275,10 @@ int free_count(const DDArena *A, int cls) {
     return n;
 }
 
-// best assignment of groups to classes for the chunks at hand: maximise the chunks served from a group's own class;
-// groups that were given a class by an earlier call keep it
-// (`fixed[c]`: chunks the rotated arrays of the request want from class c, whatever the assignment)
-int best_assignment(const DDArena *A, const int need[MAX_CLASSES], const int fixed[MAX_CLASSES], int perm_out[MAX_CLASSES]) {
-    int avail[MAX_CLASSES];
-    for (int k = 0; k < MAX_CLASSES; ++k) avail[k] = free_count(A, k);
-    int p[MAX_CLASSES] = {0, 1, 2}, best = -1;
-    do {
-        bool ok = true;
-        for (int g = 0; g < MAX_CLASSES; ++g) if (A->group_class[g] >= 0 && A->group_class[g] != p[g]) ok = false;
-        if (!ok) continue;
-        int want[MAX_CLASSES];
-        for (int c = 0; c < MAX_CLASSES; ++c) want[c] = fixed[c];
-        for (int g = 0; g < MAX_CLASSES; ++g) want[p[g]] += need[g];
-        int served = 0;
-        for (int c = 0; c < MAX_CLASSES; ++c) served += std::min(want[c], avail[c]);
-        if (served > best) { best = served; memcpy(perm_out, p, sizeof(p)); }
-    } while (std::next_permutation(p, p + MAX_CLASSES));
-    return best;
-}
-
-// Which class every chunk of every array of a request is taken from, given the free chunks at hand.  Class-pure arrays take
-// the class of their group (`perm`).  Rotated arrays are laid out index by index: at chunk index k the arrays, in phase
-// order, each take the class with the most free chunks left that no other rotated array of the request uses at k (ties go to
-// (phase + k) mod 3, so balanced supplies give the exact rotation, and two plentiful classes give two class-pure arrays in
-// different classes).  `missing`: chunks nobody can supply yet; `conflicts`: chunk indices where one of the first TWO rotated
-// arrays (the lock-step store streams) had to share a class -- the third (colours) sharing one is harmless.
-void plan_classes(const DDArena *A, int n, const std::vector<int> &nch, const int32_t *layouts, const int perm[MAX_CLASSES],
-                  std::vector<std::vector<int>> &choice, int *missing, int *conflicts) {
-    int avail[MAX_CLASSES];
+// the layout planning (which class every chunk of every array comes from) is plain host logic: ddarena_plan.h, compiled
+// into tests/c_client/arena_plan_test.cpp by the CPU suite as well
+void free_counts(const DDArena *A, int avail[MAX_CLASSES]) {
     for (int c = 0; c < MAX_CLASSES; ++c) avail[c] = free_count(A, c);
-    choice.assign(n, std::vector<int>());
-    *missing = 0; *conflicts = 0;
-    auto any_class = [&]() { int b = -1; for (int c = 0; c < MAX_CLASSES; ++c) if (avail[c] > 0 && (b < 0 || avail[c] > avail[b])) b = c; return b; };
-    for (int i = 0; i < n; ++i) {
-        if (layouts[i] >= MAX_CLASSES) continue;
-        for (int k = 0; k < nch[i]; ++k) {
-            int c = perm[layouts[i]];
-            if (avail[c] <= 0) { c = any_class(); if (c >= 0) *conflicts += 1; }
-            if (c < 0) { *missing += 1; choice[i].push_back(-1); continue; }
-            avail[c] -= 1;
-            choice[i].push_back(c);
-        }
-    }
-    std::vector<int> rot;
-    for (int ph = 0; ph < MAX_CLASSES; ++ph) for (int i = 0; i < n; ++i) if (layouts[i] == DD_ARENA_ROTATED + ph) rot.push_back(i);
-    int kmax = 0;
-    for (int i : rot) kmax = std::max(kmax, nch[i]);
-    for (int k = 0; k < kmax; ++k) {
-        bool used[MAX_CLASSES] = {false, false, false};
-        int order = 0;
-        for (int i : rot) {
-            const int my = order++;
-            if (k >= nch[i]) continue;
-            const int pref = (layouts[i] - DD_ARENA_ROTATED + k) % MAX_CLASSES;
-            int c = -1;
-            for (int d = 0; d < MAX_CLASSES; ++d) {
-                const int cand = (pref + d) % MAX_CLASSES;
-                if (avail[cand] > 0 && !used[cand] && (c < 0 || avail[cand] > avail[c])) c = cand;
-            }
-            if (c < 0) {                     // every class that still has chunks is taken at this index
-                c = any_class();
-                if (c >= 0 && my < 2) *conflicts += 1;
-            }
-            if (c < 0) { *missing += 1; choice[i].push_back(-1); continue; }
-            avail[c] -= 1;
-            used[c] = true;
-            choice[i].push_back(c);
-        }
-    }
 }
 
 int take_chunk(DDArena *A, int cls) {      // a free chunk of the class; -1 = none
@@ -434,8 +373,10 @@ int dd_arena_alloc(DDArena *A, int32_t n, const int64_t *sizes, const int32_t *g
     int missing = 0, conflicts = 0;
     // scout until every array can be laid out without two lock-step arrays sharing a class, or the budget / the memory is spent
     for (;;) {
-        best_assignment(A, need, fixed, perm);
-        plan_classes(A, n, nch, groups, perm, choice, &missing, &conflicts);
+        int avail[MAX_CLASSES];
+        free_counts(A, avail);
+        best_assignment(avail, A->group_class, need, fixed, perm);
+        plan_classes(avail, n, nch, groups, perm, choice, &missing, &conflicts);
         if ((missing == 0 && conflicts == 0) || oom) break;
         int live_free = 0;
         for (const Chunk &c : A->chunks) if (c.live && !c.used && !c.anchor && c.cls >= 0) ++live_free;

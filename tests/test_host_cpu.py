@@ -254,3 +254,17 @@ def test_csrc_makefile_builds_a_loadable_library(libmod, tmp_path):
         assert getattr(handle, sym) is not None
     handle.dd_abi_version.restype = C.c_int
     assert handle.dd_abi_version() == libmod.DD_ABI_VERSION
+
+
+def test_arena_layout_planning(tmp_path):
+    """The HBM zone arena's planning (which class every chunk of every array comes from) is plain C++
+    (csrc/ddarena_plan.h): compiled with g++ and run here, no GPU involved."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not installed")
+    exe = tmp_path / "arena_plan_test"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", f"-I{ROOT / 'include'}", f"-I{ROOT / 'depthdensifier_amd' / 'csrc'}",
+                    "-o", str(exe), str(ROOT / "tests" / "c_client" / "arena_plan_test.cpp")], check=True, timeout=120)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "plan OK" in out.stdout, out.stdout + out.stderr
