@@ -27,6 +27,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "ddcore.h"
 #include "ddrefine_math.h"
 
@@ -88,9 +90,11 @@ struct KArgs {
     unsigned flags;
     int conf_f16;
     int view_base;
-    int sp_static;                // diagnostic: single-pass without tickets (tile = blockIdx.x)
+    unsigned prefetch_ahead;      // single-pass lean kernel: tile t touches the input lines of tile t + prefetch_ahead (0 = off; see prefetch_tile)
+    int no_prefetch;              // tuning bit 16: keep prefetch_ahead at 0 (A/B)
     int align_runs;               // lean kernels: shift the sweeps so that wave runs start on 128-byte lines (default on)
     unsigned spin_limit;          // look-back polls before a tile gives up (SPIN_LIMIT; 0 with the fault-injection tuning bit 64)
+    int dense_ok;                 // lean kernels: tiles whose pixels all survive take the list-free path (dense_wave)
 };
 
 
@@ -613,6 +617,282 @@ __device__ __forceinline__ long long lookback13(unsigned long long *state, unsig
     return excl;
 }
 
+// ==================================================================================================
+// Dense tiles.  Where every pixel of a tile survives (the inside of a mask blob, an unmasked depth map: all of BASELINE
+// configs[4] and most tiles of a real scan) the compaction is the identity: point j of the tile is pixel j.  Such a
+// tile builds no list.  Each wave keeps its own 1024 pixels:
+//   * xyz: the raw depth vectors go to LDS as they were loaded (one ds_write_b128 per lane), are read back one
+//     pixel per lane (x advances by 64 per step: no division), and the 12-byte rows are staged in LDS at the byte
+//     phase they have in HBM, so that they leave as line-aligned 16-byte pieces: one wave store = 1 KiB = 8 whole
+//     128-byte lines (the shape a plain fill reaches 6.9-7.0 TB/s with where 12-byte row stores reach 5.75,
+//     profiles/r03_zone_interleave.txt); the bytes that share a line with the next chunk are carried over in LDS;
+//   * normals / colours: the tile's rows are one contiguous run of the source map -- a shifted copy, 16 bytes
+//     per lane, aligned on the store side;
+//   * pixel / view indices: generated.
+// Same arithmetic as the list path (same FMA chain), so the rows are bit-identical (tests/test_dense_tiles.py).
+// ==================================================================================================
+#ifndef DD_DENSE
+#define DD_DENSE 1
+#endif
+constexpr int DENSE_CHUNK = 256;                                  // rows staged per flush: 3072 B = 3 wave stores of 1 KiB
+constexpr int DENSE_STAGE = DENSE_CHUNK * 12 + 128 + 16;          // + the line phase (< 128 B) + slack to a 16-byte multiple
+constexpr int DENSE_LDS_PER_WAVE = DENSE_STAGE + 1024;            // + one 16-byte depth vector per lane
+static_assert(L_WSPAN % DENSE_CHUNK == 0 && DENSE_STAGE % 16 == 0, "dense path geometry");
+
+typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
+typedef u32x4 u32x4_a1 __attribute__((aligned(1)));
+
+// a workgroup-uniform 64-bit value that came through LDS or memory, moved to SGPRs (addresses derived from it stay scalar)
+__device__ __forceinline__ long long uniform64(long long x) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)x);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)x >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+// LDS operations of one wave execute in issue order; this keeps the COMPILER from moving the LDS accesses of a
+// lane across a point where the wave's lanes exchange data through LDS (no instruction is emitted).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Experiment build (-DDD_X_STAMPS): per tile, lane 0 of two waves writes shader-clock stamps of the phases to the buffer passed
+// in DDViewBatch.refined_out (16 x 8 bytes per tile): where a tile's time goes (tools/ab_builds.py --stamps).
+#ifdef DD_X_STAMPS
+#define STAMP(slot) do { if (lane == 0 && a.refined_out) reinterpret_cast<unsigned long long *>(a.refined_out)[(size_t)t * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
+// Experiment knob (tools/ab_builds.py): at most DD_STORE_CAP vector-memory operations of a wave stay in flight behind a store.
+#ifndef DD_STORE_CAP
+#define DD_STORE_CAP -1
+#endif
+__device__ __forceinline__ void cap_stores() {
+    if constexpr (DD_STORE_CAP >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DD_STORE_CAP) : "memory");
+}
+
+// One wave's contiguous run of one output array in "span coordinates": byte 0 is the 128-byte line that holds the
+// run's first byte, the run is [lo, hi) with lo < 128.
+struct Span {
+    unsigned char *line;
+    unsigned lo, hi;
+};
+__device__ __forceinline__ Span make_span(void *base, long long row0, unsigned row_bytes, unsigned rows) {
+#ifdef DD_X_SINK    // experiment: every span lands in the first MiB of its array (stores stay in L2): what the kernel costs without its HBM writes
+    unsigned char *g = reinterpret_cast<unsigned char *>(base) + ((row0 * (long long)row_bytes) & 0xFFFFCll);
+#else
+    unsigned char *g = reinterpret_cast<unsigned char *>(base) + row0 * (long long)row_bytes;
+#endif
+    const unsigned h = (unsigned)(reinterpret_cast<uintptr_t>(g) & 127u);
+    Span s; s.line = g - h; s.lo = h; s.hi = h + rows * row_bytes;
+    return s;
+}
+// the 16-byte piece at span offset o (a multiple of 16): whole if it lies inside the run, else its dwords / bytes that do
+template <int GRAN>
+__device__ __forceinline__ void put16(const Span &s, unsigned o, const uint4 &v) {
+    if (o >= s.lo && o + 16u <= s.hi) { *reinterpret_cast<uint4 *>(s.line + o) = v; return; }
+    if (o + 16u <= s.lo || o >= s.hi) return;
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    if constexpr (GRAN == 4) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const unsigned b = o + 4u * c; if (b >= s.lo && b < s.hi) *reinterpret_cast<unsigned *>(s.line + b) = w[c]; }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { const unsigned b = o + (unsigned)c; if (b >= s.lo && b < s.hi) s.line[b] = (unsigned char)(w[c >> 2] >> (8 * (c & 3))); }
+    }
+}
+// sweep i of a span = its bytes [1024 i, 1024 (i + 1)): one 16-byte piece per lane.  `gen(o)` yields the piece at span offset o.
+template <int GRAN, typename Gen>
+__device__ __forceinline__ void span_sweep(const Span &s, int i, int lane, Gen gen) {
+    const unsigned o = (unsigned)(i * 64 + lane) * 16u;
+    const unsigned b0 = (unsigned)i * 1024u;
+    if (b0 >= s.hi || b0 + 1024u <= s.lo) return;                               // wave-uniform: nothing of this sweep is ours
+    if (b0 >= s.lo && b0 + 1024u <= s.hi) { *reinterpret_cast<uint4 *>(s.line + o) = gen(o); cap_stores(); return; }   // wave-uniform: all of it
+    if (o + 16u > s.lo && o < s.hi) put16<GRAN>(s, o, gen(o));
+    cap_stores();
+}
+// shifted copy: source byte 0 corresponds to span byte s.lo; NSW sweeps cover the nominal run + the line phase.
+// Loads of a group of 4 sweeps are issued together.  A piece is loaded only if some of it is inside the run; a
+// straddling piece loads its 16 bytes from a clamped address and shifts them (the source run has >= 16 bytes).
+template <int GRAN, int NSW, typename VecT>
+__device__ __forceinline__ void span_copy(const Span &s, const unsigned char *__restrict__ src, int lane) {
+#pragma unroll 1
+    for (int g = 0; g < NSW; g += 4) {          // a real loop: 4 loads in flight per lane, not 13
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (g + k < NSW) {
+                const unsigned o = (unsigned)((g + k) * 64 + lane) * 16u;
+                v[k] = make_uint4(0u, 0u, 0u, 0u);
+                if (o >= s.lo && o + 16u <= s.hi) {
+                    const u32x4 w = __builtin_nontemporal_load(reinterpret_cast<const VecT *>(src + (o - s.lo)));
+                    v[k] = make_uint4(w.x, w.y, w.z, w.w);
+                } else if (o + 16u > s.lo && o < s.hi) {          // straddles an end of the run: element by element
+                    unsigned w[4] = {0u, 0u, 0u, 0u};
+                    if constexpr (GRAN == 4) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { const unsigned b = o + 4u * c; if (b >= s.lo && b < s.hi) w[c] = *reinterpret_cast<const unsigned *>(src + (b - s.lo)); }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) { const unsigned b = o + (unsigned)c; if (b >= s.lo && b < s.hi) w[c >> 2] |= (unsigned)src[b - s.lo] << (8 * (c & 3)); }
+                    }
+                    v[k] = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (g + k < NSW) {
+                const uint4 val = v[k];
+                span_sweep<GRAN>(s, g + k, lane, [&](unsigned) { return val; });
+            }
+        }
+    }
+}
+
+struct CamBlock { float m00, m01, m02, m10, m11, m12, m20, m21, m22, c0, c1, c2; };
+
+// One wave's 1024 pixels of a dense tile.  `d`: the raw depth vectors as loaded (lane l, group ch: pixels
+// qw + (64 ch + l) VEC ...); `lds`: this wave's DENSE_LDS_PER_WAVE bytes (16-byte aligned); `row0`: output row of pixel qw.
+template <typename DepthT, bool HAS_NORMAL, bool HAS_RGB>
+__device__ __forceinline__ void dense_wave(const KArgs &a, const uint4 (&d)[L_PXT / (16 / (int)sizeof(DepthT))], unsigned char *lds,
+                                           const CamBlock &cam, unsigned v, long long vbase, unsigned q0, unsigned qw, long long row0, int lane) {
+    constexpr int VEC = 16 / (int)sizeof(DepthT), CH = L_PXT / VEC, CSPAN = 64 * VEC, SUBS = CSPAN / DENSE_CHUNK;
+    static_assert(CSPAN % DENSE_CHUNK == 0, "a depth vector group is a whole number of staged chunks");
+    const long long room = a.capacity - row0;
+    if (room <= 0) return;
+    const unsigned rows = room < (long long)L_WSPAN ? (unsigned)room : (unsigned)L_WSPAN;   // < L_WSPAN only where the capacity cuts the cloud
+
+    // ---- xyz ----
+#ifndef DD_X_NOXYZ
+    if (a.out_xyz) {
+        float *const stage_f = reinterpret_cast<float *>(lds);
+        unsigned *const stage_u = reinterpret_cast<unsigned *>(lds);
+        uint4 *const dvec = reinterpret_cast<uint4 *>(lds + DENSE_STAGE);
+        const DepthT *const delem = reinterpret_cast<const DepthT *>(lds + DENSE_STAGE);
+        const Span sx = make_span(a.out_xyz, row0, 12u, rows);
+        const unsigned hq = sx.lo >> 2;                       // line phase in dwords (< 32)
+        // (x, y) of this lane's first pixel: one division per lane and tile, then x += 64 per step (W >= 64)
+        const unsigned W = (unsigned)a.W;
+        const unsigned y0 = q0 / W;
+        const unsigned r = qw + (unsigned)lane - y0 * W;     // < tile + W
+        unsigned yo = (unsigned)((float)r * (1.0f / (float)W));
+        if (yo * W > r) --yo; else if ((yo + 1) * W <= r) ++yo;
+        float fy = (float)(y0 + yo), fx = (float)(r - yo * W);
+        const float Wf = (float)W;
+        int cc = 0;
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) {
+            wave_lds_sync();
+            dvec[lane] = d[ch];
+            wave_lds_sync();
+#pragma unroll
+            for (int sub = 0; sub < SUBS; ++sub) {
+                constexpr int STEPS = DENSE_CHUNK / 64;
+                float dd[STEPS];
+#pragma unroll
+                for (int s = 0; s < STEPS; ++s) dd[s] = Elem<DepthT>::cvt(delem[sub * DENSE_CHUNK + s * 64 + lane]);   // pixel inside the group's span
+#pragma unroll
+                for (int s = 0; s < STEPS; ++s) {
+                    float *o = stage_f + hq + (unsigned)(s * 64 + lane) * 3u;
+                    o[0] = fmaf(dd[s], fmaf(cam.m00, fx, fmaf(cam.m01, fy, cam.m02)), cam.c0);
+                    o[1] = fmaf(dd[s], fmaf(cam.m10, fx, fmaf(cam.m11, fy, cam.m12)), cam.c1);
+                    o[2] = fmaf(dd[s], fmaf(cam.m20, fx, fmaf(cam.m21, fy, cam.m22)), cam.c2);
+                    const float nx = fx + 64.0f;
+                    const bool wrap = nx >= Wf;
+                    fx = wrap ? nx - Wf : nx;
+                    fy = wrap ? fy + 1.0f : fy;
+                }
+                wave_lds_sync();
+                const unsigned base = (unsigned)cc * (unsigned)(DENSE_CHUNK * 12);
+                Span sc;                                        // this chunk's window of the span, in LDS coordinates
+                sc.line = sx.line + base;
+                sc.lo = sx.lo > base ? sx.lo - base : 0u;
+                sc.hi = sx.hi > base ? sx.hi - base : 0u;
+#pragma unroll
+                for (int i = 0; i < DENSE_CHUNK * 12 / 1024; ++i)
+                    span_sweep<4>(sc, i, lane, [&](unsigned o) { return *reinterpret_cast<const uint4 *>(lds + o); });
+                // the bytes behind the last whole line of this chunk open the next chunk's first line
+                unsigned carry = 0;
+                if ((unsigned)lane < hq) carry = stage_u[DENSE_CHUNK * 3 + lane];
+                wave_lds_sync();
+                if ((unsigned)lane < hq) stage_u[lane] = carry;
+                ++cc;
+            }
+        }
+        if (hq) {                                               // the last line's head
+            wave_lds_sync();
+            const unsigned base = (unsigned)(L_WSPAN * 12);
+            Span sc;
+            sc.line = sx.line + base;
+            sc.lo = 0u;
+            sc.hi = sx.hi > base ? sx.hi - base : 0u;
+            const unsigned o = (unsigned)lane * 16u;
+            if (o < 128u && o < sc.hi) put16<4>(sc, o, *reinterpret_cast<const uint4 *>(lds + o));
+        }
+    }
+#endif
+#ifndef DD_X_NONRM
+    // ---- normals: a shifted copy of 12 KiB (camera-frame normals pass through, scripts/test.py:220) ----
+    if constexpr (HAS_NORMAL) {
+        const Span sn = make_span(a.out_normal, row0, 12u, rows);
+        span_copy<4, L_WSPAN * 12 / 1024 + 1, u32x4_a4>(sn, reinterpret_cast<const unsigned char *>(a.normal + (vbase + qw) * 3), lane);
+    }
+#endif
+#ifndef DD_X_NORGB
+    // ---- colours: a shifted copy of 3 KiB, byte-granular ends ----
+    if (HAS_RGB && a.out_rgb != nullptr) {
+        const Span sc = make_span(a.out_rgb, row0, 3u, rows);
+        span_copy<1, L_WSPAN * 3 / 1024 + 1, u32x4_a1>(sc, a.rgb + (vbase + qw) * 3, lane);
+    }
+#endif
+#ifndef DD_X_NOIDX
+    // ---- indices: generated ----
+    if (a.out_pix) {
+        const Span sp = make_span(a.out_pix, row0, 4u, rows);
+#pragma unroll
+        for (int i = 0; i < L_WSPAN * 4 / 1024 + 1; ++i)
+            span_sweep<4>(sp, i, lane, [&](unsigned o) {
+                const unsigned e = qw + (unsigned)((int)(o - sp.lo) >> 2);   // element of the piece's first dword (negative in front of the run: not stored)
+                return make_uint4(e, e + 1u, e + 2u, e + 3u);
+            });
+    }
+    if (a.out_view) {
+        const Span sv = make_span(a.out_view, row0, 4u, rows);
+        const unsigned id = (unsigned)(a.view_base + (int)v);
+#pragma unroll
+        for (int i = 0; i < L_WSPAN * 4 / 1024 + 1; ++i)
+            span_sweep<4>(sv, i, lane, [&](unsigned) { return make_uint4(id, id, id, id); });
+    }
+#endif
+}
+
+// Touch one byte of every 128-byte line of the maps tile `tn` will read (depth, mask, confidence): issued by the whole
+// workgroup at the start of a tile's store phase for a tile about one tile-time ahead in ticket order, so that its loads
+// find their lines in the Infinity Cache instead of queueing behind the store stream in HBM.  Returns the XOR of the
+// bytes (the caller keeps it alive until the end of the tile; nothing ever depends on its value).
+__device__ __forceinline__ unsigned prefetch_tile(const KArgs &a, unsigned tn, unsigned lt, unsigned depth_esz, int tid) {
+    const unsigned v = tn / a.tiles_per_view, tv = tn - v * a.tiles_per_view;
+    const unsigned q0 = tv * lt;
+    const unsigned len = a.P - q0 < lt ? a.P - q0 : lt;               // pixels of the tile (>= 1)
+    const long long e0 = (long long)v * a.hw + q0;
+    const unsigned off = (unsigned)tid * 128u;
+    unsigned x = 0;
+    auto touch = [&](const void *base, unsigned esz) {
+        const unsigned bytes = len * esz;
+        if (off < bytes + 128u) {                                      // one probe per line + one for a line the run ends in
+            const unsigned o = off < bytes ? off : bytes - 1u;
+            x ^= reinterpret_cast<const unsigned char *>(base)[e0 * (long long)esz + o];
+        }
+    };
+    touch(a.depth, depth_esz);
+    if (a.mask) touch(a.mask, 1u);
+    if (a.flags & DD_VALID_CONF) touch(a.conf, a.conf_f16 ? 2u : 4u);
+    return x;
+}
+
 // NW = waves per workgroup: 4 (4096-pixel tiles) for the two-pass scatter; the single-pass variant uses 12
 // (12288-pixel tiles, 2 workgroups x 12 waves per CU) so that one look-back is amortised over three times the work.
 constexpr int REFINE_MAX_KNOTS = 512;
@@ -636,16 +916,15 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+#ifdef DD_X_STAMPS
+    const unsigned long long entry_clk = __builtin_amdgcn_s_memtime(), entry_rt = __builtin_amdgcn_s_memrealtime();
+#endif
     unsigned t;
     if constexpr (SINGLE_PASS) {
-        if (a.sp_static) {
-            t = blockIdx.x;
-        } else {
-            if (tid == 0) s_ticket = atomicAdd(&a.hdr->ticket, 1u);
-            __syncthreads();
-            t = __builtin_amdgcn_readfirstlane(s_ticket);
-            if (t >= a.num_tiles) return;
-        }
+        if (tid == 0) s_ticket = atomicAdd(&a.hdr->ticket, 1u);
+        __syncthreads();
+        t = __builtin_amdgcn_readfirstlane(s_ticket);
+        if (t >= a.num_tiles) return;
     } else {
 #if DD_XCD_SWIZZLE
         {   // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous range of tiles
@@ -666,6 +945,17 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
 
     uint4 d[CH];
     unsigned bits[CH];
+    if (wave == 0) STAMP(0);
+    if (wave == 5) STAMP(8);
+#ifdef DD_X_STAMPS
+    if (wave == 0 && lane == 0 && a.refined_out) {
+        unsigned long long *st = reinterpret_cast<unsigned long long *>(a.refined_out) + (size_t)t * 16;
+        st[5] = entry_clk; st[6] = entry_rt;
+    }
+#define STAMP_END() do { if (wave == 0 && lane == 0 && a.refined_out) reinterpret_cast<unsigned long long *>(a.refined_out)[(size_t)t * 16 + 7] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAMP_END() do { } while (0)
+#endif
     if constexpr (REFINE) {
         static_assert(sizeof(DepthT) == 4 && SINGLE_PASS, "the fused refine stage runs in the float32 single-pass instantiation");
         // ---- src/depthdensifier/depth_refiner.py:180-205 on this tile, from the RAW depth (scripts/test.py:179-194 fused in) ----
@@ -742,7 +1032,10 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
         m += tot[ch];
     }
     if (lane == 0) s_tot[wave] = (unsigned)m;
+    if (wave == 0) STAMP(1);
+    if (wave == 5) STAMP(9);
     __syncthreads();   // #1
+    if (wave == 0) STAMP(2);
 
     unsigned wbase = 0, n = 0;
 #pragma unroll
@@ -753,6 +1046,61 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
     if constexpr (SINGLE_PASS) {                       // publish the aggregate as early as possible
         if (tid == 0) st_state(&a.tile_state[t], ST_AGG | (unsigned long long)n);
     }
+    // Whoever draws ticket t + prefetch_ahead (about one tile-time from now: that many workgroups are resident) finds the
+    // lines of its depth / mask / confidence maps in the Infinity Cache: this workgroup touches them at the start of its
+    // store phase (prefetch_tile).  The shorter a tile's way from its ticket to its published count, the shorter every
+    // later tile's look-back (profiles/r04_tile_phase_stamps.txt).
+    unsigned pf = 0;
+    auto prefetch_next = [&]() {
+        if constexpr (SINGLE_PASS) {
+            const unsigned tn = t + a.prefetch_ahead;
+            if (a.prefetch_ahead && tn < a.num_tiles) pf = prefetch_tile(a, tn, (unsigned)LT, REFINE ? (a.raw_f16 ? 2u : 4u) : (unsigned)sizeof(DepthT), tid);
+        }
+    };
+    auto retire_prefetch = [&]() {                     // never true: keeps the touched bytes' loads in the program
+        if (pf == 0x5bd1e995u && a.capacity == -1) a.hdr->pad1[0] = pf;
+    };
+    // wave 0: the tile's first output row by ticket order (decoupled look-back), the view offsets it defines
+    auto look_back = [&]() {
+        long long e = lookback13(a.tile_state, t, n, *a.cursor, lane, &a.hdr->error, a.spin_limit);
+        if (a.spin_limit == 0u && (t & 7u) == 1u) {      // fault injection (tuning bit 64): what a give-up leaves behind --
+            e += 977;                                    // a wrong first row for this tile and the error word set
+            if (lane == 0) atomicExch(&a.hdr->error, 1);
+        }
+        if (lane == 0) {
+            s_excl = e;
+            if (tv == 0) a.view_offsets[v] = e;
+            if (t == a.num_tiles - 1) a.view_offsets[a.V] = e + n;
+        }
+    };
+#if DD_DENSE
+    if constexpr (!REFINE) {
+        if (n == (unsigned)LT && a.dense_ok) {         // workgroup-uniform: every pixel of the tile survives -> no list (dense_wave)
+            static_assert(DENSE_LDS_PER_WAVE * NW <= LT * 6, "the dense path's staging fits the list's LDS");
+            long long e0;
+            if constexpr (SINGLE_PASS) {
+                if (wave == 0) { look_back(); STAMP(3); }
+                __syncthreads();
+                if (wave == 5) STAMP(10);
+                e0 = uniform64(s_excl);
+                prefetch_next();
+            } else {
+                e0 = uniform64(a.view_offsets[v] + (long long)a.tile_off[t]);
+            }
+            const float *cp = reinterpret_cast<const float *>(a.params + v);
+            CamBlock cam;
+            cam.m00 = cp[0]; cam.m01 = cp[1]; cam.m02 = cp[2]; cam.m10 = cp[3]; cam.m11 = cp[4]; cam.m12 = cp[5];
+            cam.m20 = cp[6]; cam.m21 = cp[7]; cam.m22 = cp[8]; cam.c0 = cp[9]; cam.c1 = cp[10]; cam.c2 = cp[11];
+            dense_wave<DepthT, HAS_NORMAL, HAS_RGB>(a, d, s_raw + wave * DENSE_LDS_PER_WAVE, cam, v, vbase, q0, qw,
+                                                    e0 + (long long)wave * L_WSPAN, lane);
+            retire_prefetch();
+            if (wave == 0) STAMP(4);
+            if (wave == 5) STAMP(11);
+            STAMP_END();
+            return;
+        }
+    }
+#endif
     {   // tile-local list of surviving pixels, in output order
         int cum = (int)wbase;
 #pragma unroll
@@ -816,34 +1164,54 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
         p.y = fmaf(dd, fmaf(m10, fx, fmaf(m11, fy, m12)), c1);
         p.z = fmaf(dd, fmaf(m20, fx, fmaf(m21, fy, m22)), c2);
         p.q = q;
-        if constexpr (HAS_NORMAL) p.nr = *reinterpret_cast<const f32x3 *>(nsrc + (size_t)q * 3);
+        // scalar base + 32-bit byte offset (a view has < 2^28 pixels on this path): no 64-bit address arithmetic per lane
+        if constexpr (HAS_NORMAL) p.nr = *reinterpret_cast<const f32x3 *>(reinterpret_cast<const unsigned char *>(nsrc) + q * 12u);
         if constexpr (HAS_RGB) {
             // the 3 colour bytes with ONE unaligned dword load that stays inside the view's image:
             // bytes [3q-1, 3q+3) for q > 0 (colour in the upper 3 bytes), [0, 4) for q == 0
-            p.rgbw = *reinterpret_cast<const u32_unaligned *>(csrc + (size_t)q * 3 - (q ? 1 : 0));
+            p.rgbw = *reinterpret_cast<const u32_unaligned *>(csrc + (q * 3u - (q ? 1u : 0u)));
         }
+    };
+    // the tile's rows start at scalar addresses (excl is workgroup-uniform); a lane adds a 32-bit byte offset
+    unsigned char *xb = nullptr, *nb = nullptr, *cb = nullptr, *kb = nullptr, *ib = nullptr, *vb = nullptr;
+    unsigned cap_rows = 0;            // rows of this tile the capacity leaves room for
+    auto set_row_bases = [&]() {
+#ifdef DD_X_SINK
+        xb = reinterpret_cast<unsigned char *>(a.out_xyz) + ((excl * 12) & 0xFFFFCll);
+        nb = reinterpret_cast<unsigned char *>(a.out_normal) + ((excl * 12) & 0xFFFFCll);
+        cb = reinterpret_cast<unsigned char *>(a.out_rgb) + ((excl * 3) & 0xFFFFFll);
+#else
+        xb = reinterpret_cast<unsigned char *>(a.out_xyz) + excl * 12;
+        nb = reinterpret_cast<unsigned char *>(a.out_normal) + excl * 12;
+        cb = reinterpret_cast<unsigned char *>(a.out_rgb) + excl * 3;
+#endif
+        kb = reinterpret_cast<unsigned char *>(a.out_packed) + excl * 16;
+        ib = reinterpret_cast<unsigned char *>(a.out_pix) + excl * 4;
+        vb = reinterpret_cast<unsigned char *>(a.out_view) + excl * 4;
+        const long long room = a.capacity - excl;
+        cap_rows = room <= 0 ? 0u : room < (long long)LT ? (unsigned)room : (unsigned)LT;
     };
     auto emit = [&](const Pt &p) {
         const int j = p.j;
-        const long long slot = excl + j;
-        const bool act = (j >= 0) && (slot < a.capacity);
+        const unsigned uj = (unsigned)j;
+        const bool act = (j >= 0) && (uj < cap_rows);
         if (act) {
             f32x3 o; o.x = p.x; o.y = p.y; o.z = p.z;
             if (a.out_xyz) {
 #if DD_NT_STORE
-                __builtin_nontemporal_store(o, reinterpret_cast<f32x3 *>(a.out_xyz + slot * 3));
+                __builtin_nontemporal_store(o, reinterpret_cast<f32x3 *>(xb + uj * 12u));
 #else
-                *reinterpret_cast<f32x3 *>(a.out_xyz + slot * 3) = o;
+                *reinterpret_cast<f32x3 *>(xb + uj * 12u) = o;
 #endif
             }
             if (a.out_packed) {     // one aligned 16-byte store per point: a wave writes 1 KiB of whole lines
                 unsigned c = 0xff000000u;
                 if constexpr (HAS_RGB) c |= p.q ? (p.rgbw >> 8) : (p.rgbw & 0xffffffu);
                 uint4 rec; rec.x = __float_as_uint(p.x); rec.y = __float_as_uint(p.y); rec.z = __float_as_uint(p.z); rec.w = c;
-                *reinterpret_cast<uint4 *>(a.out_packed + slot * 4) = rec;
+                *reinterpret_cast<uint4 *>(kb + uj * 16u) = rec;
             }
-            if (a.out_pix) a.out_pix[slot] = (int)p.q;
-            if (a.out_view) a.out_view[slot] = a.view_base + (int)v;
+            if (a.out_pix) *reinterpret_cast<int *>(ib + uj * 4u) = (int)p.q;
+            if (a.out_view) *reinterpret_cast<int *>(vb + uj * 4u) = a.view_base + (int)v;
         }
         if constexpr (HAS_NORMAL) {
             f32x3 nv = p.nr;
@@ -855,9 +1223,9 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
                 nv.x = w0 * inv; nv.y = w1 * inv; nv.z = w2 * inv;
             }
 #if DD_NT_STORE
-            if (act) __builtin_nontemporal_store(nv, reinterpret_cast<f32x3 *>(a.out_normal + slot * 3));
+            if (act) __builtin_nontemporal_store(nv, reinterpret_cast<f32x3 *>(nb + uj * 12u));
 #else
-            if (act) *reinterpret_cast<f32x3 *>(a.out_normal + slot * 3) = nv;
+            if (act) *reinterpret_cast<f32x3 *>(nb + uj * 12u) = nv;
 #endif
         }
         if (HAS_RGB && a.out_rgb != nullptr) {
@@ -871,7 +1239,7 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
             const int jq = __builtin_amdgcn_update_dpp(0, j, 0x00, 0xF, 0xF, false);               // quad_perm [0,0,0,0]
             const unsigned long long am = __ballot(act && j == jq + (lane & 3));
             const unsigned quad = (unsigned)(am >> (lane & ~3)) & 0xFu;
-            unsigned char *dst = a.out_rgb + slot * 3;
+            unsigned char *dst = cb + uj * 3u;
             if (quad == 0xFu) {
                 if ((lane & 3) == 0) {
                     u32x3 w;
@@ -884,6 +1252,7 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
                 dst[0] = (unsigned char)c0w; dst[1] = (unsigned char)(c0w >> 8); dst[2] = (unsigned char)(c0w >> 16);
             }
         }
+        cap_stores();
     };
 
     constexpr int NI = LT / BT;       // 16 point slots per lane at most
@@ -891,31 +1260,27 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
     if constexpr (SINGLE_PASS) {
         // Wave 0 looks back while the other waves already issue their first gathers (the list is complete
         // after this barrier; neither the list nor the gathers need the tile's first row).
+        if (wave == 5) STAMP(12);
         __syncthreads();
         if (wave == 0) {
-            long long e = lookback13(a.tile_state, t, n, *a.cursor, lane, &a.hdr->error, a.spin_limit);
-            if (a.spin_limit == 0u && (t & 7u) == 1u) {      // fault injection (tuning bit 64): what a give-up leaves behind --
-                e += 977;                                    // a wrong first row for this tile and the error word set
-                if (lane == 0) atomicExch(&a.hdr->error, 1);
-            }
-            if (lane == 0) {
-                s_excl = e;
-                if (tv == 0) a.view_offsets[v] = e;
-                if (t == a.num_tiles - 1) a.view_offsets[a.V] = e + n;
-            }
+            look_back();
+            STAMP(3);
         } else if (n != 0) {
             prep(0, pa);
         }
         __syncthreads();
-        excl = s_excl;
-        if (n == 0) return;
+        if (wave == 5) STAMP(10);
+        excl = uniform64(s_excl);
+        prefetch_next();
+        if (n == 0) { retire_prefetch(); return; }
         if (wave == 0) prep(0, pa);
     } else {
         __syncthreads();
-        excl = a.view_offsets[v] + (long long)a.tile_off[t];
+        excl = uniform64(a.view_offsets[v] + (long long)a.tile_off[t]);
         if (n == 0) return;
         prep(0, pa);
     }
+    set_row_bases();
     if (a.align_runs) hrot = (int)((0ll - excl) & 31ll);
 #pragma unroll
     for (int i = 0; i < NI; i += 2) {
@@ -926,6 +1291,10 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
         emit(pb);
         if ((i + 2) * BT >= (int)n) break;
     }
+    retire_prefetch();
+    if (wave == 0) STAMP(4);
+    if (wave == 5) STAMP(11);
+    STAMP_END();
 }
 
 // ---- pass 1 of the two-pass mode (and dd_count_valid on stride-1 maps) ----------------------------
@@ -1137,6 +1506,9 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
 
     p.f16 = (b->depth_dtype == DD_F16);
     p.refine = (b->flags & DD_REFINE) != 0;
+#ifdef DD_X_STAMPS
+    a.refined_out = b->refined_out;
+#endif
     if (p.refine) {
         // the fused refine stage: float32 single-pass lean kernel, raw depth read element by element
         if (b->stride != 1) return fail(DD_ERR_UNSUPPORTED, "DD_REFINE needs stride 1 (at a coarser density refine with dd_refine_apply first)");
@@ -1152,15 +1524,20 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
     const int vec = p.f16 ? 8 : 4;
     // lean kernels: stride 1, any view size of at least one vector; pointers need element alignment only (views of
     // H*W % vec != 0 pixels start off the 16-byte grid anyway; the wide loads are element-aligned)
-    bool aligned = (b->stride == 1) && (hw >= vec) && (p.refine || (uintptr_t)b->depth % (p.f16 ? 2 : 4) == 0);
+    // (a lane addresses a view's attributes with 32-bit byte offsets: views of 2^28 pixels or more take the generic path)
+    bool aligned = (b->stride == 1) && (hw >= vec) && (hw < (1ll << 28)) && (p.refine || (uintptr_t)b->depth % (p.f16 ? 2 : 4) == 0);
     if (b->flags & DD_VALID_CONF) aligned = aligned && ((uintptr_t)b->conf % (b->conf_dtype == DD_F16 ? 2 : 4) == 0);
     if (b->tuning & TUNE_FORCE_GENERIC) aligned = false;
     p.lean = aligned;
     // fused call: single-pass on the lean path (measured 8-23 % faster than plan + scatter on MI355X with
     // 12288-pixel tiles and a 16-granule look-back window), two-pass on the generic path
     p.single = (b->tuning & TUNE_SINGLE_PASS) != 0 || (p.lean && !(b->tuning & TUNE_TWO_PASS));
-    a.sp_static = (b->tuning & 16u) != 0;   // diagnostic only: relies on in-order dispatch
+    a.prefetch_ahead = 0;                   // set by the single-pass launch (resident workgroups) ...
+    a.no_prefetch = (b->tuning & 16u) != 0; // ... unless tuning bit 16 is set (A/B of the look-ahead)
     a.align_runs = (b->tuning & 32u) == 0;  // tuning bit 32: rows in list order (A/B of the line-aligned sweeps)
+    // tuning bit 128: dense tiles go through the list like any other tile (A/B and bit-equality tests of the dense path);
+    // the dense path steps x by 64 per lane (width >= 64) and derives rows in float32 (width < 2^23)
+    a.dense_ok = (b->tuning & 128u) == 0 && b->width >= 64 && b->width < (1 << 23);
     a.spin_limit = (b->tuning & 64u) ? 0u : SPIN_LIMIT;   // tuning bit 64: fault injection -- a tile that would have to wait for a
                                                           // predecessor gives up at once, and every eighth tile behaves as if it had:
                                                           // wrong rows, the workspace's error word set (tests of the caller's recovery)
@@ -1198,15 +1575,58 @@ int bind_output(KArgs &a, const DDViewBatch *batch, const DDCloudOut *out) {
     a.out_xyz = out->xyz; a.out_normal = out->normal; a.out_rgb = out->rgb;
     a.out_pix = out->pixel_index; a.out_view = out->view_index; a.capacity = out->capacity;
     a.out_packed = out->xyz_rgba;
+    if (a.out_normal && (a.flags & DD_ROTATE_NORMALS)) a.dense_ok = 0;   // rotated normals are computed per point: list path
+    if (a.out_packed) a.dense_ok = 0;                                    // the 16-byte record is one aligned store per point already: list path
     return DD_OK;
+}
+
+// How many workgroups of a kernel the device holds at once (occupancy query x CUs, asked once per kernel and device): the
+// distance in tiles at which the single-pass kernel touches its successors' inputs (KArgs::prefetch_ahead).  0 = no answer.
+int device_cus() {
+    static std::mutex mu;
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = -1;
+        cus[dev] = n;
+    }
+    return cus[dev] > 0 ? cus[dev] : 0;
+}
+
+template <typename Kernel>
+unsigned resident_workgroups(Kernel kernel, int block) {
+    static std::mutex mu;
+    static int per_cu[64] = {0};                // per instantiation (function template) and device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int nb;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (per_cu[dev] == 0) {
+            int q = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kernel, block, 0) != hipSuccess || q <= 0) q = -1;
+            per_cu[dev] = q;
+        }
+        nb = per_cu[dev];
+    }
+    const int cus = device_cus();
+    return (nb > 0 && cus > 0) ? (unsigned)nb * (unsigned)cus : 0u;
+}
+
+template <typename Kernel>
+void launch_tiles(Kernel k, int block, bool single_pass, KArgs a, hipStream_t s) {
+    if (single_pass && !a.no_prefetch) a.prefetch_ahead = resident_workgroups(k, block);
+    hipLaunchKernelGGL(k, dim3(a.num_tiles), dim3(block), 0, s, a);
 }
 
 template <typename DepthT, bool SP, bool HM, bool HN>
 void launch_lean3(const KArgs &a, hipStream_t s) {
     constexpr int NW = SP ? SP_WAVES : WAVES;
-    const dim3 grid(a.num_tiles), block(64 * NW);
-    if (a.rgb && (a.out_rgb || a.out_packed)) hipLaunchKernelGGL((compact_lean<DepthT, HM, SP, HN, true, NW>), grid, block, 0, s, a);   // colours gathered
-    else hipLaunchKernelGGL((compact_lean<DepthT, HM, SP, HN, false, NW>), grid, block, 0, s, a);
+    if (a.rgb && (a.out_rgb || a.out_packed)) launch_tiles(compact_lean<DepthT, HM, SP, HN, true, NW>, 64 * NW, SP, a, s);   // colours gathered
+    else launch_tiles(compact_lean<DepthT, HM, SP, HN, false, NW>, 64 * NW, SP, a, s);
 }
 
 template <typename DepthT, bool SP>
@@ -1219,12 +1639,12 @@ void launch_lean(const KArgs &a, hipStream_t s) {
 }
 
 void launch_refine(const KArgs &a, hipStream_t s) {
-    const dim3 grid(a.num_tiles), block(64 * SP_WAVES);
     const bool hn = a.out_normal != nullptr, hc = a.rgb && (a.out_rgb || a.out_packed);
-    if (hn && hc) hipLaunchKernelGGL((compact_lean<float, false, true, true, true, SP_WAVES, true>), grid, block, 0, s, a);
-    else if (hn) hipLaunchKernelGGL((compact_lean<float, false, true, true, false, SP_WAVES, true>), grid, block, 0, s, a);
-    else if (hc) hipLaunchKernelGGL((compact_lean<float, false, true, false, true, SP_WAVES, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((compact_lean<float, false, true, false, false, SP_WAVES, true>), grid, block, 0, s, a);
+    constexpr int B = 64 * SP_WAVES;
+    if (hn && hc) launch_tiles(compact_lean<float, false, true, true, true, SP_WAVES, true>, B, true, a, s);
+    else if (hn) launch_tiles(compact_lean<float, false, true, true, false, SP_WAVES, true>, B, true, a, s);
+    else if (hc) launch_tiles(compact_lean<float, false, true, false, true, SP_WAVES, true>, B, true, a, s);
+    else launch_tiles(compact_lean<float, false, true, false, false, SP_WAVES, true>, B, true, a, s);
 }
 
 template <bool SP>

@@ -1,0 +1,164 @@
+"""The list-free path for dense tiles (``dense_wave`` in ``csrc/ddcore.hip``): tiles whose pixels all survive are written
+as line-aligned 16-byte pieces from an LDS staging area (xyz) and as shifted copies (normals, colours), per wave.  Its
+rows must be the rows of the list path (``tuning`` bit 128 switches the dense path off) bit for bit, for every phase
+of the first row against the 128-byte lines of every output array, with the capacity cutting a dense tile anywhere, in
+the single-pass and the two-pass kernels, for float32 and float16 depth -- and equal to the oracle
+(``scripts/test.py:203-233`` restated)."""
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import assert_cloud, scene_radius
+
+pytestmark = pytest.mark.gpu
+
+NO_DENSE = 128
+
+
+@pytest.fixture(scope="module")
+def dd():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import depthdensifier_amd
+    return depthdensifier_amd
+
+
+def _ring(V):
+    from test_gpu_parity import _ring_poses
+    return _ring_poses(V)
+
+
+def _scene(V, H, W, dtype, seed, mask_kind):
+    """Depth without holes; ``mask_kind``: None (every tile dense), "blob" (a rectangle cut out of every view: dense,
+    partial and empty tiles side by side), "speck" (one pixel missing per view: one partial tile among dense ones)."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    depth = torch.empty((V, H, W), device="cuda").uniform_(0.5, 8.0, generator=g).to(dtype)
+    normal = torch.nn.functional.normalize(torch.randn((V, H, W, 3), device="cuda", generator=g), dim=-1)
+    rgb = torch.randint(0, 256, (V, H, W, 3), device="cuda", generator=g, dtype=torch.uint8)
+    mask = None
+    if mask_kind == "blob":
+        mask = torch.ones((V, H, W), dtype=torch.bool, device="cuda")
+        for v in range(V):
+            y0, x0 = (17 * v + 5) % (H // 2), (29 * v + 3) % (W // 2)
+            mask[v, y0:y0 + H // 3, x0:x0 + W // 2] = False
+            mask[v, H - 1 - v, :] = False
+    elif mask_kind == "speck":
+        mask = torch.ones((V, H, W), dtype=torch.bool, device="cuda")
+        for v in range(V):
+            mask[v, (H // 2 + v) % H, (W // 3 + 7 * v) % W] = False
+    return depth, mask, normal, rgb
+
+
+FIELDS = ("points", "normals", "colors", "pixel_index", "view_index")
+
+
+def _build(dd, batch, cap, start, fields, fill=True):
+    """A cloud of capacity ``cap`` in buffers 64 rows longer (rows behind the capacity must stay untouched)."""
+    import torch
+    bufs = {}
+    for name in ("points", "normals", "colors", "pixel_index", "view_index", "packed"):
+        bufs[name] = None
+        if name in fields:
+            tail, dt = dd.CloudBuilder.FIELDS[name]
+            bufs[name] = torch.empty((cap + 64,) + tail, dtype=dt, device="cuda")
+            if fill:
+                bufs[name].fill_(201 if name == "colors" else -7)
+    b = dd.CloudBuilder(cap, normals="normals" in fields, colors="colors" in fields, pixel_index="pixel_index" in fields,
+                        view_index="view_index" in fields, start=start, buffers=bufs)
+    b.append(batch)
+    torch.cuda.synchronize()
+    return b
+
+
+def _arrays(b):
+    return dict(points=b.xyz, normals=b.normal, colors=b.rgb, pixel_index=b.pix, view_index=b.view)
+
+
+@pytest.mark.parametrize("dtype_name", ("float32", "float16"))
+@pytest.mark.parametrize("mask_kind", (None, "blob", "speck"))
+@pytest.mark.parametrize("tuning", (0, 4))
+def test_dense_path_equals_list_path(dd, dtype_name, mask_kind, tuning):
+    import torch
+    dtype = getattr(torch, dtype_name)
+    V, H, W = 3, 150, 331                       # 49 650 pixels per view: 4 tiles of 12 288 + a ragged one (two-pass: 12 + 1)
+    depth, mask, normal, rgb = _scene(V, H, W, dtype, 11, mask_kind)
+    params = np.tile([0.8 * W, 0.8 * W, W / 2, H / 2], (V, 1))
+    E = _ring(V)
+    mk = lambda tun: dd.ViewBatch(depth, params, E, mask=mask, normal=normal, rgb=rgb, tuning=tun)
+    dense, plain = mk(tuning), mk(tuning | NO_DENSE)
+    n = V * H * W if mask is None else int(mask.sum())
+    ref = _build(dd, plain, n, None, FIELDS, fill=False)
+    assert int(ref.cursor.item()) == n
+    want = _arrays(ref)
+    for start in list(range(0, 34)) + [127, 1000003]:
+        for cut in (0, 1, 5000):
+            cap = start + n - cut
+            b = _build(dd, dense, cap, start, FIELDS)
+            assert int(b.cursor.item()) == start + n
+            kept = n - cut
+            for name, t in _arrays(b).items():
+                w = want[name][:kept]
+                assert torch.equal(t[start:start + kept].view(torch.uint8), w.view(torch.uint8)), (start, cut, name)
+                assert bool((t[:start] == (201 if name == "colors" else -7)).all()), (start, cut, name, "rows in front of the cloud")
+                assert bool((t[start + kept:] == (201 if name == "colors" else -7)).all()), (start, cut, name, "rows behind the capacity")
+
+
+@pytest.mark.parametrize("fields", (("points",), ("points", "normals"), ("points", "colors"), ("points", "pixel_index"),
+                                    ("points", "colors", "view_index")))
+def test_dense_path_field_subsets_and_odd_base_pointers(dd, fields):
+    """Every subset runs its own instantiation; sub-tensor views of larger buffers shift each array's base pointer off
+    the 128-byte grid by a different amount."""
+    import torch
+    V, H, W = 2, 128, 400
+    depth, mask, normal, rgb = _scene(V, H, W, torch.float32, 5, "speck")
+    params = np.tile([0.8 * W, 0.8 * W, W / 2, H / 2], (V, 1))
+    E = _ring(V)
+    n = int(mask.sum())
+    outs = {}
+    for tun in (0, NO_DENSE):
+        batch = dd.ViewBatch(depth, params, E, mask=mask, normal=normal, rgb=rgb, tuning=tun)
+        pad = {"points": 1, "normals": 3, "colors": 5, "pixel_index": 7, "view_index": 9}      # rows in front: 12 / 36 / 15 / 28 / 36 bytes
+        bufs = {}
+        for name in fields:
+            tail, dt = dd.CloudBuilder.FIELDS[name]
+            big = torch.full((n + 16,) + tail, 3, dtype=dt, device="cuda")
+            bufs[name] = big[pad[name]:pad[name] + n]
+        for name in ("points", "normals", "colors", "pixel_index", "view_index", "packed"):
+            bufs.setdefault(name, None)
+        b = dd.CloudBuilder(n, normals="normals" in fields, colors="colors" in fields, pixel_index="pixel_index" in fields,
+                            view_index="view_index" in fields, buffers=bufs)
+        b.append(batch)
+        torch.cuda.synchronize()
+        outs[tun] = {k: v.clone() for k, v in bufs.items() if v is not None}
+    for name in fields:
+        assert torch.equal(outs[0][name].view(torch.uint8), outs[NO_DENSE][name].view(torch.uint8)), name
+
+
+@pytest.mark.parametrize("dtype_name", ("float32", "float16"))
+def test_dense_tiles_against_the_oracle(dd, dtype_name):
+    from oracle import densify_oracle as orc
+    rng = np.random.default_rng(3)
+    V, H, W = 2, 96, 640                        # 61 440 pixels per view = 5 dense tiles exactly
+    depth = rng.uniform(0.5, 6.0, (V, H, W)).astype(dtype_name)
+    normal = rng.standard_normal((V, H, W, 3)).astype(np.float32)
+    rgb = rng.integers(0, 256, (V, H, W, 3), dtype=np.uint8)
+    params = np.stack([[500.0, 510.0, 320.0, 48.0], [480.0, 470.0, 300.5, 50.25]])
+    E = _ring(V)
+    for tuning in (0, 4):
+        cloud = dd.unproject_views(depth, params, E, normal=normal, rgb=rgb, view_index=True, tuning=tuning, capacity="max")
+        ref = orc.densify_scene_script(depth, params, E, normal=normal, rgb=rgb)
+        assert_cloud(cloud, ref, scene_radius(E, depth))
+
+
+def test_narrow_views_take_the_list_path(dd):
+    """width < 64: the dense path's x += 64 stepping does not apply; the result is the oracle's all the same."""
+    from oracle import densify_oracle as orc
+    rng = np.random.default_rng(4)
+    V, H, W = 1, 1024, 48
+    depth = rng.uniform(0.5, 6.0, (V, H, W)).astype(np.float32)
+    params = np.array([[40.0, 41.0, 24.0, 512.0]])
+    E = _ring(V)
+    cloud = dd.unproject_views(depth, params, E, view_index=True)
+    assert_cloud(cloud, orc.densify_scene_script(depth, params, E), scene_radius(E, depth))
