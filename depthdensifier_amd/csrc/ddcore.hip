@@ -27,8 +27,6 @@
 #include <stdio.h>
 #include <string.h>
 
-#include <mutex>
-
 #include "ddcore.h"
 #include "ddrefine_math.h"
 
@@ -90,8 +88,6 @@ struct KArgs {
     unsigned flags;
     int conf_f16;
     int view_base;
-    unsigned prefetch_ahead;      // single-pass lean kernel: tile t touches the input lines of tile t + prefetch_ahead (0 = off; see prefetch_tile)
-    int no_prefetch;              // tuning bit 16: keep prefetch_ahead at 0 (A/B)
     int align_runs;               // lean kernels: shift the sweeps so that wave runs start on 128-byte lines (default on)
     unsigned spin_limit;          // look-back polls before a tile gives up (SPIN_LIMIT; 0 with the fault-injection tuning bit 64)
     int dense_ok;                 // lean kernels: tiles whose pixels all survive take the list-free path (dense_wave)
@@ -869,30 +865,6 @@ __device__ __forceinline__ void dense_wave(const KArgs &a, const uint4 (&d)[L_PX
 #endif
 }
 
-// Touch one byte of every 128-byte line of the maps tile `tn` will read (depth, mask, confidence): issued by the whole
-// workgroup at the start of a tile's store phase for a tile about one tile-time ahead in ticket order, so that its loads
-// find their lines in the Infinity Cache instead of queueing behind the store stream in HBM.  Returns the XOR of the
-// bytes (the caller keeps it alive until the end of the tile; nothing ever depends on its value).
-__device__ __forceinline__ unsigned prefetch_tile(const KArgs &a, unsigned tn, unsigned lt, unsigned depth_esz, int tid) {
-    const unsigned v = tn / a.tiles_per_view, tv = tn - v * a.tiles_per_view;
-    const unsigned q0 = tv * lt;
-    const unsigned len = a.P - q0 < lt ? a.P - q0 : lt;               // pixels of the tile (>= 1)
-    const long long e0 = (long long)v * a.hw + q0;
-    const unsigned off = (unsigned)tid * 128u;
-    unsigned x = 0;
-    auto touch = [&](const void *base, unsigned esz) {
-        const unsigned bytes = len * esz;
-        if (off < bytes + 128u) {                                      // one probe per line + one for a line the run ends in
-            const unsigned o = off < bytes ? off : bytes - 1u;
-            x ^= reinterpret_cast<const unsigned char *>(base)[e0 * (long long)esz + o];
-        }
-    };
-    touch(a.depth, depth_esz);
-    if (a.mask) touch(a.mask, 1u);
-    if (a.flags & DD_VALID_CONF) touch(a.conf, a.conf_f16 ? 2u : 4u);
-    return x;
-}
-
 // NW = waves per workgroup: 4 (4096-pixel tiles) for the two-pass scatter; the single-pass variant uses 12
 // (12288-pixel tiles, 2 workgroups x 12 waves per CU) so that one look-back is amortised over three times the work.
 constexpr int REFINE_MAX_KNOTS = 512;
@@ -1046,20 +1018,6 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
     if constexpr (SINGLE_PASS) {                       // publish the aggregate as early as possible
         if (tid == 0) st_state(&a.tile_state[t], ST_AGG | (unsigned long long)n);
     }
-    // Whoever draws ticket t + prefetch_ahead (about one tile-time from now: that many workgroups are resident) finds the
-    // lines of its depth / mask / confidence maps in the Infinity Cache: this workgroup touches them at the start of its
-    // store phase (prefetch_tile).  The shorter a tile's way from its ticket to its published count, the shorter every
-    // later tile's look-back (profiles/r04_tile_phase_stamps.txt).
-    unsigned pf = 0;
-    auto prefetch_next = [&]() {
-        if constexpr (SINGLE_PASS) {
-            const unsigned tn = t + a.prefetch_ahead;
-            if (a.prefetch_ahead && tn < a.num_tiles) pf = prefetch_tile(a, tn, (unsigned)LT, REFINE ? (a.raw_f16 ? 2u : 4u) : (unsigned)sizeof(DepthT), tid);
-        }
-    };
-    auto retire_prefetch = [&]() {                     // never true: keeps the touched bytes' loads in the program
-        if (pf == 0x5bd1e995u && a.capacity == -1) a.hdr->pad1[0] = pf;
-    };
     // wave 0: the tile's first output row by ticket order (decoupled look-back), the view offsets it defines
     auto look_back = [&]() {
         long long e = lookback13(a.tile_state, t, n, *a.cursor, lane, &a.hdr->error, a.spin_limit);
@@ -1083,7 +1041,6 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
                 __syncthreads();
                 if (wave == 5) STAMP(10);
                 e0 = uniform64(s_excl);
-                prefetch_next();
             } else {
                 e0 = uniform64(a.view_offsets[v] + (long long)a.tile_off[t]);
             }
@@ -1093,7 +1050,6 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
             cam.m20 = cp[6]; cam.m21 = cp[7]; cam.m22 = cp[8]; cam.c0 = cp[9]; cam.c1 = cp[10]; cam.c2 = cp[11];
             dense_wave<DepthT, HAS_NORMAL, HAS_RGB>(a, d, s_raw + wave * DENSE_LDS_PER_WAVE, cam, v, vbase, q0, qw,
                                                     e0 + (long long)wave * L_WSPAN, lane);
-            retire_prefetch();
             if (wave == 0) STAMP(4);
             if (wave == 5) STAMP(11);
             STAMP_END();
@@ -1271,8 +1227,7 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
         __syncthreads();
         if (wave == 5) STAMP(10);
         excl = uniform64(s_excl);
-        prefetch_next();
-        if (n == 0) { retire_prefetch(); return; }
+        if (n == 0) return;
         if (wave == 0) prep(0, pa);
     } else {
         __syncthreads();
@@ -1291,7 +1246,6 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
         emit(pb);
         if ((i + 2) * BT >= (int)n) break;
     }
-    retire_prefetch();
     if (wave == 0) STAMP(4);
     if (wave == 5) STAMP(11);
     STAMP_END();
@@ -1532,12 +1486,11 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
     // fused call: single-pass on the lean path (measured 8-23 % faster than plan + scatter on MI355X with
     // 12288-pixel tiles and a 16-granule look-back window), two-pass on the generic path
     p.single = (b->tuning & TUNE_SINGLE_PASS) != 0 || (p.lean && !(b->tuning & TUNE_TWO_PASS));
-    a.prefetch_ahead = 0;                   // set by the single-pass launch (resident workgroups) ...
-    a.no_prefetch = (b->tuning & 16u) != 0; // ... unless tuning bit 16 is set (A/B of the look-ahead)
     a.align_runs = (b->tuning & 32u) == 0;  // tuning bit 32: rows in list order (A/B of the line-aligned sweeps)
-    // tuning bit 128: dense tiles go through the list like any other tile (A/B and bit-equality tests of the dense path);
-    // the dense path steps x by 64 per lane (width >= 64) and derives rows in float32 (width < 2^23)
-    a.dense_ok = (b->tuning & 128u) == 0 && b->width >= 64 && b->width < (1 << 23);
+    // tuning bit 128: tiles whose pixels all survive take the list-free path (dense_wave).  Off by default: measured in the
+    // real kernel it is the same rows with a third of the instructions, and 0-5 % SLOWER.
+    // The dense path steps x by 64 per lane (width >= 64) and derives rows in float32 (width < 2^23).
+    a.dense_ok = (b->tuning & 128u) != 0 && b->width >= 64 && b->width < (1 << 23);
     a.spin_limit = (b->tuning & 64u) ? 0u : SPIN_LIMIT;   // tuning bit 64: fault injection -- a tile that would have to wait for a
                                                           // predecessor gives up at once, and every eighth tile behaves as if it had:
                                                           // wrong rows, the workspace's error word set (tests of the caller's recovery)
@@ -1580,53 +1533,12 @@ int bind_output(KArgs &a, const DDViewBatch *batch, const DDCloudOut *out) {
     return DD_OK;
 }
 
-// How many workgroups of a kernel the device holds at once (occupancy query x CUs, asked once per kernel and device): the
-// distance in tiles at which the single-pass kernel touches its successors' inputs (KArgs::prefetch_ahead).  0 = no answer.
-int device_cus() {
-    static std::mutex mu;
-    static int cus[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-    std::lock_guard<std::mutex> lock(mu);
-    if (cus[dev] == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = -1;
-        cus[dev] = n;
-    }
-    return cus[dev] > 0 ? cus[dev] : 0;
-}
-
-template <typename Kernel>
-unsigned resident_workgroups(Kernel kernel, int block) {
-    static std::mutex mu;
-    static int per_cu[64] = {0};                // per instantiation (function template) and device
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-    int nb;
-    {
-        std::lock_guard<std::mutex> lock(mu);
-        if (per_cu[dev] == 0) {
-            int q = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kernel, block, 0) != hipSuccess || q <= 0) q = -1;
-            per_cu[dev] = q;
-        }
-        nb = per_cu[dev];
-    }
-    const int cus = device_cus();
-    return (nb > 0 && cus > 0) ? (unsigned)nb * (unsigned)cus : 0u;
-}
-
-template <typename Kernel>
-void launch_tiles(Kernel k, int block, bool single_pass, KArgs a, hipStream_t s) {
-    if (single_pass && !a.no_prefetch) a.prefetch_ahead = resident_workgroups(k, block);
-    hipLaunchKernelGGL(k, dim3(a.num_tiles), dim3(block), 0, s, a);
-}
-
 template <typename DepthT, bool SP, bool HM, bool HN>
 void launch_lean3(const KArgs &a, hipStream_t s) {
     constexpr int NW = SP ? SP_WAVES : WAVES;
-    if (a.rgb && (a.out_rgb || a.out_packed)) launch_tiles(compact_lean<DepthT, HM, SP, HN, true, NW>, 64 * NW, SP, a, s);   // colours gathered
-    else launch_tiles(compact_lean<DepthT, HM, SP, HN, false, NW>, 64 * NW, SP, a, s);
+    const dim3 grid(a.num_tiles), block(64 * NW);
+    if (a.rgb && (a.out_rgb || a.out_packed)) hipLaunchKernelGGL((compact_lean<DepthT, HM, SP, HN, true, NW>), grid, block, 0, s, a);   // colours gathered
+    else hipLaunchKernelGGL((compact_lean<DepthT, HM, SP, HN, false, NW>), grid, block, 0, s, a);
 }
 
 template <typename DepthT, bool SP>
@@ -1639,12 +1551,12 @@ void launch_lean(const KArgs &a, hipStream_t s) {
 }
 
 void launch_refine(const KArgs &a, hipStream_t s) {
+    const dim3 grid(a.num_tiles), block(64 * SP_WAVES);
     const bool hn = a.out_normal != nullptr, hc = a.rgb && (a.out_rgb || a.out_packed);
-    constexpr int B = 64 * SP_WAVES;
-    if (hn && hc) launch_tiles(compact_lean<float, false, true, true, true, SP_WAVES, true>, B, true, a, s);
-    else if (hn) launch_tiles(compact_lean<float, false, true, true, false, SP_WAVES, true>, B, true, a, s);
-    else if (hc) launch_tiles(compact_lean<float, false, true, false, true, SP_WAVES, true>, B, true, a, s);
-    else launch_tiles(compact_lean<float, false, true, false, false, SP_WAVES, true>, B, true, a, s);
+    if (hn && hc) hipLaunchKernelGGL((compact_lean<float, false, true, true, true, SP_WAVES, true>), grid, block, 0, s, a);
+    else if (hn) hipLaunchKernelGGL((compact_lean<float, false, true, true, false, SP_WAVES, true>), grid, block, 0, s, a);
+    else if (hc) hipLaunchKernelGGL((compact_lean<float, false, true, false, true, SP_WAVES, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((compact_lean<float, false, true, false, false, SP_WAVES, true>), grid, block, 0, s, a);
 }
 
 template <bool SP>

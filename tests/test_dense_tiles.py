@@ -1,6 +1,7 @@
 """The list-free path for dense tiles (``dense_wave`` in ``csrc/ddcore.hip``): tiles whose pixels all survive are written
 as line-aligned 16-byte pieces from an LDS staging area (xyz) and as shifted copies (normals, colours), per wave.  Its
-rows must be the rows of the list path (``tuning`` bit 128 switches the dense path off) bit for bit, for every phase
+rows must be the rows of the list path (``tuning`` bit 128 switches the dense path on; it is off by default -- it writes the same rows with a third of the
+instructions but is not faster) bit for bit, for every phase
 of the first row against the 128-byte lines of every output array, with the capacity cutting a dense tile anywhere, in
 the single-pass and the two-pass kernels, for float32 and float16 depth -- and equal to the oracle
 (``scripts/test.py:203-233`` restated)."""
@@ -12,7 +13,7 @@ from test_gpu_parity import assert_cloud, scene_radius
 
 pytestmark = pytest.mark.gpu
 
-NO_DENSE = 128
+DENSE = 128          # DDViewBatch.tuning bit 128: dense tiles take the list-free path (off by default)
 
 
 @pytest.fixture(scope="module")
@@ -87,7 +88,7 @@ def test_dense_path_equals_list_path(dd, dtype_name, mask_kind, tuning):
     params = np.tile([0.8 * W, 0.8 * W, W / 2, H / 2], (V, 1))
     E = _ring(V)
     mk = lambda tun: dd.ViewBatch(depth, params, E, mask=mask, normal=normal, rgb=rgb, tuning=tun)
-    dense, plain = mk(tuning), mk(tuning | NO_DENSE)
+    dense, plain = mk(tuning | DENSE), mk(tuning)
     n = V * H * W if mask is None else int(mask.sum())
     ref = _build(dd, plain, n, None, FIELDS, fill=False)
     assert int(ref.cursor.item()) == n
@@ -117,7 +118,7 @@ def test_dense_path_field_subsets_and_odd_base_pointers(dd, fields):
     E = _ring(V)
     n = int(mask.sum())
     outs = {}
-    for tun in (0, NO_DENSE):
+    for tun in (DENSE, 0):
         batch = dd.ViewBatch(depth, params, E, mask=mask, normal=normal, rgb=rgb, tuning=tun)
         pad = {"points": 1, "normals": 3, "colors": 5, "pixel_index": 7, "view_index": 9}      # rows in front: 12 / 36 / 15 / 28 / 36 bytes
         bufs = {}
@@ -133,7 +134,7 @@ def test_dense_path_field_subsets_and_odd_base_pointers(dd, fields):
         torch.cuda.synchronize()
         outs[tun] = {k: v.clone() for k, v in bufs.items() if v is not None}
     for name in fields:
-        assert torch.equal(outs[0][name].view(torch.uint8), outs[NO_DENSE][name].view(torch.uint8)), name
+        assert torch.equal(outs[0][name].view(torch.uint8), outs[DENSE][name].view(torch.uint8)), name
 
 
 @pytest.mark.parametrize("dtype_name", ("float32", "float16"))
@@ -146,7 +147,7 @@ def test_dense_tiles_against_the_oracle(dd, dtype_name):
     rgb = rng.integers(0, 256, (V, H, W, 3), dtype=np.uint8)
     params = np.stack([[500.0, 510.0, 320.0, 48.0], [480.0, 470.0, 300.5, 50.25]])
     E = _ring(V)
-    for tuning in (0, 4):
+    for tuning in (DENSE, DENSE | 4):
         cloud = dd.unproject_views(depth, params, E, normal=normal, rgb=rgb, view_index=True, tuning=tuning, capacity="max")
         ref = orc.densify_scene_script(depth, params, E, normal=normal, rgb=rgb)
         assert_cloud(cloud, ref, scene_radius(E, depth))
@@ -160,5 +161,5 @@ def test_narrow_views_take_the_list_path(dd):
     depth = rng.uniform(0.5, 6.0, (V, H, W)).astype(np.float32)
     params = np.array([[40.0, 41.0, 24.0, 512.0]])
     E = _ring(V)
-    cloud = dd.unproject_views(depth, params, E, view_index=True)
+    cloud = dd.unproject_views(depth, params, E, view_index=True, tuning=DENSE)
     assert_cloud(cloud, orc.densify_scene_script(depth, params, E), scene_radius(E, depth))

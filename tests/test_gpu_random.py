@@ -42,6 +42,8 @@ def _case(seed):
     opts["capacity"] = [None, "max"][int(rng2.integers(0, 2))]
     if rng2.uniform() < 0.3:
         opts["tuning"] |= 32                      # wave runs NOT aligned to 128-byte lines: same bits out
+    if np.random.default_rng(30_000 + seed).uniform() < 0.4:
+        opts["tuning"] |= 128                     # round 4: dense tiles take the list-free path (needs >= 12 288 dense pixels: DD_RANDOM_SCALE)
     return d, opts
 
 
