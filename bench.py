@@ -612,19 +612,21 @@ def main() -> None:
 
     def step_scenes(record: bool):
         """mip360x7: this rank's scenes back to back -- per scene a cloud sized for every visited pixel (on the pooled arrays
-        above), the fused call, and the host read of the point count and the error word that writing the scene's model needs.
-        The events bracket the whole sequence, host gaps included."""
+        above), the fused call, and the read of the point count and the error word that writing the scene's model needs --
+        asked for behind each scene's kernel (``CloudBuilder.check_async``) and looked at once all scenes are enqueued, so the
+        host never stands between two kernels (round 3 read them scene by scene: 0.58 of the roofline against 0.60 for one scene).
+        The events bracket the whole sequence."""
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if record else None
         if record:
             e[0].record()
-        n = 0
+        pending = []
         for b in batches:
             bufs = {k: t[:b.max_points] for k, t in scene_pool.items() if t is not None}
             cloud = dd.CloudBuilder(b.max_points, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index, device=device,
                                     buffers=bufs)
             cloud.append(b)
-            n += cloud.check()
-            del cloud
+            pending.append(cloud.check_async())         # count + status on their way to the host; the next scene is enqueued meanwhile
+        n = sum(p.result(heal=False) for p in pending)   # (the scenes share the pooled arrays: a redo after the fact has nothing to redo into)
         if record:
             e[1].record(); e[2].record()
             ev.append(e)
@@ -795,6 +797,9 @@ def main() -> None:
                          "read_frac_note": "algorithmic READ bytes / kernel time / peak (the other "
                                            f"{100 * (1 - alg_r / alg):.0f} % of the bytes are writes sharing the same interface)",
                          "traffic": traffic, "traffic_source": traffic_source,
+                         # the counters' bytes over the same time: what the kernel really moves through the fabric (per-pixel culls
+                         # fetch whole 128-byte lines of the normal / colour maps for one survivor: frac undercounts them)
+                         "traffic_frac": None if not traffic else round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                          "traffic_over_algorithmic": None if traffic is None else round(traffic / alg, 4),
                          "algorithmic_bytes_per_launch": alg,
                          "kernel_ms": round(kernel_ms, 4), "kernel_ms_min": round(float(np.min(k_all)), 4),

@@ -95,6 +95,7 @@ class FusedCloud:
     view_offsets: torch.Tensor             # (V+1,) int64
     name: str = "Dense Cloud"
     packed: Optional[torch.Tensor] = None  # (N,4) float32 rows x, y, z, bits(r | g<<8 | b<<16 | 255<<24): the 16-byte gather record
+    rgb_passthrough: Optional[list] = None # viz semantics: per view, the image whose colours the reference hands on in a non-uint8 dtype
 
     def __len__(self) -> int:
         return int(self.points.shape[0])
@@ -176,6 +177,60 @@ _TORCH_DTYPE = {n: getattr(torch, n) for n in ("float32", "float64", "float16", 
 _small = _PinnedRing()
 
 
+class _HostSlots:
+    """Page-locked slots of 8 int64 for results on their way BACK from the GPU (a cloud's row count and the scan status words):
+    the copies are enqueued without making the host wait, an event behind them says when the slot can be read."""
+
+    def __init__(self, slots: int = 128, words: int = 8):
+        self.slots, self.words = slots, words
+        self._block = None
+        self._events = [None] * slots
+        self._next = 0
+
+    def take(self):
+        if self._block is None:
+            self._block = torch.zeros(self.slots * self.words, dtype=torch.int64, pin_memory=True)
+        k = self._next % self.slots
+        self._next += 1
+        if self._events[k] is not None:
+            self._events[k].synchronize()              # a slot comes round again only after ~128 checks: long done
+        return k, self._block[k * self.words:(k + 1) * self.words]
+
+    def stamp(self, k: int, event) -> None:
+        self._events[k] = event
+
+
+_results = _HostSlots()
+
+
+class PendingCheck:
+    """A ``CloudBuilder.check_async()`` in flight: the row count and the scan status of everything appended so far are on
+    their way to the host; ``result()`` waits for them (only for them: kernels enqueued later keep running) and does what
+    ``check()`` does."""
+
+    def __init__(self, builder: "CloudBuilder", slot: torch.Tensor, nws: int, workspaces: list, event, late=()):
+        self._b, self._slot, self._nws, self._ws, self._event, self._late = builder, slot, nws, workspaces, event, list(late)
+
+    def result(self, heal: bool = True) -> int:
+        self._event.synchronize()
+        b = self._b
+        total = int(self._slot[0])
+        bad = [w for w, v in zip(self._ws, self._slot[1:1 + self._nws].tolist()) if (v >> 32) != 0]
+        bad += [w for w in self._late if int(w[:8].view(torch.int32)[1].item()) != 0]
+        if bad:
+            for w in bad:
+                w[:16].zero_()                            # sticky word: cleared only here, once seen
+            if not heal:
+                raise RuntimeError("libddcore: in-kernel scan timed out in one of the appended batches (workspace error word set); "
+                                   "rows are invalid -- append the batches again with tuning=4")
+            total = b._heal()
+        if total > b.capacity:
+            raise OverflowError(f"cloud capacity {b.capacity} < {total} valid points; "
+                                "allocate with capacity=batch.max_points or count_valid() first")
+        b._release_retained(total)
+        return total
+
+
 def upload_small(arr: np.ndarray, device: torch.device) -> torch.Tensor:
     """Host array -> device tensor without making the host wait for the stream (up to 256 KiB; larger arrays take the
     ordinary path)."""
@@ -243,9 +298,16 @@ class ViewBatch:
             self.conf_threshold = float(np.float32(conf_threshold))
         self.normal = _gpu(normal, dev, torch.float32)
         self.rgb = _gpu(rgb, dev)
-        if self.rgb is not None and self.rgb.dtype != torch.uint8:
-            # visualizer.py:341-342: float colours in [0,1] are scaled to uint8
-            self.rgb = (self.rgb * 255).to(torch.uint8) if float(self.rgb.max()) <= 1.0 else self.rgb.to(torch.uint8)
+        if self.rgb is not None:
+            if semantics == "viz":
+                # visualizer.py:337-342, per view (the reference converts one view per call): the colours OF THE VALID PIXELS
+                # are multiplied by 255 and cast to uint8 when their maximum is <= 1 -- whatever the image's dtype -- and are
+                # otherwise left as they are.  The kernel gathers uint8 colours; a view whose colours stay non-uint8 is
+                # kept in `rgb_passthrough` for COLMAPVisualizer.add_rgbd_pointcloud, which gathers them by pixel index.
+                self.rgb, self.rgb_passthrough = _viz_colors(self.rgb, self.depth, self.mask)
+            elif self.rgb.dtype != torch.uint8:
+                # scripts/test.py:215 only ever sees uint8 (np.array of a PIL image); other dtypes are accepted as a convenience
+                self.rgb = (self.rgb * 255).to(torch.uint8) if float(self.rgb.max()) <= 1.0 else self.rgb.to(torch.uint8)
         for name, t, shape in (("mask", self.mask, (V, H, W)), ("conf", self.conf, (V, H, W)),
                                ("normal", self.normal, (V, H, W, 3)), ("rgb", self.rgb, (V, H, W, 3))):
             if t is not None and tuple(t.shape) != shape:
@@ -287,6 +349,8 @@ class ViewBatch:
         elif refined_out is not None:
             raise ValueError("refined_out needs refine=")
         self.params = upload_small(blocks, dev)
+        if not hasattr(self, "rgb_passthrough"):
+            self.rgb_passthrough = None
         self.view_index_base = int(view_index_base)
         self.tuning = int(tuning)
 
@@ -326,6 +390,7 @@ class ViewBatch:
         cut = lambda t: None if t is None else t[lo:hi]
         sub.depth, sub.mask, sub.conf, sub.normal, sub.rgb, sub.params, sub.refined = (
             cut(t) for t in (self.depth, self.mask, self.conf, self.normal, self.rgb, self.params, self.refined))
+        sub.rgb_passthrough = None if self.rgb_passthrough is None else self.rgb_passthrough[lo:hi]
         sub.view_index_base = self.view_index_base + lo
         return sub
 
@@ -373,6 +438,31 @@ class ViewBatch:
             conf_threshold=self.conf_threshold, flags=self.flags,
             view_index_base=self.view_index_base, tuning=self.tuning, refined_out=ptr(self.refined),
         )
+
+
+def _viz_colors(rgb: torch.Tensor, depth: torch.Tensor, mask: Optional[torch.Tensor]):
+    """``visualizer.py:337-342`` for a stack of views: -> (uint8 image stack for the kernel, list of per-view images that the
+    reference would hand on unchanged in a non-uint8 dtype, or None).  The test ``max <= 1`` is made on the colours of the
+    valid pixels (``mask > 0`` when a mask is given, else ``depth > 0``, ``visualizer.py:311-314``) and NaN compares false,
+    as in NumPy; the product ``colors * 255`` is formed in the image's own dtype, like NumPy's."""
+    valid = (mask > 0) if mask is not None else (depth > 0)                      # (V,H,W)
+    out = torch.empty(rgb.shape, dtype=torch.uint8, device=rgb.device)
+    keep = [None] * rgb.shape[0]
+    for v in range(rgb.shape[0]):
+        img = rgb[v]
+        cols = img[valid[v]]                                                    # (N,3) in the image's dtype
+        scale = False
+        if cols.numel() > 0:
+            m = cols.max()
+            scale = bool((m <= 1.0).item()) if cols.dtype.is_floating_point else int(m.item()) <= 1
+        if scale:
+            out[v] = (img * 255).to(torch.uint8)                                 # (values of invalid pixels may wrap: never gathered)
+        elif img.dtype == torch.uint8:
+            out[v] = img
+        else:
+            out[v] = 0
+            keep[v] = img
+    return out, (keep if any(k is not None for k in keep) else None)
 
 
 def _stream(device: torch.device) -> int:
@@ -449,9 +539,11 @@ class CloudBuilder:
         (``placement.place_outputs``; ``self.placement`` reports what was done); ``"first"`` takes the arrays as the
         allocator returns them.
 
-        The builder keeps the batches it is given (and with them their maps) until ``reset()`` so that it can redo them if
-        an in-kernel scan gives up (``check()`` / ``finish()``, ``self.healed``); it stops keeping them once they exceed a
-        quarter of the device's free memory."""
+        The builder keeps the batches it is given (and with them their maps) until the next ``check()`` / ``finish()`` /
+        ``reset()`` so that it can redo them if an in-kernel scan gives up (``self.healed``); it stops keeping them once they
+        exceed a quarter of the device's free memory.  **The maps of an appended batch must stay unmodified until then**: a
+        redo reads them again (an in-place write to one of them is noticed -- tensor version counter -- and turns the redo
+        into the error it was before round 3)."""
         dev = _require_gpu(device)
         self.device = dev
         self.capacity = int(capacity)
@@ -497,6 +589,7 @@ class CloudBuilder:
         self._retained_bytes = 0
         self._retain_limit = torch.cuda.mem_get_info(dev)[0] // 4
         self._retain_complete = True
+        self._retain_base: Optional[int] = None      # row the retained batches start from (None: the cloud's start)
         self.healed = 0
 
     def _set_start(self) -> None:
@@ -514,6 +607,7 @@ class CloudBuilder:
         self._retained.clear()
         self._retained_bytes = 0
         self._retain_complete = True
+        self._retain_base = None
 
     def _retain(self, batch: "ViewBatch", offsets: torch.Tensor) -> None:
         if not self._retain_complete:
@@ -525,8 +619,13 @@ class CloudBuilder:
             self._retain_complete = False
             self._retained.clear()
             return
-        self._retained.append((batch, offsets))
+        self._retained.append((batch, offsets, self._versions(batch)))
         self._retained_bytes += nbytes
+
+    @staticmethod
+    def _versions(batch: "ViewBatch") -> tuple:
+        """(data_ptr, version counter) of every map of a batch: what a redo must find unchanged."""
+        return tuple((t.data_ptr(), t._version) for t in (batch.depth, batch.mask, batch.conf, batch.normal, batch.rgb) if t is not None)
 
     def _offsets_slice(self, n: int) -> torch.Tensor:
         """(n,) int64 device slice from a pooled tensor (one allocation per ~4096 offsets, not per append)."""
@@ -600,13 +699,30 @@ class CloudBuilder:
         """Synchronise once: the row after the last appended point.  If an in-kernel scan gave up in one of the appended
         batches, the batches are redone once with the dependency-free two-pass kernels (``self.healed`` counts that);
         raises if that is not possible, or if the cloud overflowed."""
-        total = int(self.cursor.item())
-        if self._scan_gave_up():
-            total = self._heal()
-        if total > self.capacity:
-            raise OverflowError(f"cloud capacity {self.capacity} < {total} valid points; "
-                                "allocate with capacity=batch.max_points or count_valid() first")
-        return total
+        return self.check_async().result()
+
+    def check_async(self) -> PendingCheck:
+        """``check()`` without the wait: the cursor and the scan status words are copied to page-locked memory behind the
+        kernels enqueued so far; ``.result()`` waits for that copy alone.  A caller that runs scene after scene
+        (``scripts/run_batch.py:57-91``) asks here, enqueues the next scene and reads the answer later -- the GPU never
+        idles while the host looks at a number."""
+        ws = list({id(w): w for w in self._workspaces}.values())
+        ws, late = ws[:7], ws[7:]                     # (more than 7 distinct workspaces: the rest are read when the result is)
+        k, slot = _results.take()
+        slot[0:1].copy_(self.cursor, non_blocking=True)
+        for i, w in enumerate(ws):
+            slot[1 + i:2 + i].copy_(w[:8].view(torch.int64), non_blocking=True)      # bytes 4..7 = the error word
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        _results.stamp(k, ev)
+        return PendingCheck(self, slot, len(ws), ws, ev, late)
+
+    def _release_retained(self, total: int) -> None:
+        # everything appended so far is final: the batches (and their maps) need not be held any longer; a later redo starts here
+        self._retained.clear()
+        self._retained_bytes = 0
+        self._retain_complete = True
+        self._retain_base = total
 
     def finish(self, name: str = "Dense Cloud") -> FusedCloud:
         """Synchronise once, check the scan status words and the capacity, return exact-size views."""
@@ -638,8 +754,16 @@ class CloudBuilder:
             raise RuntimeError("libddcore: in-kernel scan timed out in one of the appended batches (workspace error word set) "
                                "and the batches are no longer held (more than a quarter of the device's memory): rows are "
                                "invalid -- append the batches again with tuning=4")
-        self._set_start()
-        for batch, offsets in self._retained:
+        for batch, _, versions in self._retained:
+            if self._versions(batch) != versions:
+                raise RuntimeError("libddcore: in-kernel scan timed out in one of the appended batches (workspace error word set) and "
+                                   "one of its maps was modified in place after append(): the rows cannot be redone -- append the "
+                                   "batches again with tuning=4 (inputs must stay unmodified until check() / finish())")
+        if self._retain_base is None:
+            self._set_start()
+        else:
+            self.cursor.fill_(self._retain_base)
+        for batch, offsets, _ in self._retained:
             saved = batch.tuning
             batch.tuning = (saved | 4) & ~(8 | 64)
             try:
@@ -663,7 +787,8 @@ def unproject_views(depth: ArrayLike, intrinsics: ArrayLike, cam_from_world: Arr
                     rgb: Optional[ArrayLike] = None, downsample_density: int = 1,
                     semantics: str = "script", rotate_normals: Optional[bool] = None,
                     capacity: Union[None, int, str] = None, pixel_index: bool = True,
-                    view_index: bool = False, device=None, tuning: int = 0, record: str = "rows") -> FusedCloud:
+                    view_index: bool = False, device=None, tuning: int = 0, record: str = "rows",
+                    _allow_passthrough: bool = False) -> FusedCloud:
     """Densify + fuse a stack of views: ``scripts/test.py:203-244`` per view and ``:262-266``.
 
     ``downsample_density`` is ``ProcessingConfig.downsample_density`` (``scripts/test.py:37``; the
@@ -680,6 +805,10 @@ def unproject_views(depth: ArrayLike, intrinsics: ArrayLike, cam_from_world: Arr
     batch = ViewBatch(depth, intrinsics, cam_from_world, mask=mask, conf=conf, conf_threshold=conf_threshold,
                       normal=normal, rgb=rgb, stride=downsample_density, semantics=semantics,
                       rotate_normals=rotate_normals, device=device, tuning=tuning)
+    if batch.rgb_passthrough is not None and not _allow_passthrough:
+        raise ValueError("the colours of some views stay non-uint8 in the reference (visualizer.py:341: valid colours above 1 are "
+                         "handed on unchanged); a fused cloud carries uint8 colours -- convert the image, or go through "
+                         "COLMAPVisualizer.add_rgbd_pointcloud, which returns them in their own dtype")
     with_normals = batch.normal is not None and (semantics == "script" or batch.mask is not None)
     rows = record != "xyz_rgba"
     fields = dict(normals=with_normals, colors=batch.rgb is not None and rows, pixel_index=pixel_index,
@@ -697,7 +826,9 @@ def unproject_views(depth: ArrayLike, intrinsics: ArrayLike, cam_from_world: Arr
         cap = int(capacity)
     builder = CloudBuilder(cap, **fields)
     builder.append(batch)
-    return builder.finish()
+    cloud = builder.finish()
+    cloud.rgb_passthrough = batch.rgb_passthrough
+    return cloud
 
 
 def fuse_batches(batches: Sequence[ViewBatch], capacity: Optional[int] = None, **cloud_fields) -> FusedCloud:

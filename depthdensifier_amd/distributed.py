@@ -266,15 +266,33 @@ def exchange_rows(tensors: Sequence[torch.Tensor], rows: Sequence[tuple], group=
     if os.environ.get("DD_ALLGATHERV", "p2p") == "broadcast" and dst is None:
         return [dist.broadcast(t[rows[r][0]:rows[r][1]], src=glob(r), group=group, async_op=True)
                 for r in range(world) if rows[r][1] > rows[r][0] for t in tensors]
-    ops = []
+    # backends without device send / recv (gloo: CPU rehearsals, ranks sharing one GPU) run the SAME schedule -- same peers, same
+    # row ranges, same order -- staged through host memory; the received rows are copied into place before this returns
+    staged = dist.get_backend(group) != "nccl" and any(t.is_cuda for t in tensors)
+    ops, landed, keep = [], [], []
     for k in range(1, world):                          # peer order staggered per rank: no hot receiver
         to, frm = (rank + k) % world, (rank - k) % world
         for t in tensors:
             if mine[1] > mine[0] and (dst is None or to == dst):
-                ops.append(dist.P2POp(dist.isend, t[mine[0] - base:mine[1] - base], glob(to), group))
+                out = t[mine[0] - base:mine[1] - base]
+                if staged:
+                    out = out.cpu()
+                    keep.append(out)
+                ops.append(dist.P2POp(dist.isend, out, glob(to), group))
             if rows[frm][1] > rows[frm][0] and (dst is None or rank == dst):
-                ops.append(dist.P2POp(dist.irecv, t[rows[frm][0]:rows[frm][1]], glob(frm), group))
-    return list(dist.batch_isend_irecv(ops)) if ops else []
+                into = t[rows[frm][0]:rows[frm][1]]
+                if staged:
+                    buf = torch.empty(into.shape, dtype=into.dtype)
+                    landed.append((into, buf))
+                    into = buf
+                ops.append(dist.P2POp(dist.irecv, into, glob(frm), group))
+    work = list(dist.batch_isend_irecv(ops)) if ops else []
+    if staged:
+        wait_all(work)
+        for into, buf in landed:
+            into.copy_(buf)
+        return []
+    return work
 
 
 def wait_all(work: Sequence) -> None:
@@ -315,9 +333,21 @@ def fuse_replicated(batch, num_views_total: int, *, normals: bool = True, colors
         builder.append(batch.slice(lo, hi))                             # kernel of this chunk on the current stream ...
         work += exchange_rows(moved, ranges, group, dst, base)          # ... its exchange waits for it, then runs on RCCL's stream
     wait_all(work)
+    healed_before = builder.healed
     end = builder.check()
     if end != own_hi - base:
         raise RuntimeError(f"rank {plan.rank}: kernel wrote up to row {end + base}, plan says {own_hi}")
+    # check() may have healed THIS rank's rows (an in-kernel scan gave up; the batches were redone two-pass, CloudBuilder._heal)
+    # -- after they went out.  The peers hold the rows of the failed attempt and cannot know: agree on it, and if any rank
+    # healed, every rank sends its (now final) rows of every chunk once more.
+    if dist.get_world_size(group) > 1:
+        flag = torch.tensor([1 if builder.healed != healed_before else 0], dtype=torch.int32, device=batch.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        if int(flag.item()):
+            work = []
+            for ranges in plan.chunk_rows:
+                work += exchange_rows(moved, ranges, group, dst, base)
+            wait_all(work)
     cut = lambda t: None if t is None else t[:cap]
     if rows:
         cloud = FusedCloud(points=cut(builder.xyz), colors=cut(builder.rgb), normals=cut(builder.normal), pixel_index=cut(builder.pix),
@@ -378,15 +408,19 @@ def views_in_reach(points: torch.Tensor, K: "np.ndarray", E: "np.ndarray", sizes
     n = points.shape[0]
     if n == 0 or V == 0:
         return torch.zeros(V, dtype=torch.bool, device=dev)
-    p = points.to(torch.float64)
-    finite = bool(torch.isfinite(p).all())
-    if not finite:
+    # per-run bounding boxes on the points as they are (min / max are exact in any dtype): no float64 copy of the cloud, no padded
+    # second copy -- at 2 G points per rank those were ~100 GB of transients.  The ragged tail is a run of its own.
+    whole = (n // chunk) * chunk
+    parts_lo, parts_hi = [], []
+    if whole:
+        body = points[:whole].view(-1, chunk, 3)
+        parts_lo.append(body.amin(dim=1)); parts_hi.append(body.amax(dim=1))
+    if n > whole:
+        tail = points[whole:]
+        parts_lo.append(tail.amin(dim=0, keepdim=True)); parts_hi.append(tail.amax(dim=0, keepdim=True))
+    lo, hi = torch.cat(parts_lo).to(torch.float64), torch.cat(parts_hi).to(torch.float64)    # (S,3)
+    if not bool((torch.isfinite(lo) & torch.isfinite(hi)).all()):          # amin / amax propagate NaN; an infinity shows in one of them
         return torch.ones(V, dtype=torch.bool, device=dev)
-    pad = (-n) % chunk
-    if pad:
-        p = torch.cat([p, p[-1:].expand(pad, 3)])
-    p = p.view(-1, chunk, 3)
-    lo, hi = p.amin(dim=1), p.amax(dim=1)
     c = 0.5 * (lo + hi)                                                     # (S,3) sphere centres
     r = 0.5 * torch.linalg.vector_norm(hi - lo, dim=1) * (1.0 + 1e-6) + 1e-9     # (S,) half diagonals: every point is inside
     Kt = torch.as_tensor(np.asarray(K, dtype=np.float64), device=dev)       # (V,3,3)

@@ -411,8 +411,13 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
         if layout_error is not None:                    # every rank raises the same error instead of hanging in a collective
             raise RuntimeError(f"rank 0 could not lay out the model file: {layout_error}")
         own_lo, own_hi = plan.rank_rows[ranks.rank]
-        if len(kept) != own_hi - own_lo:                # a rank writing more or fewer records than its slot would corrupt its neighbours'
-            raise RuntimeError(f"rank {ranks.rank} holds {len(kept)} kept points but its slice of the model file has room for {own_hi - own_lo}")
+        # a rank writing more or fewer records than its slot would corrupt its neighbours' -- checked by all ranks TOGETHER:
+        # one rank raising on its own would leave the others in the barrier below until the collective times out
+        mismatch = [None] * ranks.world
+        dist.all_gather_object(mismatch, None if len(kept) == own_hi - own_lo else
+                               f"rank {ranks.rank} holds {len(kept)} kept points but its slice of the model file has room for {own_hi - own_lo}")
+        if any(m is not None for m in mismatch):
+            raise RuntimeError("; ".join(m for m in mismatch if m is not None))
         if len(kept):
             write_dense_at(config.paths.output_model_dir / "points3D.bin", where["dense_offset"] + own_lo * RECORD_BYTES,
                            kept, where["first_dense_id"] + own_lo)

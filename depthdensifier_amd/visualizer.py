@@ -46,11 +46,20 @@ class COLMAPVisualizer:
         to the world frame and re-normalised) only when both ``normal_map`` and ``mask`` are given."""
         if K is None or cam_from_world is None:
             raise ValueError("Camera intrinsics (K) and extrinsics (cam_from_world) are required")
-        cloud = unproject_views(np.asarray(depth_map)[None], np.asarray(K, dtype=np.float64)[None],
+        image = None if rgb_image is None else np.asarray(rgb_image)
+        # colours (visualizer.py:337-342): x255 -> uint8 when the VALID colours' maximum is <= 1, otherwise handed on in the
+        # image's own dtype.  uint8 results are gathered by the kernel; a float image that stays float is gathered here by
+        # the pixel index the kernel emits.
+        keeps_dtype = image is not None and image.dtype != np.uint8
+        fused = unproject_views(np.asarray(depth_map)[None], np.asarray(K, dtype=np.float64)[None],
                                 np.asarray(cam_from_world, dtype=np.float64)[None],
                                 mask=None if mask is None else np.asarray(mask)[None],
                                 normal=None if normal_map is None else np.asarray(normal_map, dtype=np.float32)[None],
-                                rgb=None if rgb_image is None else np.asarray(rgb_image)[None],
-                                semantics="viz", pixel_index=False).numpy()
-        self.add_pointcloud(points=cloud["points"], colors=cloud["colors"], normals=cloud["normals"], name=name, **kwargs)
+                                rgb=None if image is None else image[None],
+                                semantics="viz", pixel_index=keeps_dtype, _allow_passthrough=True)
+        cloud = fused.numpy()
+        colors = cloud["colors"]
+        if keeps_dtype and fused.rgb_passthrough is not None:
+            colors = image.reshape(-1, image.shape[-1])[cloud["pixel_index"]]
+        self.add_pointcloud(points=cloud["points"], colors=colors, normals=cloud["normals"], name=name, **kwargs)
         return cloud["points"]

@@ -58,7 +58,18 @@ def main():
     same(cloud.packed, full_packed.packed, "xyz_rgba record")
     same(cloud.points.contiguous(), full.points, "xyz_rgba points view")
     same(cloud.colors.contiguous(), full.colors, "xyz_rgba colours view")
-    if backend == "nccl" and world > 1:                                       # gather-to-owner needs send/recv
+    fault = os.environ.get("DD_FUSE_FAULT_RANK")
+    if fault is not None:
+        # an in-kernel scan gives up on ONE rank (fault injection, tuning bit 64): that rank heals its rows after they went out;
+        # every rank must still end up with the whole cloud (the re-exchange is agreed on collectively)
+        bad = dd.ViewBatch(cut(d["depth"]), cut(params), cut(d["cam_from_world"]), mask=cut(d["mask"]), normal=cut(d["normal"]),
+                           rgb=cut(d["rgb"]), view_index_base=lo, device=dev, tuning=64 if rank == int(fault) else 0)
+        cloud, plan = D.fuse_replicated(bad, V, pixel_index=True, view_index=True, chunks=3)
+        torch.cuda.synchronize()
+        for name in ("points", "colors", "normals", "pixel_index", "view_index"):
+            same(getattr(cloud, name), getattr(full, name), f"healed on rank {fault}, {name}")
+    p2p = os.environ.get("DD_ALLGATHERV", "p2p") == "p2p"
+    if p2p and world > 1:                                                     # gather-to-owner needs send/recv (gloo: host-staged)
         owner = world - 1
         cloud, plan = D.fuse_replicated(batch, V, record="xyz_rgba", chunks=2, dst=owner)
         torch.cuda.synchronize()

@@ -483,8 +483,46 @@ def build_votes():
     return g
 
 
+def build_colors():
+    """colors_small.npz: the colour branch of ``_depth_to_pointcloud`` (src/depthdensifier/visualizer.py:337-342) and what
+    ``add_rgbd_pointcloud`` stores, for the image types the uint8 fixtures do not reach:
+      f01      float32 image in [0, 1]                      -> x255, uint8
+      f255     float32 image in [0, 255]                    -> kept as float32
+      fmasked  float32 image in [0, 1] whose only values above 1 lie under the mask's holes -> x255, uint8 (the test is on the VALID colours)
+      u01      uint8 image with maximum 1                   -> x255, uint8
+      f64      float64 image in [0, 1]                      -> x255 in float64, uint8
+      nomask   float32 image in [0, 1], no mask: validity = depth > 0, colours of the pixels with depth <= 0 above 1
+    Every case: one 24 x 32 view, skewed K, random pose."""
+    rng = np.random.default_rng(77)
+    H, W = 24, 32
+    K = np.array([[30.0, 0.4, 15.5], [0.0, 31.0, 11.5], [0.0, 0.0, 1.0]])
+    E = random_pose(rng)
+    depth = rng.uniform(0.5, 4.0, (H, W)).astype(np.float32)
+    depth[rng.uniform(size=(H, W)) < 0.15] = 0.0
+    mask = rng.uniform(size=(H, W)) < 0.7
+    base = rng.uniform(0.0, 1.0, (H, W, 3))
+    f01 = base.astype(np.float32)
+    f255 = (base * 255.0).astype(np.float32)
+    fmasked = f01.copy(); fmasked[~mask] = 7.5
+    u01 = (base > 0.5).astype(np.uint8)
+    f64 = base.copy()
+    nomask = f01.copy(); nomask[depth <= 0] = 3.0
+    g = dict(in_K=K, in_cam_from_world=E, in_depth=depth, in_mask=mask)
+    for name, img, m in (("f01", f01, mask), ("f255", f255, mask), ("fmasked", fmasked, mask), ("u01", u01, mask), ("f64", f64, mask),
+                         ("nomask", nomask, None)):
+        pts, cols = VIZ._depth_to_pointcloud(depth, K, E, img, m)
+        viz = COLMAPVisualizer()
+        ret = viz.add_rgbd_pointcloud(depth, img, K, E, m, None)
+        assert np.array_equal(ret, pts) and np.array_equal(viz.point_clouds[0].colors, cols)
+        g[f"{name}_in_rgb"] = img
+        g[f"{name}_exp_points__depth_to_pointcloud"] = pts
+        g[f"{name}_exp_colors__depth_to_pointcloud"] = cols
+    np.savez_compressed(OUT / "colors_small.npz", **g)
+    return g
+
+
 ALL_FIXTURES = ("densify_small.npz", "densify_vga.npz", "filter_small.npz", "refiner_small.npz", "script_block_small.npz",
-                "votes_small.npz")
+                "votes_small.npz", "colors_small.npz")
 
 
 def build_all():
@@ -494,6 +532,7 @@ def build_all():
     build_refiner()
     build_script_block()
     build_votes()
+    build_colors()
     return a, b
 
 
@@ -504,6 +543,8 @@ if __name__ == "__main__":
     build_refiner()
     build_script_block()
     v = build_votes()
+    c = build_colors()
+    print("colour cases:", {k.split("_exp_")[0]: str(v_.dtype) for k, v_ in c.items() if "_exp_colors" in k})
     for f in ALL_FIXTURES:
         print(f, (OUT / f).stat().st_size, "bytes")
     for tag in ("default", "tight"):

@@ -157,3 +157,24 @@ def test_gloo_sharded_batch(tmp_path, world):
     assert [n for n, _ in reports[0]] == ["alpha", "beta", "broken", "delta", "gamma"]
     assert dict(map(tuple, reports[0]))["broken"] == "FAILED"
     assert "Batch Processing Time Report" in outs[0] and all("Batch Processing Time Report" not in o for o in outs[1:])
+
+
+def test_c_abi_allgatherv_schedule_on_a_fake_rccl(tmp_path):
+    """``dd_allgatherv`` at world 2, 3 and 8 without a GPU: ``tests/c_client/fake_rccl.cpp`` exports the five RCCL entry points
+    itself (libddcore.so resolves them from the running process), plays every rank on host buffers, matches the logged
+    sends with the logged receives the way NCCL does and moves the bytes: every receiver ends with the whole cloud, a pure
+    sender's base offset is honoured, nothing is sent twice or left unmatched -- replicate and gather-to-owner, all six
+    fields, ragged and empty shards."""
+    import shutil
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    lib_dir = ROOT / "depthdensifier_amd"
+    if not (lib_dir / "libddcore.so").exists():
+        pytest.skip("libddcore.so not built")
+    exe = tmp_path / "fake_rccl"
+    build = subprocess.run([gxx, "-std=c++17", "-O1", "-rdynamic", f"-I{ROOT / 'include'}", str(ROOT / "tests" / "c_client" / "fake_rccl.cpp"),
+                            f"-L{lib_dir}", "-lddcore", "-ldl", f"-Wl,-rpath,{lib_dir}", "-o", str(exe)], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-3000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and "exchanges OK" in run.stdout, run.stdout[-2000:] + run.stderr[-2000:]

@@ -66,15 +66,30 @@ def test_rccl_world1_in_process():
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("flavour", ("broadcast", "p2p"))
 @pytest.mark.parametrize("ranks, views", [(2, 9), (3, 4), (3, 2)])
-def test_ranks_sharing_the_gpu_over_gloo(ranks, views):
-    """Even shards, uneven shards (2 + 1 + 1 views) and a rank that owns NO view at all (3 ranks, 2 views)."""
+def test_ranks_sharing_the_gpu_over_gloo(ranks, views, flavour):
+    """Even shards, uneven shards (2 + 1 + 1 views) and a rank that owns NO view at all (3 ranks, 2 views); both flavours of
+    the exchange -- ``p2p`` is the grouped send / recv schedule RCCL runs by default (here staged through host memory), with
+    its gather-to-owner form."""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    r = _torchrun(ranks, dict(DD_DIST_BACKEND="gloo", DD_ALLGATHERV="broadcast", DD_SHARE_GPU="1", DD_FUSE_VIEWS=str(views)))
+    r = _torchrun(ranks, dict(DD_DIST_BACKEND="gloo", DD_ALLGATHERV=flavour, DD_SHARE_GPU="1", DD_FUSE_VIEWS=str(views)))
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count(": ok,") == ranks
+
+
+@pytest.mark.parametrize("fault_rank", (0, 1))
+def test_a_rank_that_heals_after_sending_is_resent(fault_rank):
+    """a look-back that gave up on one rank is healed by ``check()`` AFTER the rank's rows went to its peers.  The
+    ranks agree on it (all-reduce of a flag) and exchange every chunk once more: all ranks hold the right cloud."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    r = _torchrun(2, dict(DD_DIST_BACKEND="gloo", DD_ALLGATHERV="p2p", DD_SHARE_GPU="1", DD_FUSE_VIEWS="9", DD_FUSE_FAULT_RANK=str(fault_rank)))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count(": ok,") == 2
 
 
 def test_two_ranks_over_rccl():

@@ -127,6 +127,34 @@ def test_golden_package_formulation(dd, golden_small, c):
     assert nomask["normals"] is None          # visualizer.py:276: normals only with a mask
 
 
+@pytest.mark.parametrize("case", ("f01", "f255", "fmasked", "u01", "f64", "nomask"))
+def test_golden_package_colour_conversion(dd, case):
+    """The colour branch of ``_depth_to_pointcloud`` (``visualizer.py:337-342``) on the image types the uint8 fixtures do not
+    reach (``tests/golden/colors_small.npz``, captured from the reference): the test ``max <= 1`` is made on the VALID colours,
+    x255 applies to any dtype (also uint8 with maximum 1), and colours that are not scaled keep their dtype -- through
+    ``COLMAPVisualizer.add_rgbd_pointcloud``, values and dtype equal to the reference's; through ``unproject_views`` the
+    uint8 outcomes equal, the float outcome refused (a fused cloud carries uint8 colours)."""
+    from pathlib import Path
+    from depthdensifier_amd.visualizer import COLMAPVisualizer
+    g = np.load(Path(__file__).parent / "golden" / "colors_small.npz")
+    depth, K, E = g["in_depth"], g["in_K"], g["in_cam_from_world"]
+    mask = None if case == "nomask" else g["in_mask"]
+    img = g[f"{case}_in_rgb"]
+    want_p, want_c = g[f"{case}_exp_points__depth_to_pointcloud"], g[f"{case}_exp_colors__depth_to_pointcloud"]
+    viz = COLMAPVisualizer()
+    pts = viz.add_rgbd_pointcloud(depth, img, K, E, mask, None)
+    got_c = viz.point_clouds[0].colors
+    assert_xyz(pts, want_p, scene_radius(E[None], depth[None]))
+    assert got_c.dtype == want_c.dtype and np.array_equal(got_c, want_c), case
+    kw = dict(mask=None if mask is None else mask[None], rgb=img[None], semantics="viz")
+    if want_c.dtype == np.uint8:
+        cloud = dd.unproject_views(depth[None], K[None], E[None], **kw).numpy()
+        assert np.array_equal(cloud["colors"], want_c)
+    else:
+        with pytest.raises(ValueError, match="non-uint8"):
+            dd.unproject_views(depth[None], K[None], E[None], **kw)
+
+
 @pytest.mark.parametrize("kname", ("ident", "real"))
 @pytest.mark.parametrize("tag", ("dense", "masked"))
 @pytest.mark.parametrize("s", (1, 32))
@@ -629,6 +657,24 @@ def test_scan_timeout_is_healed_by_a_two_pass_redo(dd, fields):
     b.reset()
     b.append(good)
     assert torch.equal(b.finish().points, want.points) and b.healed == 1
+    # check() between appends: what it has verified is final and no longer held; a later give-up redoes only what came after it
+    b.reset()
+    b.append(first)
+    n1 = b.check()
+    assert n1 == int(want.view_offsets[2]) and not b._retained
+    b.append(second)
+    got2 = b.finish()
+    assert b.healed == 2 and torch.equal(got2.points, want.points) and torch.equal(got2.pixel_index, want.pixel_index)
+    assert not b._retained                                                            # finish() lets the maps go
+    # an input overwritten in place between append() and finish(): the redo would read other pixels -- refused, like before round 3
+    b.reset()
+    scratch = depth[2:].clone()
+    third = dd.ViewBatch(scratch, params[2:], E[2:], view_index_base=2, tuning=64, **{k: t[2:] for k, t in kw.items()})
+    b.append(first)
+    b.append(third)
+    scratch.add_(1.0)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        b.finish()
 
 
 @pytest.mark.parametrize("rho", (0.05, 0.5, 0.97))

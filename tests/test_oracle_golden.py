@@ -135,3 +135,16 @@ def test_two_formulations_agree(vga_inputs):
     b, _, lin = orc.depth_to_pointcloud_viz(d["depth"][0], K, d["cam_from_world"][0], None, d["mask"][0])
     assert np.array_equal(a["pixel_index"], lin)
     assert np.abs(a["points"] - b).max() < 1e-12 * 10
+
+
+@pytest.mark.parametrize("case", ("f01", "f255", "fmasked", "u01", "f64", "nomask"))
+def test_package_colour_conversion(case):
+    """The oracle's restatement of ``visualizer.py:337-342`` against the reference's own return values for float images, a
+    uint8 image with maximum 1 and colours above 1 that lie under the mask's holes (``tests/golden/colors_small.npz``)."""
+    from pathlib import Path
+    g = np.load(Path(__file__).parent / "golden" / "colors_small.npz")
+    mask = None if case == "nomask" else g["in_mask"]
+    pts, cols, _ = orc.depth_to_pointcloud_viz(g["in_depth"], g["in_K"], g["in_cam_from_world"], g[f"{case}_in_rgb"], mask)
+    want = g[f"{case}_exp_colors__depth_to_pointcloud"]
+    assert cols.dtype == want.dtype and np.array_equal(cols, want)
+    assert np.array_equal(pts, g[f"{case}_exp_points__depth_to_pointcloud"])
