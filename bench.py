@@ -621,11 +621,9 @@ def main() -> None:
             e[0].record()
         pending = []
         for b in batches:
-            bufs = {k: t[:b.max_points] for k, t in scene_pool.items() if t is not None}
-            cloud = dd.CloudBuilder(b.max_points, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index, device=device,
-                                    buffers=bufs)
-            cloud.append(b)
-            pending.append(cloud.check_async())         # count + status on their way to the host; the next scene is enqueued meanwhile
+            big.reset()                                 # the next scene's cloud: the same pooled arrays, rows from 0
+            big.append(b)
+            pending.append(big.check_async())           # count + status on their way to the host; the next scene is enqueued meanwhile
         n = sum(p.result(heal=False) for p in pending)   # (the scenes share the pooled arrays: a redo after the fact has nothing to redo into)
         if record:
             e[1].record(); e[2].record()
@@ -760,7 +758,8 @@ def main() -> None:
         traffic, traffic_source = None, None
         tfile = ROOT / "profiles" / "traffic.json"
         if tfile.exists():
-            tkey = args.workload + (":bernoulli" if args.mask_kind == "bernoulli" else "") + ("" if single_pass else ":two-pass")
+            tkey = ("mip360conf" if multi else args.workload) + (":bernoulli" if args.mask_kind == "bernoulli" else "") + ("" if single_pass else ":two-pass")
+            # (mip360x7 runs the mip360conf kernel scene after scene on the same kind of maps: its bytes per view)
             rec = json.loads(tfile.read_text()).get(tkey)
             if rec:     # PMC bytes were collected on the full workload; a launch over fewer views moves proportionally fewer
                 traffic = int(rec["hbm_bytes_per_launch"] * V / rec["views"])

@@ -14,7 +14,6 @@
 // camera, outside the image) and most pairs never reach the square root.
 //
 // What is in this file (DDFilterViews.mode; every form gives the same votes, bit for bit):
-//   floater_votes_kernel            the round-1 float64 kernel (mode 1 without a workspace)
 //   floater_votes_kernel2           float64, image bounds without the division, reciprocal only before the lookup (mode 1)
 //   floater_votes_kernel_cull       kernel2's pair test behind a two-level view cull: a mask of visible views per 65 536
 //                                   points, then the workgroup's own bounding sphere (mode 3; mode 4 = default of the host
@@ -168,31 +167,6 @@ __device__ __forceinline__ bool pair_votes(const FArgs &a, const Cam &c, const i
     if (!(seen > 0.0f)) return false;                        // :315
     const float limit = a.depth_threshold * seen;        // :320 float32 product (NEP 50)
     return zc < (double)limit;                           // :319-328
-}
-
-__global__ __launch_bounds__(256) void floater_votes_kernel(const FArgs a) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    const bool live = i < a.n;
-    const double wlim = (double)a.W, hlim = (double)a.H;
-    if (!live) return;
-    const double x = a.xyz[3 * i], y = a.xyz[3 * i + 1], z = a.xyz[3 * i + 2];
-    const double nx = a.normal[3 * i], ny = a.normal[3 * i + 1], nz = a.normal[3 * i + 2];
-    int votes = a.accumulate ? a.votes[i] : 0;
-    // The view's [R|t] is fetched one view AHEAD (scalar loads into SGPRs): with the load at the top of the iteration
-    // that uses it, every wave sat out a scalar-memory round trip per view before its first FMA.
-    auto fetch = [&](int v, CamAhead &c) {
-        cam_vec4 *p = (cam_vec4 *)(a.cams + (size_t)v * 24);
-        c.r0 = p[0]; c.r1 = p[1]; c.r2 = p[2];
-        c.rest = (cam_double *)(a.cams + (size_t)v * 24);
-    };
-    CamAhead cur, nxt;
-    fetch(0, cur);
-    for (int v = 0; v < a.V; ++v) {
-        fetch(v + 1 < a.V ? v + 1 : v, nxt);
-        votes += pair_votes(a, cur, v, x, y, z, nx, ny, nz, wlim, hlim) ? 1 : 0;   // wave-uniform block: scalar operands
-        cur = nxt;
-    }
-    a.votes[i] = votes;
 }
 
 // ==================================================================================================
@@ -761,7 +735,7 @@ int dd_floater_votes(const DDFilterViews *views, const float *xyz, const float *
     hipStream_t s = (hipStream_t)stream;
     const int V = views->num_views;
     // mode 0 (a zero-initialised struct) = the best the workspace allows: 4 (culling chosen on the device) with
-    // 512 * V + 64 bytes, 1 (table kernel) with 256 * V, the table-free kernel without a workspace
+    // 512 * V + 64 bytes, 1 (table kernel) with 256 * V
     int mode = views->mode;
     if (mode == 0) mode = (views->workspace && views->workspace_bytes >= (int64_t)V * 512 + 64) ? 4 : 1;
     if (mode == 3 || mode == 4) {
@@ -794,7 +768,7 @@ int dd_floater_votes(const DDFilterViews *views, const float *xyz, const float *
         hipLaunchKernelGGL(votes_prepare64, dim3((unsigned)((V + 63) / 64)), dim3(64), 0, s, views->cams, tab, V, views->height, views->width);
         hipLaunchKernelGGL(floater_votes_kernel2, dim3((unsigned)blocks), dim3(256), 0, s, a, (const double *)tab, (const unsigned long long *)nullptr);
     } else
-        hipLaunchKernelGGL(floater_votes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        return fail("a workspace of at least 256 * num_views bytes is required (ABI 10: the table-free kernel of round 1 is gone)");
     if (hipGetLastError() != hipSuccess) { snprintf(g_ferr, sizeof(g_ferr), "floater_votes launch failed"); return DD_ERR_LAUNCH; }
     return DD_OK;
 }

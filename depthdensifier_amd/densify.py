@@ -210,6 +210,7 @@ class PendingCheck:
 
     def __init__(self, builder: "CloudBuilder", slot: torch.Tensor, nws: int, workspaces: list, event, late=()):
         self._b, self._slot, self._nws, self._ws, self._event, self._late = builder, slot, nws, workspaces, event, list(late)
+        self._epoch = builder._epoch                 # reset() since then: the cloud asked about is no longer the builder's
 
     def result(self, heal: bool = True) -> int:
         self._event.synchronize()
@@ -220,14 +221,15 @@ class PendingCheck:
         if bad:
             for w in bad:
                 w[:16].zero_()                            # sticky word: cleared only here, once seen
-            if not heal:
+            if not heal or b._epoch != self._epoch:
                 raise RuntimeError("libddcore: in-kernel scan timed out in one of the appended batches (workspace error word set); "
                                    "rows are invalid -- append the batches again with tuning=4")
             total = b._heal()
         if total > b.capacity:
             raise OverflowError(f"cloud capacity {b.capacity} < {total} valid points; "
                                 "allocate with capacity=batch.max_points or count_valid() first")
-        b._release_retained(total)
+        if b._epoch == self._epoch:
+            b._release_retained(total)
         return total
 
 
@@ -590,6 +592,7 @@ class CloudBuilder:
         self._retain_limit = torch.cuda.mem_get_info(dev)[0] // 4
         self._retain_complete = True
         self._retain_base: Optional[int] = None      # row the retained batches start from (None: the cloud's start)
+        self._epoch = 0                              # counts reset(): a PendingCheck knows which cloud it was asked about
         self.healed = 0
 
     def _set_start(self) -> None:
@@ -601,6 +604,7 @@ class CloudBuilder:
             self.cursor.fill_(int(self._start))
 
     def reset(self) -> None:
+        self._epoch += 1
         self._set_start()
         self._offsets.clear()
         self._workspaces.clear()

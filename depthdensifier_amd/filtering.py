@@ -52,7 +52,7 @@ def filter_cameras(intrinsics: ArrayLike, cam_from_world: ArrayLike) -> np.ndarr
     return cams
 
 
-VOTE_MODES = {"auto": 4, "float64": 1, "float64_classic": 1, "float64_cull": 3, "float64_cull1": 3}
+VOTE_MODES = {"auto": 4, "float64": 1, "float64_cull": 3, "float64_cull1": 3}
 
 
 def floater_votes(points: torch.Tensor, normals: torch.Tensor, depth: ArrayLike, intrinsics: ArrayLike,
@@ -69,8 +69,8 @@ def floater_votes(points: torch.Tensor, normals: torch.Tensor, depth: ArrayLike,
     ``"float64_cull1"`` = the same without the super-tile masks (level 1 of the cull), for A/B;
     ``"float64"`` = every decision in float64, the fastest un-culled form on MI355X (division-free image-bounds
     test first, grazing second, reciprocal only for pairs that reach the lookup; a 256-byte table per view is built in a
-    scratch buffer); ``"float64_classic"`` = the round-1 kernel (projection with a reciprocal for every pair in front of
-    the camera; needs no scratch -- what a C caller gets with ``workspace = NULL``).  (The float32 first pass of round 2 --
+    scratch buffer).  (The round-1 kernel -- a reciprocal for every pair in front of the camera, no scratch -- was removed
+    in round 4, the float32 first pass of round 2 --
     same votes, 0.7-0.8x the rate -- was removed in round 3.)  ``stats`` (a dict) receives ``pairs`` and, in auto mode, the
     counters of the on-device choice (one host synchronisation)."""
     if mode not in VOTE_MODES:
@@ -104,7 +104,7 @@ def floater_votes(points: torch.Tensor, normals: torch.Tensor, depth: ArrayLike,
     V, H, W = d.shape
     # culling modes: two 256-byte tables per view, the decision counters, one mask of V bits per 65 536 points (level 1)
     cull_bytes = 512 * V + 64 + -(-pts.shape[0] // 65536) * (-(-V // 64)) * 8
-    ws_bytes = {"float64": 256 * V, "float64_classic": 16, "float64_cull": cull_bytes, "float64_cull1": 512 * V + 64, "auto": cull_bytes}[mode]
+    ws_bytes = {"float64": 256 * V, "float64_cull": cull_bytes, "float64_cull1": 512 * V + 64, "auto": cull_bytes}[mode]
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     fv = DDFilterViews(num_views=V, height=H, width=W, depth=d.data_ptr(), mask=None if m is None else m.data_ptr(),
                        cams=cams.data_ptr(), grazing_cos=GRAZING_COS, depth_threshold=float(depth_threshold),

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 9
+#define DD_ABI_VERSION 10
 
 enum {
     DD_OK = 0,
@@ -214,16 +214,16 @@ typedef struct DDFilterViews {
     double grazing_cos;     /* 0.087, scripts/test.py:295 */
     float depth_threshold;  /* FilteringConfig.depth_threshold = 0.7, scripts/test.py:45-46, 320 */
     float reserved2;
-    void *workspace;        /* device scratch, 32-byte aligned, or NULL.  NULL: the table-free float64 kernel of round 1.
-                               >= 256 * num_views bytes: the float64 kernel builds a per-view table there (K [R|t] and a band
-                               coefficient) and tests the image bounds without the division -- same votes, 5-10 % faster on
-                               coherent normal maps.  >= 512 * num_views + 64 bytes: per-workgroup view culling becomes
+    void *workspace;        /* device scratch, 32-byte aligned, at least 256 * num_views bytes (ABI 10; the table-free kernel that a
+                               NULL workspace selected up to ABI 9 was removed): the float64 kernel builds a per-view table there
+                               (K [R|t] and a band coefficient) and tests the image bounds without the division.
+                               >= 512 * num_views + 64 bytes: per-workgroup view culling becomes
                                possible (a view is skipped for 256 consecutive points when their bounding sphere cannot touch
                                its frustum -- conservative, same votes); with ceil(n / 65536) * ceil(num_views / 64) * 8 bytes
                                more (dd_votes_workspace_bytes() covers it) the cull is two-level: a mask of visible views per
                                65 536 consecutive points first */
     int64_t workspace_bytes;
-    int32_t mode;           /* 0 = the best the workspace allows (4, else 1, else the table-free kernel); 1 = float64 with
+    int32_t mode;           /* 0 = the best the workspace allows (4, else 1); 1 = float64 with
                                the table, no culling; 3 = culling always; 4 = 1 or 3, chosen on the device from a sample of
                                the workgroups (culling when it removes more than 10 % of the workgroup x view cells);
                                2 = removed (the float32 first pass of ABI 8) */

@@ -82,8 +82,8 @@ def test_gpu_votes_match_oracle(with_mask):
     ref = forc.floater_votes(pts[fin], cloud.normals.cpu().numpy()[fin], culled, K, d["cam_from_world"])
     assert ref.max() >= 3, "scene too tame to exercise the vote path"
     assert np.array_equal(votes[fin], ref)
-    classic = dd.floater_votes(cloud.points, cloud.normals, depth_in, K, d["cam_from_world"], mask=mask, mode="float64_classic")
-    assert np.array_equal(classic.cpu().numpy(), votes)             # the round-1 kernel (no scratch table): same votes
+    plain = dd.floater_votes(cloud.points, cloud.normals, depth_in, K, d["cam_from_world"], mask=mask, mode="float64")
+    assert np.array_equal(plain.cpu().numpy(), votes)               # the un-culled kernel: same votes as the default (auto)
     # accumulate over view chunks == one call
     v2 = dd.floater_votes(cloud.points, cloud.normals, depth_in[:3], K[:3], d["cam_from_world"][:3], mask=None if mask is None else mask[:3])
     v2 = dd.floater_votes(cloud.points, cloud.normals, depth_in[3:], K[3:], d["cam_from_world"][3:], mask=None if mask is None else mask[3:], votes=v2)
@@ -109,8 +109,8 @@ def test_gpu_votes_random_scenes(seed):
     culled = np.where(d["mask"], depth, 0).astype(np.float32)
     ref = forc.floater_votes(cloud.points.cpu().numpy(), cloud.normals.cpu().numpy(), culled, K, d["cam_from_world"], depth_threshold=thr)
     assert np.array_equal(votes, ref)
-    classic = dd.floater_votes(cloud.points, cloud.normals, depth, K, d["cam_from_world"], mask=d["mask"], depth_threshold=thr, mode="float64_classic")
-    assert np.array_equal(classic.cpu().numpy(), ref)
+    plain = dd.floater_votes(cloud.points, cloud.normals, depth, K, d["cam_from_world"], mask=d["mask"], depth_threshold=thr, mode="float64")
+    assert np.array_equal(plain.cpu().numpy(), ref)
 
 
 @pytest.mark.gpu
@@ -147,7 +147,7 @@ def test_gpu_votes_on_decision_boundaries():
     ref = forc.floater_votes(pts, nrm, depth, K, E)
     got = dd.floater_votes(torch.from_numpy(pts).cuda(), torch.from_numpy(nrm).cuda(), depth, K, E).cpu().numpy()
     assert np.array_equal(got, ref)
-    got = dd.floater_votes(torch.from_numpy(pts).cuda(), torch.from_numpy(nrm).cuda(), depth, K, E, mode="float64_classic").cpu().numpy()
+    got = dd.floater_votes(torch.from_numpy(pts).cuda(), torch.from_numpy(nrm).cuda(), depth, K, E, mode="float64").cpu().numpy()
     assert np.array_equal(got, ref)
     assert 0 < (ref[-20000:] > 0).mean() < 1 and ref[:-20000].max() == 3 and ref[:-20000].min() == 0     # both outcomes occur
 
@@ -238,7 +238,7 @@ def test_every_vote_kernel_gives_the_oracle_votes_on_special_points():
     pts[100:110] = float("nan"); pts[110:120] = float("inf"); pts[120:130] = 3e30; nrm[130:140] = float("nan")
     pts[140:150] *= 1e-30                                                      # underflow territory
     v64 = dd.floater_votes(pts, nrm, depth_in, K, E, mask=d["mask"], mode="float64")
-    for mode in ("float64_classic", "float64_cull", "float64_cull1", "auto"):
+    for mode in ("float64", "float64_cull", "float64_cull1", "auto"):
         assert torch.equal(dd.floater_votes(pts, nrm, depth_in, K, E, mask=d["mask"], mode=mode), v64), mode
     fin = torch.isfinite(pts).all(dim=1).cpu().numpy()                         # and the oracle on every finite point
     culled = np.where(d["mask"], depth_in, 0).astype(np.float32)
@@ -300,12 +300,12 @@ def test_view_culling_keeps_the_votes(layout, normals):
     depth_in = np.where(np.isfinite(d["depth"]), d["depth"], 0).astype(np.float32)
     cloud = dd.unproject_views(d["depth"], d["params"], E, mask=d["mask"], normal=d["normal"])     # inf depths -> inf points
     res, stats = {}, {}
-    for mode in ("float64_classic", "float64", "float64_cull", "float64_cull1", "auto"):
+    for mode in ("float64", "float64_cull", "float64_cull1", "auto"):
         st = {}
         res[mode] = dd.floater_votes(cloud.points, cloud.normals, depth_in, K, E, mask=d["mask"], mode=mode, stats=st).cpu().numpy()
         stats[mode] = st
     for mode in ("float64", "float64_cull", "float64_cull1", "auto"):
-        assert np.array_equal(res[mode], res["float64_classic"]), mode
+        assert np.array_equal(res[mode], res["float64"]), mode
     pts = cloud.points.cpu().numpy()
     fin = np.isfinite(pts).all(axis=1)
     culled = np.where(d["mask"], depth_in, 0).astype(np.float32)
@@ -321,7 +321,7 @@ def test_view_culling_keeps_the_votes(layout, normals):
     # accumulating over chunks of views goes through the same choice per call
     v2 = dd.floater_votes(cloud.points, cloud.normals, depth_in[:5], K[:5], E[:5], mask=d["mask"][:5], mode="float64_cull")
     v2 = dd.floater_votes(cloud.points, cloud.normals, depth_in[5:], K[5:], E[5:], mask=d["mask"][5:], votes=v2, mode="auto")
-    assert np.array_equal(v2.cpu().numpy(), res["float64_classic"])
+    assert np.array_equal(v2.cpu().numpy(), res["float64"])
 
 
 @pytest.mark.gpu

@@ -136,8 +136,8 @@ def test_hip_votes_and_compaction_equal_the_reference_loop(gvotes):
         dthr, vthr = float(g[f"{tag}_in_thresholds"][0]), int(g[f"{tag}_in_thresholds"][1])
         votes = dd.floater_votes(pts, nrm, g["in_depth"], g["in_K"], g["in_cam_from_world"], depth_threshold=dthr)
         assert np.array_equal(votes.cpu().numpy(), g[f"{tag}_exp_floater_votes{VTAG}"])
-        classic = dd.floater_votes(pts, nrm, g["in_depth"], g["in_K"], g["in_cam_from_world"], depth_threshold=dthr, mode="float64_classic")
-        assert np.array_equal(classic.cpu().numpy(), g[f"{tag}_exp_floater_votes{VTAG}"])
+        plain = dd.floater_votes(pts, nrm, g["in_depth"], g["in_K"], g["in_cam_from_world"], depth_threshold=dthr, mode="float64")
+        assert np.array_equal(plain.cpu().numpy(), g[f"{tag}_exp_floater_votes{VTAG}"])
         cloud = dd.FusedCloud(points=pts, colors=col, normals=nrm, pixel_index=None, view_index=None,
                               view_offsets=torch.tensor([0, len(pts)], dtype=torch.int64, device="cuda"))
         kept = dd.compact_cloud(cloud, votes, vthr)

@@ -13,7 +13,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_IN
   timeout -k 10 400 rocprofv3 --pmc $set --kernel-include-regex "floater_votes" --kernel-trace --output-format csv -d "$OUT/set$i" -- \
       python3 "$R/tools/bench_filter.py" --views "$V" $EXTRA > "$OUT/set$i.log" 2>&1 || echo "set$i failed"
 done
-python3 - "$OUT" <<'PY'
+PMC_VOTES_VIEWS=$V python3 - "$OUT" <<'PY'
 import csv, sys, json, re
 from collections import defaultdict
 from pathlib import Path
@@ -30,7 +30,8 @@ for kern, a in avg.items():
         a["valu_active_per_sq_busy_cycle"] = a["SQ_ACTIVE_INST_VALU"] / a["SQ_BUSY_CYCLES"]
     if a.get("SQ_THREAD_CYCLES_VALU") and a.get("SQ_ACTIVE_INST_VALU"):
         a["lanes_active_fraction"] = a["SQ_THREAD_CYCLES_VALU"] / a["SQ_ACTIVE_INST_VALU"] / 64
-json.dump(avg, open(out / "summary.json", "w"), indent=1)
+import os
+json.dump({"views": int(os.environ.get("PMC_VOTES_VIEWS", "48")), "counters": avg}, open(out / "summary.json", "w"), indent=1)
 print(json.dumps(avg, indent=1))
 PY
 rm -rf "$OUT"/set*/
