@@ -199,12 +199,29 @@ int scout_one(DDArena *A, int *chunk_out) {
     float *w = reinterpret_cast<float *>(slot_ptr(A, slot));
     int rc;
     if (A->n_classes == 0) {
-        // the very first chunk: anchor of class 0; its two halves give the same-class level
-        float ms;
-        if ((rc = probe_pair(A, w, reinterpret_cast<float *>(slot_ptr(A, slot) + A->chunk / 2), &ms)) != DD_OK) return rc;
+        // the very first chunk: anchor of class 0; windows inside it give the same-class level -- IF it lies inside one class.
+        // The classes meet at two places of the physical memory that are not chunk-aligned: a first chunk that straddles one
+        // would set same_ms to the CROSS-class level, every later pair would look "same class" and every allocation would end up
+        // in class 0.  Three windows (first, middle, last) must agree pairwise; a chunk in which they do not is set aside as
+        // mixed and the next chunk scouted takes its place.
+        float *mid = reinterpret_cast<float *>(slot_ptr(A, slot) + A->chunk / 2);
+        float *last = reinterpret_cast<float *>(slot_ptr(A, slot) + A->chunk - A->rows * 12);
+        float ms, ms_fl, ms_ml;
+        if ((rc = probe_pair(A, w, mid, &ms)) != DD_OK) return rc;
+        if ((rc = probe_pair(A, w, last, &ms_fl)) != DD_OK) return rc;
+        if ((rc = probe_pair(A, mid, last, &ms_ml)) != DD_OK) return rc;
+        const float lo = fminf(ms, fminf(ms_fl, ms_ml)), hi = fmaxf(ms, fmaxf(ms_fl, ms_ml));
+        if (lo < 0.91f * hi) {
+            A->chunks[ci].cls = -1;
+            A->mixed += 1;
+            if (A->debug) fprintf(stderr, "[ddarena] chunk %d: the first, windows %.4f / %.4f / %.4f ms -> two classes inside, not used\n", ci, ms, ms_fl, ms_ml);
+            *chunk_out = ci;
+            return DD_OK;
+        }
+        ms = hi;
         A->same_ms = ms;
         A->fast_ms = ms;
-        if (A->debug) fprintf(stderr, "[ddarena] chunk %d: the first, its two halves %.4f ms -> anchor of class 0\n", ci, ms);
+        if (A->debug) fprintf(stderr, "[ddarena] chunk %d: the first, its windows %.4f ms -> anchor of class 0\n", ci, ms);
         A->chunks[ci].cls = 0;
         A->chunks[ci].anchor = true;
         A->anchors[0] = ci;
@@ -454,9 +471,11 @@ int dd_arena_alloc(DDArena *A, int32_t n, const int64_t *sizes, const int32_t *g
         ptrs_out[i] = built[i].va;
     }
     // what was scouted and not needed goes back to the driver, but for a few spares per class (the anchors stay)
+    // (the arrays are built and handed out from here on: a failure to unmap or release a SPARE chunk is not the caller's problem --
+    // returning it would make the caller drop arrays that stay mapped; the chunk simply stays with the arena until the next trim)
     for (size_t ci = 0; ci < A->chunks.size(); ++ci)
         if (A->chunks[ci].live && !A->chunks[ci].used && !A->chunks[ci].anchor) {
-            if ((rc = pool_or_release(A, (int)ci)) != DD_OK) return rc;
+            if (pool_or_release(A, (int)ci) != DD_OK) (void)hipGetLastError();
         }
     if (degraded) A->degraded += 1;
     A->seconds += now_s() - t_start;

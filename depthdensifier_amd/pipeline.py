@@ -205,8 +205,9 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
     for im in mine:
         pw, ph = _processing_size(config.paths.image_dir / im.name, f)
         capacity += (-(-ph // s)) * (-(-pw // s))
-    # (views are appended one at a time here: launches of 26 us whose rows sit in one chunk anyway -- no placement scouting)
-    builder = CloudBuilder(capacity, normals=True, colors=True, pixel_index=False, device=device, placement="first")
+    # (views are appended a few at a time here: launches of 26 us whose rows sit in one chunk anyway -- the default rule applies: a
+    # placed cloud when the scan is large or the arena already holds classified spares from an earlier scan, no scouting otherwise)
+    builder = CloudBuilder(capacity, normals=True, colors=True, pixel_index=False, device=device)
     cached = []                                                                 # :128 cached_refinement_data
     stage = {"image_decode": 0.0, "depth_source": 0.0, "refine": 0.0, "densify": 0.0}     # host seconds per stage
     clock = time.perf_counter

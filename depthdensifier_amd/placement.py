@@ -208,6 +208,29 @@ def place_arrays(specs: Dict[str, Tuple[Sequence[int], torch.dtype, int]], devic
     return tensors, rep
 
 
+def _spares_cover(specs: Dict[str, Tuple[Sequence[int], torch.dtype, int]], device) -> bool:
+    """True when the device's arena already exists and its pool of classified spare chunks can serve ``specs`` with the two
+    lock-step arrays (points, normals) in different classes -- placing the cloud then costs no scouting at all, whatever its size
+    (round 4: a 60-view scan or a scene of a batch after the first takes a placed cloud too)."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    with _arenas_lock:
+        arena = _arenas.get(idx)
+    if arena is None:
+        return False
+    try:
+        st = arena.stats()
+    except ArenaError:
+        return False
+    chunk = max(int(st["chunk_bytes"]), 1)
+    need = sorted((-(-int(np.prod(shape, dtype=np.int64)) * torch.empty((), dtype=dt).element_size() // chunk) for shape, dt, _ in specs.values()), reverse=True)
+    have = sorted(st["chunks_pooled"], reverse=True)
+    # the largest arrays (points, normals) each from a class of their own, the rest (colours) from whatever is left
+    if len(need) >= 2:
+        return have[0] >= need[0] and have[1] >= need[1] and sum(have) >= sum(need)
+    return sum(have) >= sum(need)
+
+
 def _summary(classes: list) -> list:
     """Class sequence of an array's chunks, condensed: [0, 1, 2, 0] stays, long ones become a description."""
     if len(classes) <= 6:
@@ -232,9 +255,10 @@ def place_outputs(capacity: int, *, colors: bool, device, mode: Optional[str] = 
         specs["colors"] = ((n, 3), torch.uint8, codes[2])
     explicit = mode is not None
     mode = mode or default_mode()
-    if mode != "first" and n < MIN_ROWS and not explicit:
+    if mode != "first" and n < MIN_ROWS and not explicit and not _spares_cover(specs, device):
         t, rep = place_arrays(specs, device, "first")
-        rep.mode = f"skipped: {n} rows < {MIN_ROWS} (scouting the memory costs more than a cloud this small wins back; placement='probed' forces it)"
+        rep.mode = (f"skipped: {n} rows < {MIN_ROWS} and the arena holds no classified spare chunks for them (scouting the memory costs "
+                    "more than a cloud this small wins back; placement='probed' forces it)")
     else:
         t, rep = place_arrays(specs, device, mode)
     if rep.mode == "probed":

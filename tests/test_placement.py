@@ -117,9 +117,25 @@ def test_placed_cloud_equals_unplaced_cloud(gpu):
 
 
 @pytest.mark.gpu
-def test_small_clouds_are_left_alone(gpu):
+def test_small_clouds_are_left_alone_unless_spares_are_at_hand(gpu):
+    """Below the threshold a cloud is allocated plainly -- scouting the memory would cost more than it wins -- UNLESS the arena
+    already holds classified spare chunks (left by an earlier, larger cloud): then placing costs nothing and is done."""
     import depthdensifier_amd as dd
+    from depthdensifier_amd import placement
+    arena = placement.get_arena(gpu)
+    arena.trim(0)                                                                  # no spares
     b = dd.CloudBuilder(40 << 20, normals=True, colors=True, device=gpu)          # 40 Mi rows: below the default threshold
     assert b.placement is not None and b.placement.mode.startswith("skipped"), b.placement.as_dict()
     b2 = dd.CloudBuilder(1000, normals=False, colors=False, device=gpu)
     assert b2.placement is None
+    del b, b2
+    arena.trim(4)                                                                  # the default pool again: 4 spares per class
+    big = dd.CloudBuilder(100 << 20, normals=True, colors=True, device=gpu, placement="probed")     # scouts, then leaves its chunks as spares
+    assert big.placement.mode == "probed"
+    del big
+    gc.collect()
+    assert sum(arena.stats()["chunks_pooled"]) >= 3
+    probes = arena.stats()["probes"]
+    small = dd.CloudBuilder(40 << 20, normals=True, colors=True, device=gpu)
+    assert small.placement.mode == "probed" and small.placement.classes["points"][0] != small.placement.classes["normals"][0], small.placement.as_dict()
+    assert arena.stats()["probes"] == probes                                       # served from the pool: nothing was scouted
