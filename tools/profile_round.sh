@@ -6,7 +6,7 @@
 # then tools/profile_collect.py condenses them into profiles/ (kernel-stats CSVs, traffic.json).
 #   usage: tools/profile_round.sh <outdir> [workload tags...]      tags: garden185 bernoulli mip360conf roofline12mp scene2000
 set -uo pipefail
-OUT=$(realpath -m "$1"); shift
+OUT=$(realpath -m "$1"); shift          # (raw traces are large: give a directory under /tmp, not under gpurun_out/ -- only 64 MiB travel back)
 R=$(cd "$(dirname "$0")/.." && pwd)
 TAGS=${@:-garden185 bernoulli mip360conf roofline12mp}
 export TMPDIR=/tmp
