@@ -351,7 +351,9 @@ def test_floater_votes_argument_errors():
         rc = lib.dd_floater_votes(C.byref(_lib.DDFilterViews(**f)), pts.data_ptr(), nrm.data_ptr(), n, out.data_ptr(), 0, stream)
         return rc, lib.dd_filter_last_error().decode()
 
-    assert call()[0] == 0
+    rc, msg = call()                                                                  # ABI 10: no workspace, no kernel
+    assert rc == -1 and "256 * num_views" in msg
+    assert call(workspace=ws.data_ptr(), workspace_bytes=256 * V)[0] == 0
     rc, msg = call(mode=7)
     assert rc == -1 and "mode" in msg
     rc, msg = call(mode=4)
