@@ -23,8 +23,12 @@ def _port():
 
 def _torchrun(nproc, env_extra, timeout=150):
     env = dict(os.environ, **env_extra)
-    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
-                           "--master-port", str(_port()), str(ROOT / "tests" / "fuse_worker.py")], capture_output=True, text=True, timeout=timeout, env=env)
+    for attempt in range(3):            # the port found free a moment ago can be taken by the time the rendezvous binds it: another one then
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+                            "--master-port", str(_port()), str(ROOT / "tests" / "fuse_worker.py")], capture_output=True, text=True, timeout=timeout, env=env)
+        if r.returncode == 0 or "EADDRINUSE" not in r.stderr:
+            break
+    return r
 
 
 def test_rccl_world1_in_process():
