@@ -182,6 +182,8 @@ def cpu_baseline(cfg: dict, scene: dict, params: np.ndarray, E: np.ndarray, budg
                   f"{np.__version__} (the reference is one Python process; oracle/densify_oracle.py)",
         "mpoints_per_s": round(pts / t_total / 1e6, 3),
         "reference_formulation": lit,
+        "note": "SURVEY.md / BASELINE.md quote 1.4 Mpixels/s for the same block: that probe ran in the survey container (one thread of a "
+                "2.1 GHz Xeon, a slower host than the GPU box's) -- the figure here is measured on this box, now",
     }
 
 

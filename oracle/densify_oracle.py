@@ -151,7 +151,9 @@ def densify_view_script_literal(depth: np.ndarray, params, cam_from_world: np.nd
     int64 grids (``:212``), fancy-index gathers of colours / normals / depths with int64 index pairs
     (``:216, 220, 229``), ``np.stack`` of the pixel pairs (``:231``), ``unproject_points`` (``:79-90``:
     three float64 temporaries + ``np.stack``) and the rigid inverse (``:233``).  Same results as
-    :func:`densify_view_script`, which reaches them with ``np.nonzero`` on a strided view (~20x faster).
+    :func:`densify_view_script`, which reaches them with ``np.nonzero`` on a strided view -- about the same speed on the GPU
+    box's host (27.7 against 26.2 Mpixels/s in ``BENCH_r03.json``; the "~20x" once written here came from the slower survey
+    container and an earlier form of the port).
     """
     refined = np.array(depth, copy=True)
     refined[~np.asarray(mask, bool)] = 0
