@@ -95,8 +95,11 @@ typedef struct DDViewBatch {
     int32_t view_index_base;  /* added to the per-point view index (global view id of view 0) */
     uint32_t tuning;          /* 0 = default; 1 = force the scalar kernels; 4 / 8 = dd_unproject_compact as
                                  plan + scatter / as the single-pass look-back kernel (default on stride-1 maps);
+                                 32 = rows in list order (no shift of the wave runs onto 128-byte lines; A/B);
                                  64 = fault injection for tests: the look-back gives up at its first wait and sets the
-                                 workspace's error word */
+                                 workspace's error word; 128 = tiles whose pixels all survive take the list-free path
+                                 (LDS-staged, line-aligned 16-byte stores; same rows, a third of the instructions, not
+                                 faster -- DESIGN.md section 4; not with the 16-byte record or rotated normals) */
     float *refined_out;       /* DD_REFINE: NULL, or (V,H,W) float32 receiving the refined, mask-zeroed depth -- the map the
                                  reference caches for the multi-view filter (scripts/test.py:194, 197-201) */
 } DDViewBatch;
