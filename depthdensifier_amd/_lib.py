@@ -118,6 +118,7 @@ class DDFilterViews(C.Structure):
 
 
 DD_ARENA_ROTATED = 8
+DD_ARENA_BLOCKED = 16
 
 
 class DDArenaStats(C.Structure):

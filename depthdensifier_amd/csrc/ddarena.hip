@@ -370,10 +370,11 @@ int dd_arena_alloc(DDArena *A, int32_t n, const int64_t *sizes, const int32_t *g
     for (int i = 0; i < n; ++i) {
         if (sizes[i] <= 0) return afail(DD_ERR_INVALID_ARG, "sizes must be positive");
         const int L = groups[i];
-        const bool pure = L >= 0 && L < MAX_CLASSES, rotated = L >= DD_ARENA_ROTATED && L < DD_ARENA_ROTATED + MAX_CLASSES;
-        if (!pure && !rotated) return afail(DD_ERR_INVALID_ARG, "layouts must be a group 0..2 or DD_ARENA_ROTATED + phase 0..2");
+        const bool pure = L >= 0 && L < MAX_CLASSES, rotated = L >= DD_ARENA_ROTATED && L < DD_ARENA_ROTATED + MAX_CLASSES, blocked = L == DD_ARENA_BLOCKED;
+        if (!pure && !rotated && !blocked) return afail(DD_ERR_INVALID_ARG, "layouts must be a group 0..2, DD_ARENA_ROTATED + phase 0..2 or DD_ARENA_BLOCKED");
         nch[i] = (int)(((size_t)sizes[i] + A->chunk - 1) / A->chunk);
         if (pure) need[L] += nch[i];
+        else if (blocked) for (int k = 0; k < nch[i]; ++k) fixed[std::min(MAX_CLASSES - 1, k * MAX_CLASSES / nch[i])] += 1;
         else for (int k = 0; k < nch[i]; ++k) fixed[(L - DD_ARENA_ROTATED + k) % MAX_CLASSES] += 1;
         ptrs_out[i] = nullptr;
     }

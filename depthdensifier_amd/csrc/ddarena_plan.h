@@ -9,7 +9,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "ddcore.h"      // DD_ARENA_ROTATED
+#include "ddcore.h"      // DD_ARENA_ROTATED, DD_ARENA_BLOCKED
 
 namespace ddarena_plan {
 
@@ -50,9 +50,26 @@ inline void plan_classes(const int avail_in[MAX_CLASSES], int n, const std::vect
     *missing = 0; *conflicts = 0;
     auto any_class = [&]() { int b = -1; for (int c = 0; c < MAX_CLASSES; ++c) if (avail[c] > 0 && (b < 0 || avail[c] > avail[b])) b = c; return b; };
     for (int i = 0; i < n; ++i) {
-        if (layouts[i] >= MAX_CLASSES) continue;
+        if (layouts[i] < 0 || layouts[i] >= MAX_CLASSES) continue;
         for (int k = 0; k < nch[i]; ++k) {
             int c = perm[layouts[i]];
+            if (avail[c] <= 0) { c = any_class(); if (c >= 0) *conflicts += 1; }
+            if (c < 0) { *missing += 1; choice[i].push_back(-1); continue; }
+            avail[c] -= 1;
+            choice[i].push_back(c);
+        }
+    }
+    // Blocked arrays (DD_ARENA_BLOCKED): the first, middle and last third of the array's chunks each from a class of its own
+    // (the thirds go to the classes in the order of their supply: the driver hands out long stretches of one class, so a
+    // blocked array is what it gives most readily).  A chunk that has to come from another class than its third's counts
+    // as a conflict (scouting goes on while the budget lasts).
+    for (int i = 0; i < n; ++i) {
+        if (layouts[i] != DD_ARENA_BLOCKED) continue;
+        int order[MAX_CLASSES] = {0, 1, 2};
+        std::sort(order, order + MAX_CLASSES, [&](int x, int y) { return avail[x] != avail[y] ? avail[x] > avail[y] : x < y; });
+        for (int k = 0; k < nch[i]; ++k) {
+            const int third = std::min(MAX_CLASSES - 1, (int)(((long long)k * MAX_CLASSES) / std::max(nch[i], 1)));
+            int c = order[third];
             if (avail[c] <= 0) { c = any_class(); if (c >= 0) *conflicts += 1; }
             if (c < 0) { *missing += 1; choice[i].push_back(-1); continue; }
             avail[c] -= 1;

@@ -91,6 +91,7 @@ struct KArgs {
     int align_runs;               // lean kernels: shift the sweeps so that wave runs start on 128-byte lines (default on)
     unsigned spin_limit;          // look-back polls before a tile gives up (SPIN_LIMIT; 0 with the fault-injection tuning bit 64)
     int dense_ok;                 // lean kernels: tiles whose pixels all survive take the list-free path (dense_wave)
+    unsigned order_regions;       // two-pass scatter: 1 = tiles in order, K > 1 = K stretches of the batch interleaved (tuning bits 8-11)
 };
 
 
@@ -630,6 +631,9 @@ __device__ __forceinline__ long long lookback13(unsigned long long *state, unsig
 #ifndef DD_DENSE
 #define DD_DENSE 1
 #endif
+#ifndef DD_GATHER_DEPTH
+#define DD_GATHER_DEPTH 2         // point sets in flight per lane in the list path's sweeps (3: measured in round 4)
+#endif
 constexpr int DENSE_CHUNK = 256;                                  // rows staged per flush: 3072 B = 3 wave stores of 1 KiB
 constexpr int DENSE_STAGE = DENSE_CHUNK * 12 + 128 + 16;          // + the line phase (< 128 B) + slack to a 16-byte multiple
 constexpr int DENSE_LDS_PER_WAVE = DENSE_STAGE + 1024;            // + one 16-byte depth vector per lane
@@ -762,7 +766,6 @@ __device__ __forceinline__ void dense_wave(const KArgs &a, const uint4 (&d)[L_PX
     const unsigned rows = room < (long long)L_WSPAN ? (unsigned)room : (unsigned)L_WSPAN;   // < L_WSPAN only where the capacity cuts the cloud
 
     // ---- xyz ----
-#ifndef DD_X_NOXYZ
     if (a.out_xyz) {
         float *const stage_f = reinterpret_cast<float *>(lds);
         unsigned *const stage_u = reinterpret_cast<unsigned *>(lds);
@@ -829,22 +832,16 @@ __device__ __forceinline__ void dense_wave(const KArgs &a, const uint4 (&d)[L_PX
             if (o < 128u && o < sc.hi) put16<4>(sc, o, *reinterpret_cast<const uint4 *>(lds + o));
         }
     }
-#endif
-#ifndef DD_X_NONRM
     // ---- normals: a shifted copy of 12 KiB (camera-frame normals pass through, scripts/test.py:220) ----
     if constexpr (HAS_NORMAL) {
         const Span sn = make_span(a.out_normal, row0, 12u, rows);
         span_copy<4, L_WSPAN * 12 / 1024 + 1, u32x4_a4>(sn, reinterpret_cast<const unsigned char *>(a.normal + (vbase + qw) * 3), lane);
     }
-#endif
-#ifndef DD_X_NORGB
     // ---- colours: a shifted copy of 3 KiB, byte-granular ends ----
     if (HAS_RGB && a.out_rgb != nullptr) {
         const Span sc = make_span(a.out_rgb, row0, 3u, rows);
         span_copy<1, L_WSPAN * 3 / 1024 + 1, u32x4_a1>(sc, a.rgb + (vbase + qw) * 3, lane);
     }
-#endif
-#ifndef DD_X_NOIDX
     // ---- indices: generated ----
     if (a.out_pix) {
         const Span sp = make_span(a.out_pix, row0, 4u, rows);
@@ -862,7 +859,6 @@ __device__ __forceinline__ void dense_wave(const KArgs &a, const uint4 (&d)[L_PX
         for (int i = 0; i < L_WSPAN * 4 / 1024 + 1; ++i)
             span_sweep<4>(sv, i, lane, [&](unsigned) { return make_uint4(id, id, id, id); });
     }
-#endif
 }
 
 // NW = waves per workgroup: 4 (4096-pixel tiles) for the two-pass scatter; the single-pass variant uses 12
@@ -908,6 +904,15 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
 #else
         t = blockIdx.x;
 #endif
+        if (a.order_regions > 1u) {
+            // tiles of K distant stretches of the batch taken in turn: consecutive workgroups write K regions of the output
+            // that lie a K-th of the cloud apart -- in different 1 GiB chunks, i.e. (placed by the arena) in different classes
+            // of HBM.  Only the scatter pass can do this: its rows are known before it starts.
+            const unsigned K = a.order_regions, per = (a.num_tiles + K - 1u) / K;
+            const unsigned b = blockIdx.x, r = b % K, i = b / K;
+            t = r * per + i;
+            if (t >= a.num_tiles) return;
+        }
     }
     const unsigned v = t / a.tiles_per_view;
     const unsigned tv = t - v * a.tiles_per_view;
@@ -1105,20 +1110,15 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
         const int g = BT + (p - end);
         return (g < BT + hrot && g < (int)n) ? g : -1;
     };
-    struct Pt { float x, y, z; f32x3 nr; unsigned rgbw; unsigned q; int j; };
+    // what a lane holds of a point between its gathers and its stores: the depth and the pixel (xyz is computed when the row is
+    // stored: two registers less per point in flight than carrying x, y, z), the gathered normal and colour
+    struct Pt { float d; f32x3 nr; unsigned rgbw; unsigned q; int j; };
     auto prep = [&](int i, Pt &p) {
         const int j = point_of(i);
         p.j = j;
         const int jj = j >= 0 ? j : 0;
         const unsigned q = q0 + s_q[jj];
-        const float dd = s_d[jj];
-        const unsigned r = q - rowstart;                 // < 4096 + W
-        unsigned yo = (unsigned)((float)r * invW);
-        if (yo * W > r) --yo; else if ((yo + 1) * W <= r) ++yo;
-        const float fy = (float)(y0 + yo), fx = (float)(r - yo * W);
-        p.x = fmaf(dd, fmaf(m00, fx, fmaf(m01, fy, m02)), c0);
-        p.y = fmaf(dd, fmaf(m10, fx, fmaf(m11, fy, m12)), c1);
-        p.z = fmaf(dd, fmaf(m20, fx, fmaf(m21, fy, m22)), c2);
+        p.d = s_d[jj];
         p.q = q;
         // scalar base + 32-bit byte offset (a view has < 2^28 pixels on this path): no 64-bit address arithmetic per lane
         if constexpr (HAS_NORMAL) p.nr = *reinterpret_cast<const f32x3 *>(reinterpret_cast<const unsigned char *>(nsrc) + q * 12u);
@@ -1151,8 +1151,15 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
         const int j = p.j;
         const unsigned uj = (unsigned)j;
         const bool act = (j >= 0) && (uj < cap_rows);
+        const unsigned r = p.q - rowstart;               // < 12288 + W
+        unsigned yo = (unsigned)((float)r * invW);
+        if (yo * W > r) --yo; else if ((yo + 1) * W <= r) ++yo;
+        const float fy = (float)(y0 + yo), fx = (float)(r - yo * W);
+        const float px = fmaf(p.d, fmaf(m00, fx, fmaf(m01, fy, m02)), c0);
+        const float py = fmaf(p.d, fmaf(m10, fx, fmaf(m11, fy, m12)), c1);
+        const float pz = fmaf(p.d, fmaf(m20, fx, fmaf(m21, fy, m22)), c2);
         if (act) {
-            f32x3 o; o.x = p.x; o.y = p.y; o.z = p.z;
+            f32x3 o; o.x = px; o.y = py; o.z = pz;
             if (a.out_xyz) {
 #if DD_NT_STORE
                 __builtin_nontemporal_store(o, reinterpret_cast<f32x3 *>(xb + uj * 12u));
@@ -1163,7 +1170,7 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
             if (a.out_packed) {     // one aligned 16-byte store per point: a wave writes 1 KiB of whole lines
                 unsigned c = 0xff000000u;
                 if constexpr (HAS_RGB) c |= p.q ? (p.rgbw >> 8) : (p.rgbw & 0xffffffu);
-                uint4 rec; rec.x = __float_as_uint(p.x); rec.y = __float_as_uint(p.y); rec.z = __float_as_uint(p.z); rec.w = c;
+                uint4 rec; rec.x = __float_as_uint(px); rec.y = __float_as_uint(py); rec.z = __float_as_uint(pz); rec.w = c;
                 *reinterpret_cast<uint4 *>(kb + uj * 16u) = rec;
             }
             if (a.out_pix) *reinterpret_cast<int *>(ib + uj * 4u) = (int)p.q;
@@ -1237,6 +1244,23 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
     }
     set_row_bases();
     if (a.align_runs) hrot = (int)((0ll - excl) & 31ll);
+#if DD_GATHER_DEPTH == 3
+    // the gathers of TWO sweeps in flight behind the sweep that is being stored (three point sets taking turns)
+    Pt pc;
+    prep(1, pb);
+#pragma unroll
+    for (int i = 0; i < NI; i += 3) {
+        if (i + 2 < NI) prep(i + 2, pc);
+        emit(pa);
+        if ((i + 1) * BT >= (int)n) break;
+        if (i + 3 < NI) prep(i + 3, pa);
+        emit(pb);
+        if ((i + 2) * BT >= (int)n) break;
+        if (i + 4 < NI) prep(i + 4, pb);
+        emit(pc);
+        if ((i + 3) * BT >= (int)n) break;
+    }
+#else
 #pragma unroll
     for (int i = 0; i < NI; i += 2) {
         prep(i + 1, pb);
@@ -1246,6 +1270,7 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
         emit(pb);
         if ((i + 2) * BT >= (int)n) break;
     }
+#endif
     if (wave == 0) STAMP(4);
     if (wave == 5) STAMP(11);
     STAMP_END();
@@ -1491,6 +1516,7 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
     // real kernel it is the same rows with a third of the instructions, and 0-5 % SLOWER.
     // The dense path steps x by 64 per lane (width >= 64) and derives rows in float32 (width < 2^23).
     a.dense_ok = (b->tuning & 128u) != 0 && b->width >= 64 && b->width < (1 << 23);
+    a.order_regions = 1u + ((b->tuning >> 8) & 15u);       // tuning bits 8-11 (experiment): the scatter pass interleaves 2 .. 16 stretches of tiles
     a.spin_limit = (b->tuning & 64u) ? 0u : SPIN_LIMIT;   // tuning bit 64: fault injection -- a tile that would have to wait for a
                                                           // predecessor gives up at once, and every eighth tile behaves as if it had:
                                                           // wrong rows, the workspace's error word set (tests of the caller's recovery)
@@ -1536,7 +1562,8 @@ int bind_output(KArgs &a, const DDViewBatch *batch, const DDCloudOut *out) {
 template <typename DepthT, bool SP, bool HM, bool HN>
 void launch_lean3(const KArgs &a, hipStream_t s) {
     constexpr int NW = SP ? SP_WAVES : WAVES;
-    const dim3 grid(a.num_tiles), block(64 * NW);
+    const unsigned K = SP ? 1u : a.order_regions;
+    const dim3 grid(K * ((a.num_tiles + K - 1u) / K)), block(64 * NW);
     if (a.rgb && (a.out_rgb || a.out_packed)) hipLaunchKernelGGL((compact_lean<DepthT, HM, SP, HN, true, NW>), grid, block, 0, s, a);   // colours gathered
     else hipLaunchKernelGGL((compact_lean<DepthT, HM, SP, HN, false, NW>), grid, block, 0, s, a);
 }

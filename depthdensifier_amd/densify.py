@@ -525,6 +525,13 @@ class CloudBuilder:
     the host.  ``finish()`` reads the count once and returns exact-size views.
     """
 
+    # A cloud that is ONE large row array (points, no normals) and was placed with its thirds in three classes of HBM is
+    # filled two-pass with the scatter taking tiles of the three thirds in turn (round 4, DESIGN.md section 4): consecutive
+    # workgroups then write three classes at once -- 0.72 instead of 0.66 of the roofline on BASELINE configs[4], count pass
+    # included.  Below this many rows (3 GiB of points) the count pass costs more than the interleaving wins back.
+    INTERLEAVE_MIN_ROWS = 256 << 20
+    INTERLEAVE_REGIONS = 3
+
     FIELDS = {"points": ((3,), torch.float32), "normals": ((3,), torch.float32), "colors": ((3,), torch.uint8),
               "pixel_index": ((), torch.int32), "view_index": ((), torch.int32), "packed": ((4,), torch.float32)}
 
@@ -554,7 +561,7 @@ class CloudBuilder:
         if not (points or packed):
             raise ValueError("a cloud needs points or the packed record")
         self.placement = None
-        if buffers is None and points and normals:
+        if buffers is None and points and (normals or placement == "probed" or (placement is None and n >= self.INTERLEAVE_MIN_ROWS)):
             # the kernel is bound by its row stores: the row arrays are built from chunks spread over the three classes of HBM
             from . import placement as _placement
             p_xyz, p_nrm, p_rgb, self.placement = _placement.place_outputs(n, colors=colors, normals=normals, device=dev, mode=placement)
@@ -664,17 +671,32 @@ class CloudBuilder:
                 self._offsets.append(offsets)
                 self._retain(batch, offsets)
             return offsets
-        cb = batch.c_struct()
-        ws = self._workspace(batch.workspace_bytes())
-        out = self._out_struct()
-        offsets = _offsets if redo else self._offsets_slice(batch.num_views + 1)
-        check(lib.dd_unproject_compact(C.byref(cb), C.byref(out), offsets.data_ptr(), self.cursor.data_ptr(),
-                                       ws.data_ptr(), ws.numel(), _stream(self.device)))
+        saved = batch.tuning
+        batch.tuning = self.fuse_tuning(batch)
+        try:
+            cb = batch.c_struct()
+            ws = self._workspace(batch.workspace_bytes())
+            out = self._out_struct()
+            offsets = _offsets if redo else self._offsets_slice(batch.num_views + 1)
+            check(lib.dd_unproject_compact(C.byref(cb), C.byref(out), offsets.data_ptr(), self.cursor.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), _stream(self.device)))
+        finally:
+            batch.tuning = saved
         if not redo:
             self._offsets.append(offsets)
             self._workspaces.append(ws)
             self._retain(batch, offsets)
         return offsets
+
+    def fuse_tuning(self, batch: "ViewBatch") -> int:
+        """``DDViewBatch.tuning`` with which ``append`` runs ``batch``: the batch's own, plus -- for a placed cloud of points
+        only whose thirds lie in three classes (``placement.layout == "blocked"``), a large batch, and no explicit choice of
+        a path in the batch's tuning -- two-pass with the scatter interleaving ``INTERLEAVE_REGIONS`` stretches of tiles."""
+        t = batch.tuning
+        if (self.placement is not None and self.placement.layout == "blocked" and self.placement.mode.startswith(("probed", "degraded"))
+                and not (t & (1 | 4 | 8 | 0xF00)) and batch.stride == 1 and batch.max_points >= self.INTERLEAVE_MIN_ROWS // 2):
+            t |= 4 | ((self.INTERLEAVE_REGIONS - 1) << 8)
+        return t
 
     def _out_struct(self) -> DDCloudOut:
         if getattr(self, "_out_cached", None) is None:

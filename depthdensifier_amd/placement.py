@@ -42,6 +42,12 @@ def rotated(phase: int = 0) -> int:
     return _lib.DD_ARENA_ROTATED + int(phase) % 3
 
 
+def blocked() -> int:
+    """Layout code of ONE large row array whose first, middle and last third come from three different classes (a cloud of
+    points only: its scatter pass then takes tiles of the three thirds in turn -- ``CloudBuilder`` does that by itself)."""
+    return _lib.DD_ARENA_BLOCKED
+
+
 def default_layout() -> str:
     """``DD_PLACEMENT_LAYOUT`` = ``rotated`` (default: chunk k of every array from class (phase + k) mod 3, the phases of
     points / normals / colours differ) or ``separated`` (points, normals and colours class-pure in three different classes)."""
@@ -62,7 +68,7 @@ class PlacementReport:
     classes: Optional[Dict[str, list]] = None   # per array: the classes of its chunks
     seconds: float = 0.0
     stats: Optional[dict] = None
-    layout: Optional[str] = None                # "rotated" | "separated"
+    layout: Optional[str] = None                # "rotated" | "separated" | "blocked"
 
     def as_dict(self) -> dict:
         return {"mode": self.mode, "layout": self.layout, "classes": self.classes, "seconds": round(self.seconds, 3), "arena": self.stats}
@@ -237,6 +243,14 @@ def _summary(classes: list) -> list:
         return classes
     if all(classes[k] == (classes[0] + k) % 3 for k in range(len(classes))):
         return [f"{len(classes)} chunks rotating from class {classes[0]}"]
+    runs = [[classes[0], 1]]
+    for c in classes[1:]:
+        if c == runs[-1][0]:
+            runs[-1][1] += 1
+        else:
+            runs.append([c, 1])
+    if len(runs) <= 4:
+        return [" + ".join(f"{k} chunks of class {c}" for c, k in runs)]
     if len(set(classes)) == 1:
         return [f"{len(classes)} chunks of class {classes[0]}"]
     return classes
@@ -248,6 +262,10 @@ def place_outputs(capacity: int, *, colors: bool, device, mode: Optional[str] = 
     n = max(int(capacity), 1)
     layout = layout or default_layout()
     codes = (GROUP_POINTS, GROUP_NORMALS, GROUP_OTHER) if layout == "separated" else (rotated(0), rotated(1), rotated(2))
+    if not normals:
+        # one row stream only: nothing to keep apart at equal rows.  Its thirds go to the three classes instead, and the
+        # scatter pass walks the thirds in turn (DDViewBatch.tuning bits 8-11; CloudBuilder.append decides)
+        layout, codes = "blocked", (blocked(), GROUP_NORMALS, GROUP_OTHER)
     specs = {"points": ((n, 3), torch.float32, codes[0])}
     if normals:
         specs["normals"] = ((n, 3), torch.float32, codes[1])

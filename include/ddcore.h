@@ -314,6 +314,10 @@ typedef struct DDArena DDArena;
  * rotation and two plentiful classes give two class-pure arrays.  Phases 0 and 1 are the ones that must differ (the
  * lock-step store streams); phase 2 (the colours) may share a class when only two are at hand */
 #define DD_ARENA_ROTATED 8
+/* DD_ARENA_BLOCKED = the first, middle and last third of the array's chunks each from a class of its own: for ONE large row
+ * array (a cloud of points only) whose scatter pass takes tiles of the three thirds in turn (DDViewBatch.tuning bits 8-11),
+ * so that consecutive workgroups write three classes at once */
+#define DD_ARENA_BLOCKED 16
 
 typedef struct DDArenaStats {
     int64_t chunk_bytes;

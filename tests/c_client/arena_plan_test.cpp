@@ -90,6 +90,18 @@ int main() {
         best_assignment(avail, none, need, fixed, perm);
         CHECK(perm[0] != 0, "group 0 sent to class %d where the rotated arrays already want 3 of 4", perm[0]);
     }
+    {   // a blocked array: its thirds in three classes, the largest supply first; uneven supply spills over and is counted
+        const int avail[3] = {5, 9, 7};
+        Plan p = plan(avail, {9, 2}, {DD_ARENA_BLOCKED, 2}, ident);        // + a small class-pure array of group 2
+        CHECK(p.missing == 0 && p.conflicts == 0, "missing %d conflicts %d", p.missing, p.conflicts);
+        for (int k = 0; k < 9; ++k) CHECK(p.choice[0][k] == (k < 3 ? 1 : k < 6 ? 0 : 2), "blocked chunk %d in class %d", k, p.choice[0][k]);   // (the group-2 array took 2 of class 2 first: supplies 5, 9, 5)
+        const int thin[3] = {1, 20, 1};
+        Plan q = plan(thin, {9}, {DD_ARENA_BLOCKED}, ident);
+        CHECK(q.missing == 0 && q.conflicts == 4, "thin supply: missing %d conflicts %d", q.missing, q.conflicts);   // thirds two and three find one chunk each
+        const int two[3] = {1, 1, 0};
+        Plan r = plan(two, {2}, {DD_ARENA_BLOCKED}, ident);                 // fewer chunks than classes: still laid out
+        CHECK(r.missing == 0 && r.choice[0].size() == 2 && r.choice[0][0] != r.choice[0][1], "two-chunk blocked array");
+    }
     if (failures) { printf("%d checks failed\n", failures); return 1; }
     printf("plan OK\n");
     return 0;

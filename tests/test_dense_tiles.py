@@ -163,3 +163,58 @@ def test_narrow_views_take_the_list_path(dd):
     E = _ring(V)
     cloud = dd.unproject_views(depth, params, E, view_index=True, tuning=DENSE)
     assert_cloud(cloud, orc.densify_scene_script(depth, params, E), scene_radius(E, depth))
+
+
+@pytest.mark.parametrize("shape", ((3, 211, 307), (1, 70, 70), (2, 128, 400)))
+def test_interleaved_scatter_order_writes_the_same_cloud(dd, shape):
+    """``DDViewBatch.tuning`` bits 8-11: the scatter pass of the two-pass path takes tiles of K = 2 .. 16 stretches of the batch in
+    turn (consecutive workgroups then write K distant regions of the output -- different classes of HBM for a cloud placed in
+    thirds).  Every tile knows its rows before the pass starts, so the order cannot change a byte; K may exceed the number of
+    tiles and need not divide it."""
+    import torch
+    V, H, W = shape
+    depth, mask, normal, rgb = _scene(V, H, W, torch.float32, 21, "blob")
+    params = np.tile([0.8 * W, 0.8 * W, W / 2, H / 2], (V, 1))
+    E = _ring(V)
+    n = int(mask.sum())
+    ref = _build(dd, dd.ViewBatch(depth, params, E, mask=mask, normal=normal, rgb=rgb, tuning=4), n, None, FIELDS, fill=False)
+    want = _arrays(ref)
+    for k in range(1, 16):
+        b = _build(dd, dd.ViewBatch(depth, params, E, mask=mask, normal=normal, rgb=rgb, tuning=4 | (k << 8)), n, None, FIELDS)
+        assert int(b.cursor.item()) == n
+        for name, t in _arrays(b).items():
+            assert torch.equal(t[:n].view(torch.uint8), want[name][:n].view(torch.uint8)), (k + 1, name)
+            assert bool((t[n:] == (201 if name == "colors" else -7)).all()), (k + 1, name)
+
+
+def test_a_blocked_cloud_of_points_is_filled_in_thirds(dd):
+    """A cloud of points only, placed with its thirds in three classes, chooses the interleaved two-pass path by itself for a large
+    batch (``CloudBuilder.fuse_tuning``) and leaves small batches, explicit choices and clouds with normals alone; the cloud it
+    builds is the single-pass cloud."""
+    import torch
+    V, H, W = 40, 1080, 1920                                     # 83 M pixels: above half of a lowered threshold
+    g = torch.Generator(device="cuda").manual_seed(5)
+    depth = torch.empty((V, H, W), device="cuda", dtype=torch.float16).uniform_(0.5, 8.0, generator=g)
+    depth[:, 100:300, 200:900] = 0
+    params = np.tile([0.8 * W, 0.8 * W, W / 2, H / 2], (V, 1))
+    E = _ring(V)
+    batch = dd.ViewBatch(depth, params, E)
+    old = dd.CloudBuilder.INTERLEAVE_MIN_ROWS
+    dd.CloudBuilder.INTERLEAVE_MIN_ROWS = 64 << 20
+    try:
+        b = dd.CloudBuilder(batch.max_points, pixel_index=False, placement="probed")
+        assert b.placement.layout == "blocked", b.placement.as_dict()
+        tun = b.fuse_tuning(batch)
+        assert tun & 4 and (tun >> 8) & 15 == dd.CloudBuilder.INTERLEAVE_REGIONS - 1
+        assert b.fuse_tuning(dd.ViewBatch(depth[:2], params[:2], E[:2])) == 0                 # a small batch: the fused single pass
+        assert b.fuse_tuning(dd.ViewBatch(depth, params, E, tuning=8)) == 8                   # an explicit choice stands
+        b.append(batch)
+        got = b.finish()
+    finally:
+        dd.CloudBuilder.INTERLEAVE_MIN_ROWS = old
+    plain = dd.CloudBuilder(batch.max_points, pixel_index=False, placement="first")
+    assert plain.fuse_tuning(batch) == 0
+    plain.append(batch)
+    want = plain.finish()
+    assert len(got) == len(want) and torch.equal(got.view_offsets, want.view_offsets)
+    assert torch.equal(got.points.view(torch.int32), want.points.view(torch.int32))
