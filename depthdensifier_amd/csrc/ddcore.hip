@@ -91,7 +91,7 @@ struct KArgs {
     int align_runs;               // lean kernels: shift the sweeps so that wave runs start on 128-byte lines (default on)
     unsigned spin_limit;          // look-back polls before a tile gives up (SPIN_LIMIT; 0 with the fault-injection tuning bit 64)
     int dense_ok;                 // lean kernels: tiles whose pixels all survive take the list-free path (dense_wave)
-    unsigned order_regions;       // two-pass scatter: 1 = tiles in order, K > 1 = K stretches of the batch interleaved (tuning bits 8-11)
+    unsigned order_regions;       // two-pass scatter: 1 = tiles in order, K > 1 = K stretches of the batch interleaved (tuning bits 8-13)
 };
 
 
@@ -1516,7 +1516,7 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
     // real kernel it is the same rows with a third of the instructions, and 0-5 % SLOWER.
     // The dense path steps x by 64 per lane (width >= 64) and derives rows in float32 (width < 2^23).
     a.dense_ok = (b->tuning & 128u) != 0 && b->width >= 64 && b->width < (1 << 23);
-    a.order_regions = 1u + ((b->tuning >> 8) & 15u);       // tuning bits 8-11 (experiment): the scatter pass interleaves 2 .. 16 stretches of tiles
+    a.order_regions = 1u + ((b->tuning >> 8) & 63u);       // tuning bits 8-13: the scatter pass interleaves 2 .. 64 stretches of tiles
     a.spin_limit = (b->tuning & 64u) ? 0u : SPIN_LIMIT;   // tuning bit 64: fault injection -- a tile that would have to wait for a
                                                           // predecessor gives up at once, and every eighth tile behaves as if it had:
                                                           // wrong rows, the workspace's error word set (tests of the caller's recovery)

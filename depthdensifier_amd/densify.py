@@ -527,10 +527,10 @@ class CloudBuilder:
 
     # A cloud that is ONE large row array (points, no normals) and was placed with its thirds in three classes of HBM is
     # filled two-pass with the scatter taking tiles of the three thirds in turn (round 4): consecutive
-    # workgroups then write three classes at once -- 0.72 instead of 0.66 of the roofline on BASELINE configs[4], count pass
-    # included.  Below this many rows (3 GiB of points) the count pass costs more than the interleaving wins back.
+    # workgroups then write three classes at once -- 0.705 instead of 0.66 of the roofline on BASELINE configs[4] with the count
+    # pass included, 0.80 for the scatter kernel alone.  Below this many rows (3 GiB of points) the count pass costs more than the interleaving wins back.
     INTERLEAVE_MIN_ROWS = 256 << 20
-    INTERLEAVE_REGIONS = 3
+    INTERLEAVE_REGIONS = 15          # (3 ... 21 stretches are within 1 % of each other, 30 and more lose 2-4 %: profiles/r04_interleaved_scatter.txt)
 
     FIELDS = {"points": ((3,), torch.float32), "normals": ((3,), torch.float32), "colors": ((3,), torch.uint8),
               "pixel_index": ((), torch.int32), "view_index": ((), torch.int32), "packed": ((4,), torch.float32)}
@@ -694,7 +694,7 @@ class CloudBuilder:
         a path in the batch's tuning -- two-pass with the scatter interleaving ``INTERLEAVE_REGIONS`` stretches of tiles."""
         t = batch.tuning
         if (self.placement is not None and self.placement.layout == "blocked" and self.placement.mode.startswith(("probed", "degraded"))
-                and not (t & (1 | 4 | 8 | 0xF00)) and batch.stride == 1 and batch.max_points >= self.INTERLEAVE_MIN_ROWS // 2):
+                and not (t & (1 | 4 | 8 | 0x3F00)) and batch.stride == 1 and batch.max_points >= self.INTERLEAVE_MIN_ROWS // 2):
             t |= 4 | ((self.INTERLEAVE_REGIONS - 1) << 8)
         return t
 

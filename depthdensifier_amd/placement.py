@@ -264,7 +264,7 @@ def place_outputs(capacity: int, *, colors: bool, device, mode: Optional[str] = 
     codes = (GROUP_POINTS, GROUP_NORMALS, GROUP_OTHER) if layout == "separated" else (rotated(0), rotated(1), rotated(2))
     if not normals:
         # one row stream only: nothing to keep apart at equal rows.  Its thirds go to the three classes instead, and the
-        # scatter pass walks the thirds in turn (DDViewBatch.tuning bits 8-11; CloudBuilder.append decides)
+        # scatter pass walks the thirds in turn (DDViewBatch.tuning bits 8-13; CloudBuilder.append decides)
         layout, codes = "blocked", (blocked(), GROUP_NORMALS, GROUP_OTHER)
     specs = {"points": ((n, 3), torch.float32, codes[0])}
     if normals:

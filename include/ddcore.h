@@ -99,7 +99,11 @@ typedef struct DDViewBatch {
                                  64 = fault injection for tests: the look-back gives up at its first wait and sets the
                                  workspace's error word; 128 = tiles whose pixels all survive take the list-free path
                                  (LDS-staged, line-aligned 16-byte stores; same rows, a third of the instructions, not
-                                 faster -- DESIGN.md section 4; not with the 16-byte record or rotated normals) */
+                                 faster -- DESIGN.md section 4; not with the 16-byte record or rotated normals);
+                                 bits 8-13 = K - 1: the scatter pass of the two-pass path (tuning 4 / dd_scatter) takes the tiles
+                                 of K stretches of the batch in turn, so that consecutive workgroups write K distant regions
+                                 of the output -- for ONE large row array whose thirds lie in different classes of HBM
+                                 (DD_ARENA_BLOCKED) that is 0.80 instead of 0.66 of the roofline; rows are the same for every K */
     float *refined_out;       /* DD_REFINE: NULL, or (V,H,W) float32 receiving the refined, mask-zeroed depth -- the map the
                                  reference caches for the multi-view filter (scripts/test.py:194, 197-201) */
 } DDViewBatch;

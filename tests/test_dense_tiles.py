@@ -167,7 +167,7 @@ def test_narrow_views_take_the_list_path(dd):
 
 @pytest.mark.parametrize("shape", ((3, 211, 307), (1, 70, 70), (2, 128, 400)))
 def test_interleaved_scatter_order_writes_the_same_cloud(dd, shape):
-    """``DDViewBatch.tuning`` bits 8-11: the scatter pass of the two-pass path takes tiles of K = 2 .. 16 stretches of the batch in
+    """``DDViewBatch.tuning`` bits 8-13: the scatter pass of the two-pass path takes tiles of K = 2 .. 64 stretches of the batch in
     turn (consecutive workgroups then write K distant regions of the output -- different classes of HBM for a cloud placed in
     thirds).  Every tile knows its rows before the pass starts, so the order cannot change a byte; K may exceed the number of
     tiles and need not divide it."""
@@ -179,7 +179,7 @@ def test_interleaved_scatter_order_writes_the_same_cloud(dd, shape):
     n = int(mask.sum())
     ref = _build(dd, dd.ViewBatch(depth, params, E, mask=mask, normal=normal, rgb=rgb, tuning=4), n, None, FIELDS, fill=False)
     want = _arrays(ref)
-    for k in range(1, 16):
+    for k in list(range(1, 16)) + [20, 44, 63]:
         b = _build(dd, dd.ViewBatch(depth, params, E, mask=mask, normal=normal, rgb=rgb, tuning=4 | (k << 8)), n, None, FIELDS)
         assert int(b.cursor.item()) == n
         for name, t in _arrays(b).items():
