@@ -205,7 +205,7 @@ def test_a_blocked_cloud_of_points_is_filled_in_thirds(dd):
         b = dd.CloudBuilder(batch.max_points, pixel_index=False, placement="probed")
         assert b.placement.layout == "blocked", b.placement.as_dict()
         tun = b.fuse_tuning(batch)
-        assert tun & 4 and (tun >> 8) & 15 == dd.CloudBuilder.INTERLEAVE_REGIONS - 1
+        assert tun & 4 and tun & DENSE and (tun >> 8) & 63 == dd.CloudBuilder.INTERLEAVE_REGIONS - 1
         assert b.fuse_tuning(dd.ViewBatch(depth[:2], params[:2], E[:2])) == 0                 # a small batch: the fused single pass
         assert b.fuse_tuning(dd.ViewBatch(depth, params, E, tuning=8)) == 8                   # an explicit choice stands
         b.append(batch)
