@@ -53,6 +53,8 @@ def main(src: str, rnd: str, dest: str = "") -> None:
         rb, wb = fetch * 1024 * 2, write * 1024
         alg = line["roofline"]["algorithmic_bytes_per_launch"]
         key = "garden185:bernoulli" if tag == "bernoulli" else tag
+        if "dd_scatter" in line["roofline"]["kernel"]:      # the builder chose plan + scatter for this cloud: bench.py looks the scatter up under this key
+            key += ":two-pass"
         traffic[key] = {
             "views": cfg["views_per_gpu"], "hbm_bytes_per_launch": int(rb + wb), "kernel": line["roofline"]["kernel"],
             "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "read_bytes_corrected": int(rb), "write_bytes": int(wb),
