@@ -677,6 +677,40 @@ def test_scan_timeout_is_healed_by_a_two_pass_redo(dd, fields):
         b.finish()
 
 
+def test_check_async_reads_later_what_check_reads_now(dd):
+    """``CloudBuilder.check_async``: count and scan status travel to page-locked memory behind the kernels enqueued so far; the
+    answer is that of ``check()``, also when the builder has been reset and refilled in the meantime (scene after scene on one
+    pooled set of arrays, ``scripts/run_batch.py:57-91``); a give-up seen late is an error when a redo is no longer possible."""
+    import torch
+    V, H, W = 4, 300, 500
+    depth, mask, normal, rgb = _device_stack(V, H, W, 5)
+    params = np.tile([0.8 * W, 0.8 * W, W / 2, H / 2], (V, 1))
+    E = _ring_poses(V)
+    a = dd.ViewBatch(depth[:3], params[:3], E[:3], mask=mask[:3])
+    c = dd.ViewBatch(depth[1:], params[1:], E[1:], mask=mask[1:])
+    b = dd.CloudBuilder(a.max_points + c.max_points, pixel_index=True)
+    b.append(a)
+    p1 = b.check_async()
+    b.reset()                                              # the next "scene" on the same arrays
+    b.append(c)
+    p2 = b.check_async()
+    assert p1.result() == int(mask[:3].sum()) and p2.result() == int(mask[1:].sum())
+    assert b.check() == int(mask[1:].sum())
+    # a fault seen by a late reader: the cloud it was asked about is gone -> an error, not a silent redo of another cloud
+    bad = dd.ViewBatch(depth, params, E, mask=mask, tuning=64)
+    b.reset(); b.append(bad)
+    p3 = b.check_async()
+    b.reset(); b.append(a)
+    with pytest.raises(RuntimeError, match="timed out"):
+        p3.result()
+    assert b.check() == int(mask[:3].sum())                # the sticky word was cleared by the reader that saw it
+    b.reset(); b.append(bad)
+    with pytest.raises(RuntimeError, match="timed out"):
+        b.check_async().result(heal=False)
+    b.reset(); b.append(bad)
+    assert b.check() == int(mask.sum()) and b.healed >= 1   # the synchronous form heals
+
+
 @pytest.mark.parametrize("rho", (0.05, 0.5, 0.97))
 def test_every_row_alignment_of_the_first_row(dd, rho):
     """The lean kernel shifts its sweeps so that wave runs start on 128-byte lines of the outputs (32-row period); the
