@@ -601,7 +601,7 @@ def main() -> None:
     ev = []
     state = {"plan": None}
     single_pass = not args.two_pass
-    auto_two_pass = None
+    auto_two_pass = speculative = None
     if builder is not None and single_pass:
         # the path CloudBuilder.append would take for this cloud and batch: for ONE large row array placed with its thirds in three
         # classes of HBM that is plan + scatter with the scatter walking the thirds in turn.  The same calls are made here
@@ -609,7 +609,12 @@ def main() -> None:
         tun = builder.fuse_tuning(batch)
         if (tun & 4) and not (batch.tuning & 4):
             batch.tuning, single_pass = tun, False
-            auto_two_pass = f"CloudBuilder.fuse_tuning: two-pass, scatter interleaving {1 + ((tun >> 8) & 15)} stretches of tiles (cloud placed '{builder.placement.layout}')"
+            auto_two_pass = f"CloudBuilder.fuse_tuning: two-pass, scatter interleaving {1 + ((tun >> 8) & 63)} stretches of tiles (cloud placed '{builder.placement.layout}')"
+        elif tun & (1 << 17):
+            # unmasked depth maps on a blocked cloud: the fused call runs the scatter against a count-free plan and the scatter verifies
+            # it (DDViewBatch.tuning bit 17); builder.append makes that call itself, builder.check() below redoes the batch on a miss
+            speculative = (f"CloudBuilder.fuse_tuning: no counting pass -- plan_dense + the scatter kernel, which verifies that every pixel is valid; "
+                           f"scatter interleaving {1 + ((tun >> 8) & 63)} stretches of tiles (cloud placed '{builder.placement.layout}')")
 
     scene_pool, state_placement, big = {}, None, None
     if multi and batches:
@@ -800,7 +805,8 @@ def main() -> None:
                                "sharded: contiguous view shards + RCCL all-gather of per-view counts (global offsets)"},
             "roofline": {"bound": "hbm",
                          "kernel": "compact_lean<single-pass> (dd_unproject_compact: cull+unproject+transform+scan+compact+write)"
-                                   if single_pass else "compact_lean (dd_scatter: cull+unproject+transform+compact+write)" + (f"; {auto_two_pass}" if auto_two_pass else ""),
+                                   if single_pass and not speculative else "compact_lean (dd_scatter: cull+unproject+transform+compact+write)"
+                                   + (f"; {auto_two_pass}" if auto_two_pass else "") + (f"; {speculative}" if speculative else ""),
                          "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "read_frac": round(alg_r / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
@@ -821,6 +827,8 @@ def main() -> None:
                          "whole_step_frac": round(alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
         }
         rf = line["roofline"]
+        if builder is not None:                     # redone batches: look-back give-ups and dense speculations that missed (0 / 0 expected)
+            rf["redone"] = {"healed": int(builder.healed), "dense_misses": int(builder.dense_misses)}
         prep = (builder.placement if builder is not None else state_placement) if (builder is not None or multi) else None
         rf["placement"] = "first" if prep is None else (args.placement if prep.mode == "probed" else prep.mode)
         rf["placement_report"] = None if prep is None else prep.as_dict()

@@ -119,6 +119,7 @@ class DDFilterViews(C.Structure):
 
 DD_ARENA_ROTATED = 8
 DD_ARENA_BLOCKED = 16
+DD_TUNE_ASSUME_DENSE = 1 << 17      # DDViewBatch.tuning: count-free plan, verified by the scatter pass (include/ddcore.h)
 
 
 class DDArenaStats(C.Structure):

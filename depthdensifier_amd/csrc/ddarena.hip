@@ -414,7 +414,14 @@ int dd_arena_alloc(DDArena *A, int32_t n, const int64_t *sizes, const int32_t *g
     for (int i = 0; i < n && rc == DD_OK; ++i) {
         for (int k = 0; k < nch[i]; ++k) {
             const int ci = choice[i][k] >= 0 ? take_chunk(A, choice[i][k]) : -1;
-            if (ci < 0) { rc = afail(DD_ERR_WORKSPACE, "arena: out of device memory"); break; }
+            if (ci < 0) {
+                int avail[MAX_CLASSES];
+                free_counts(A, avail);
+                snprintf(g_aerr, sizeof(g_aerr), "arena: out of device memory (%d chunks wanted, %d + %d + %d free after scouting; %lld created, %lld released, %lld mixed so far)",
+                         total_need, avail[0], avail[1], avail[2], (long long)A->created, (long long)A->released, (long long)A->mixed);
+                rc = DD_ERR_WORKSPACE;
+                break;
+            }
             A->chunks[ci].used = true;
             chosen[i].push_back(ci);
         }

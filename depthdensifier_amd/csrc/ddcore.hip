@@ -92,6 +92,8 @@ struct KArgs {
     unsigned spin_limit;          // look-back polls before a tile gives up (SPIN_LIMIT; 0 with the fault-injection tuning bit 64)
     int dense_ok;                 // lean kernels: tiles whose pixels all survive take the list-free path (dense_wave)
     unsigned order_regions;       // two-pass scatter: 1 = tiles in order, K > 1 = K stretches of the batch interleaved (tuning bits 8-13)
+    int assume_dense;             // scatter pass: the plan was written WITHOUT counting, as if every visited pixel were valid (tuning bit 17);
+                                  // a tile that finds otherwise sets the workspace's error word to 2 (the rows are then invalid: redo)
 };
 
 
@@ -1022,6 +1024,16 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
     }
     if constexpr (SINGLE_PASS) {                       // publish the aggregate as early as possible
         if (tid == 0) st_state(&a.tile_state[t], ST_AGG | (unsigned long long)n);
+    } else {
+        // tuning bit 17: the rows of this tile were assigned without a count, on the assumption that every pixel is valid --
+        // this pass reads the validity inputs anyway, so it is also the check; one miss voids the batch (error word 2)
+        if (a.assume_dense) {
+            const unsigned there = a.P - q0 < (unsigned)LT ? a.P - q0 : (unsigned)LT;
+            if (n != there) {
+                if (tid == 0) atomicExch(&a.hdr->error, 2);
+                return;
+            }
+        }
     }
     // wave 0: the tile's first output row by ticket order (decoupled look-back), the view offsets it defines
     auto look_back = [&]() {
@@ -1276,6 +1288,24 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
     STAMP_END();
 }
 
+// ---- the count-free plan (tuning bit 17): every visited pixel taken as valid -- tile t of a view starts tv * tile rows
+// into the view, view v starts v * P rows behind the cursor.  The scatter pass verifies it (assume_dense above). ----
+__global__ __launch_bounds__(256) void plan_dense(const KArgs a, const unsigned tile) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i < a.num_tiles) {
+        const unsigned v = i / a.tiles_per_view, tv = i - v * a.tiles_per_view;
+        a.tile_off[i] = tv * tile;
+        a.tile_cnt[i] = a.P - tv * tile < tile ? a.P - tv * tile : tile;
+    }
+    if (blockIdx.x == 0) {                            // (the cursor is read by this workgroup only, and written after it has read it)
+        const long long c = *a.cursor;
+        __syncthreads();
+        for (int v = threadIdx.x; v <= a.V; v += 256) a.view_offsets[v] = c + (long long)v * a.P;
+        for (int v = threadIdx.x; v < a.V; v += 256) a.view_tot[v] = a.P;
+        if (threadIdx.x == 0 && a.cursor_out) *a.cursor_out = c + (long long)a.V * a.P;
+    }
+}
+
 // ---- pass 1 of the two-pass mode (and dd_count_valid on stride-1 maps) ----------------------------
 template <typename DepthT, bool HAS_MASK, bool NEED_DEPTH>
 __global__ __launch_bounds__(BLOCK) void count_lean(const KArgs a) {
@@ -1447,6 +1477,7 @@ int fail(int code, const char *msg) {
 constexpr unsigned TUNE_FORCE_GENERIC = 1u;   // scalar kernels even on aligned stride-1 maps (testing)
 constexpr unsigned TUNE_TWO_PASS = 4u;        // dd_unproject_compact: plan + scatter even on the lean path
 constexpr unsigned TUNE_SINGLE_PASS = 8u;     // dd_unproject_compact: ticket + decoupled look-back (default on the lean path)
+constexpr unsigned TUNE_ASSUME_DENSE = 1u << 17;   // dd_unproject_compact, lean path: scatter against a count-free plan, verified by the scatter
 
 struct Plan {
     bool refine;    // DD_REFINE: the fused refine stage (single-pass lean kernel, float32)
@@ -1510,7 +1541,7 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
     p.lean = aligned;
     // fused call: single-pass on the lean path (measured 8-23 % faster than plan + scatter on MI355X with
     // 12288-pixel tiles and a 16-granule look-back window), two-pass on the generic path
-    p.single = (b->tuning & TUNE_SINGLE_PASS) != 0 || (p.lean && !(b->tuning & TUNE_TWO_PASS));
+    p.single = (b->tuning & TUNE_SINGLE_PASS) != 0 || (p.lean && (p.refine || !(b->tuning & (TUNE_TWO_PASS | TUNE_ASSUME_DENSE))));
     a.align_runs = (b->tuning & 32u) == 0;  // tuning bit 32: rows in list order (A/B of the line-aligned sweeps)
     // tuning bit 128: tiles whose pixels all survive take the list-free path (dense_wave).  Off by default: measured in the
     // real kernel it is the same rows with a third of the instructions, and 0-5 % SLOWER.
@@ -1727,7 +1758,12 @@ int dd_unproject_compact(const DDViewBatch *batch, const DDCloudOut *out, int64_
         return DD_OK;
     }
     a.cursor_out = reinterpret_cast<long long *>(cursor_dev);   // the scan kernel advances the cursor itself
-    if ((rc = enqueue_plan(p, a, s)) != DD_OK) return rc;
+    if ((batch->tuning & TUNE_ASSUME_DENSE) && p.lean && !p.refine) {
+        // speculation for inputs that are expected to be dense (a depth map without holes and no mask): no counting pass.
+        // The plan is arithmetic, the scatter pass -- which reads the validity inputs anyway -- verifies every tile.
+        a.assume_dense = 1;
+        hipLaunchKernelGGL(plan_dense, dim3((a.num_tiles + 255u) / 256u), dim3(256), 0, s, a, (unsigned)p.tile);
+    } else if ((rc = enqueue_plan(p, a, s)) != DD_OK) return rc;
     launch_scatter<false>(p, a, s);
     return check_launch("dd_unproject_compact");
 }

@@ -216,15 +216,16 @@ class PendingCheck:
         self._event.synchronize()
         b = self._b
         total = int(self._slot[0])
-        bad = [w for w, v in zip(self._ws, self._slot[1:1 + self._nws].tolist()) if (v >> 32) != 0]
-        bad += [w for w in self._late if int(w[:8].view(torch.int32)[1].item()) != 0]
+        words = [(w, v >> 32) for w, v in zip(self._ws, self._slot[1:1 + self._nws].tolist())]
+        words += [(w, int(w[:8].view(torch.int32)[1].item())) for w in self._late]
+        bad = [w for w, code in words if code != 0]
         if bad:
             for w in bad:
                 w[:16].zero_()                            # sticky word: cleared only here, once seen
             if not heal or b._epoch != self._epoch:
-                raise RuntimeError("libddcore: in-kernel scan timed out in one of the appended batches (workspace error word set); "
-                                   "rows are invalid -- append the batches again with tuning=4")
-            total = b._heal()
+                raise RuntimeError("libddcore: in-kernel scan timed out in one of the appended batches, or a batch run as 'assume dense' "
+                                   "was not dense (workspace error word set); rows are invalid -- append the batches again with tuning=4")
+            total = b._heal(dense_miss=any(code == 2 for _, code in words))       # (2: a batch run as 'assume dense' was not)
         if total > b.capacity:
             raise OverflowError(f"cloud capacity {b.capacity} < {total} valid points; "
                                 "allocate with capacity=batch.max_points or count_valid() first")
@@ -601,6 +602,8 @@ class CloudBuilder:
         self._retain_base: Optional[int] = None      # row the retained batches start from (None: the cloud's start)
         self._epoch = 0                              # counts reset(): a PendingCheck knows which cloud it was asked about
         self.healed = 0
+        self.speculate_dense = True                  # fuse_tuning may run unmasked batches of a blocked cloud without the counting pass
+        self.dense_misses = 0                        # ... until one of them was not dense (then never again on this cloud)
 
     def _set_start(self) -> None:
         if self._start is None:
@@ -694,10 +697,15 @@ class CloudBuilder:
         a path in the batch's tuning -- two-pass with the scatter interleaving ``INTERLEAVE_REGIONS`` stretches of tiles."""
         t = batch.tuning
         if (self.placement is not None and self.placement.layout == "blocked" and self.placement.mode.startswith(("probed", "degraded"))
-                and not (t & (1 | 4 | 8 | 0x3F00)) and batch.stride == 1 and batch.max_points >= self.INTERLEAVE_MIN_ROWS // 2):
+                and not (t & (1 | 4 | 8 | 0x3F00 | _lib.DD_TUNE_ASSUME_DENSE)) and batch.stride == 1 and batch._knots is None
+                and batch.max_points >= self.INTERLEAVE_MIN_ROWS // 2):
             # (+ bit 128: dense tiles take the list-free path -- in the scatter pass, which waits for no look-back, its smaller
             # instruction count is worth 0.3-1.3 %; in the single-pass kernel it is not, see DESIGN.md section 4)
             t |= 4 | 128 | ((self.INTERLEAVE_REGIONS - 1) << 8)
+            if batch.mask is None and batch.conf is None and self.speculate_dense and not self.dense_misses:
+                # depth maps without a mask: expected to have no holes.  No counting pass -- the plan is arithmetic and the scatter
+                # pass verifies it; a miss is redone like a scan that gave up (check() / finish()), once, and this cloud stops guessing
+                t = (t & ~4) | _lib.DD_TUNE_ASSUME_DENSE
         return t
 
     def _out_struct(self) -> DDCloudOut:
@@ -774,7 +782,7 @@ class CloudBuilder:
                 bad = True
         return bad
 
-    def _heal(self) -> int:
+    def _heal(self, dense_miss: bool = False) -> int:
         """A look-back of the single-pass kernel timed out (a workgroup was parked for ~2 s: another tenant, ranks sharing
         the GPU): every batch appended since the last reset is run again through dd_plan + dd_scatter (``tuning`` bit 4),
         whose workgroups do not depend on each other, writing the same rows and the same offset tensors."""
@@ -793,12 +801,14 @@ class CloudBuilder:
             self.cursor.fill_(self._retain_base)
         for batch, offsets, _ in self._retained:
             saved = batch.tuning
-            batch.tuning = (saved | 4) & ~(8 | 64)
+            batch.tuning = (saved | 4) & ~(8 | 64 | _lib.DD_TUNE_ASSUME_DENSE)
             try:
                 self.append(batch, _offsets=offsets)
             finally:
                 batch.tuning = saved
         self.healed += 1
+        if dense_miss:
+            self.dense_misses += 1                           # this cloud stops guessing (fuse_tuning)
         total = int(self.cursor.item())
         if self._scan_gave_up():                             # cannot happen: the two-pass kernels have no look-back
             raise RuntimeError("libddcore: the two-pass redo reported a scan time-out")

@@ -207,7 +207,10 @@ def place_arrays(specs: Dict[str, Tuple[Sequence[int], torch.dtype, int]], devic
         arena = get_arena(dev)
         tensors, degraded = arena.alloc(specs)
     except (ArenaError, RuntimeError) as e:          # the virtual-memory API is missing or out of memory: carry on unplaced
-        return plain(), PlacementReport(f"skipped: {e}"[:200])
+        free, total = torch.cuda.mem_get_info(dev)
+        want = sum(int(np.prod(sh, dtype=np.int64)) * torch.empty((), dtype=dt).element_size() for sh, dt, _ in specs.values())
+        why = f"skipped: {e} (request {want / GIB:.1f} GiB; {free / GIB:.1f} of {total / GIB:.1f} GiB free afterwards, torch holds {torch.cuda.memory_reserved(dev) / GIB:.1f} GiB)"
+        return plain(), PlacementReport(why[:300])
     rep = PlacementReport("degraded: some arrays share a class" if degraded else "probed", seconds=time.perf_counter() - t0)
     rep.classes = {k: _summary(arena.classes_of(t)) for k, t in tensors.items()}
     rep.stats = arena.stats()

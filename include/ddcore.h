@@ -103,7 +103,13 @@ typedef struct DDViewBatch {
                                  bits 8-13 = K - 1: the scatter pass of the two-pass path (tuning 4 / dd_scatter) takes the tiles
                                  of K stretches of the batch in turn, so that consecutive workgroups write K distant regions
                                  of the output -- for ONE large row array whose thirds lie in different classes of HBM
-                                 (DD_ARENA_BLOCKED) that is 0.80 instead of 0.66 of the roofline; rows are the same for every K */
+                                 (DD_ARENA_BLOCKED) that is 0.80 instead of 0.66 of the roofline; rows are the same for every K;
+                                 bit 17 (131072) = dd_unproject_compact on stride-1 maps SPECULATES that every visited pixel is
+                                 valid (a depth map without holes, no mask): no counting pass -- the plan is arithmetic (view v starts
+                                 v * H * W rows behind the cursor) and the scatter pass, which reads the validity inputs anyway,
+                                 verifies every tile; a tile that finds an invalid pixel sets the workspace's error word to 2
+                                 and the batch's rows, offsets and cursor are void: redo it with tuning = 4 (what CloudBuilder
+                                 does by itself).  Ignored with tuning 8, DD_REFINE and on strided maps */
     float *refined_out;       /* DD_REFINE: NULL, or (V,H,W) float32 receiving the refined, mask-zeroed depth -- the map the
                                  reference caches for the multi-view filter (scripts/test.py:194, 197-201) */
 } DDViewBatch;
@@ -170,8 +176,9 @@ int dd_scatter(const DDViewBatch *batch, const DDCloudOut *out, const int64_t *v
  *  cursor_dev       (1) int64, device, in/out: advanced by the batch's number of points.
  *  view_offsets_dev (V+1) int64, device, out.
  *  workspace        as above.  ((int32_t*)workspace)[1] != 0 after the stream has drained means the
- *                   in-kernel look-back gave up after ~2 s of polling (should never happen; rows
- *                   are then invalid -- redo the batch with tuning = 4).  The first 16 bytes of the
+ *                   in-kernel look-back gave up after ~2 s of polling (1: should never happen) or a batch
+ *                   run with tuning bit 17 was not dense (2); rows, offsets and the cursor
+ *                   are then invalid -- redo the batch with tuning = 4.  The first 16 bytes of the
  *                   workspace are STICKY: the library never zeroes them, so the caller zeroes the
  *                   workspace once before its first use and a set error word survives any number
  *                   of later calls on the same workspace until the caller clears it.

@@ -14,6 +14,7 @@ from test_gpu_parity import assert_cloud, scene_radius
 pytestmark = pytest.mark.gpu
 
 DENSE = 128          # DDViewBatch.tuning bit 128: dense tiles take the list-free path (off by default)
+ASSUME = 1 << 17     # DDViewBatch.tuning bit 17: count-free plan, verified by the scatter pass
 
 
 @pytest.fixture(scope="module")
@@ -187,6 +188,68 @@ def test_interleaved_scatter_order_writes_the_same_cloud(dd, shape):
             assert bool((t[n:] == (201 if name == "colors" else -7)).all()), (k + 1, name)
 
 
+@pytest.mark.parametrize("dtype_name", ("float32", "float16"))
+@pytest.mark.parametrize("shape", ((3, 150, 331), (1, 70, 70), (5, 64, 64), (2, 128, 400)))
+def test_assume_dense_scatter_writes_the_counted_cloud(dd, dtype_name, shape):
+    """``DDViewBatch.tuning`` bit 17: no counting pass -- the plan is arithmetic (every visited pixel taken as valid) and the scatter
+    pass verifies it.  On maps without holes the cloud is the counted cloud bit for bit: ragged last tiles, views of exactly one
+    tile, a cloud that starts at an odd row, two batches chained, all fields, with the dense path and the interleaved order."""
+    import torch
+    dtype = getattr(torch, dtype_name)
+    V, H, W = shape
+    depth, _, normal, rgb = _scene(V, H, W, dtype, 31, None)
+    params = np.tile([0.8 * W, 0.8 * W, W / 2, H / 2], (V, 1))
+    E = _ring(V)
+    n = V * H * W
+    ref = _build(dd, dd.ViewBatch(depth, params, E, normal=normal, rgb=rgb), n, None, FIELDS, fill=False)
+    want, want_off = _arrays(ref), ref._offsets[0].clone()
+    for extra in (0, DENSE, DENSE | (14 << 8), 2 << 8):
+        b = _build(dd, dd.ViewBatch(depth, params, E, normal=normal, rgb=rgb, tuning=ASSUME | extra), n, None, FIELDS)
+        assert int(b.cursor.item()) == n and b.check() == n and b.healed == 0 and b.dense_misses == 0
+        assert torch.equal(b._offsets[0], want_off)
+        for name, t in _arrays(b).items():
+            assert torch.equal(t[:n].view(torch.uint8), want[name][:n].view(torch.uint8)), (extra, name)
+            assert bool((t[n:] == (201 if name == "colors" else -7)).all()), (extra, name)
+    half = max(V // 2, 1)
+    b = dd.CloudBuilder(37 + n, normals=True, colors=True, pixel_index=True, view_index=True, start=37)
+    b.append(dd.ViewBatch(depth[:half], params[:half], E[:half], normal=normal[:half], rgb=rgb[:half], tuning=ASSUME))
+    if half < V:
+        b.append(dd.ViewBatch(depth[half:], params[half:], E[half:], normal=normal[half:], rgb=rgb[half:], tuning=ASSUME | DENSE, view_index_base=half))
+    got = b.finish()
+    assert len(got) == n and b.healed == 0
+    for name in FIELDS:
+        assert torch.equal(getattr(got, name).view(torch.uint8), want[name][:n].view(torch.uint8)), name
+
+
+@pytest.mark.parametrize("hole", ("depth", "mask", "last_pixel"))
+def test_a_dense_guess_that_misses_is_redone(dd, hole):
+    """One invalid pixel anywhere voids a batch run as 'assume dense': the tile that holds it sets the workspace's error word to 2;
+    ``check()`` / ``finish()`` redo the batch through the counting path (``healed``, ``dense_misses``) and the cloud is the counted
+    cloud; without the redo the error surfaces."""
+    import torch
+    V, H, W = 4, 150, 331
+    depth, _, normal, rgb = _scene(V, H, W, torch.float32, 37, None)
+    mask = None
+    if hole == "depth":
+        depth[2, 77, 200] = 0.0
+    elif hole == "last_pixel":
+        depth[V - 1, H - 1, W - 1] = float("nan")
+    else:
+        mask = torch.ones((V, H, W), dtype=torch.bool, device="cuda")
+        mask[1, 3, 5] = False
+    params = np.tile([0.8 * W, 0.8 * W, W / 2, H / 2], (V, 1))
+    E = _ring(V)
+    n = V * H * W - 1
+    want = _arrays(_build(dd, dd.ViewBatch(depth, params, E, mask=mask, normal=normal, rgb=rgb), n, None, FIELDS, fill=False))
+    b = _build(dd, dd.ViewBatch(depth, params, E, mask=mask, normal=normal, rgb=rgb, tuning=ASSUME), n, None, FIELDS)
+    with pytest.raises(RuntimeError, match="not dense"):
+        b.check_async().result(heal=False)
+    b2 = _build(dd, dd.ViewBatch(depth, params, E, mask=mask, normal=normal, rgb=rgb, tuning=ASSUME | DENSE), n, None, FIELDS)
+    assert b2.check() == n and b2.healed == 1 and b2.dense_misses == 1
+    for name, t in _arrays(b2).items():
+        assert torch.equal(t[:n].view(torch.uint8), want[name][:n].view(torch.uint8)), name
+
+
 def test_a_blocked_cloud_of_points_is_filled_in_thirds(dd):
     """A cloud of points only, placed with its thirds in three classes, chooses the interleaved two-pass path by itself for a large
     batch (``CloudBuilder.fuse_tuning``) and leaves small batches, explicit choices and clouds with normals alone; the cloud it
@@ -195,26 +258,52 @@ def test_a_blocked_cloud_of_points_is_filled_in_thirds(dd):
     V, H, W = 40, 1080, 1920                                     # 83 M pixels: above half of a lowered threshold
     g = torch.Generator(device="cuda").manual_seed(5)
     depth = torch.empty((V, H, W), device="cuda", dtype=torch.float16).uniform_(0.5, 8.0, generator=g)
-    depth[:, 100:300, 200:900] = 0
     params = np.tile([0.8 * W, 0.8 * W, W / 2, H / 2], (V, 1))
     E = _ring(V)
-    batch = dd.ViewBatch(depth, params, E)
+    holes = depth.clone()
+    holes[:, 100:300, 200:900] = 0
+    mask = torch.ones((V, H, W), dtype=torch.bool, device="cuda")
+    mask[:, 100:300, 200:900] = False
     old = dd.CloudBuilder.INTERLEAVE_MIN_ROWS
     dd.CloudBuilder.INTERLEAVE_MIN_ROWS = 64 << 20
+    K1 = dd.CloudBuilder.INTERLEAVE_REGIONS - 1
     try:
-        b = dd.CloudBuilder(batch.max_points, pixel_index=False, placement="probed")
+        # a masked batch: counted, the scatter interleaved
+        masked = dd.ViewBatch(depth, params, E, mask=mask)
+        b = dd.CloudBuilder(masked.max_points, pixel_index=False, placement="probed")
         assert b.placement.layout == "blocked", b.placement.as_dict()
-        tun = b.fuse_tuning(batch)
-        assert tun & 4 and tun & DENSE and (tun >> 8) & 63 == dd.CloudBuilder.INTERLEAVE_REGIONS - 1
+        tun = b.fuse_tuning(masked)
+        assert tun & 4 and not tun & ASSUME and tun & DENSE and (tun >> 8) & 63 == K1
         assert b.fuse_tuning(dd.ViewBatch(depth[:2], params[:2], E[:2])) == 0                 # a small batch: the fused single pass
         assert b.fuse_tuning(dd.ViewBatch(depth, params, E, tuning=8)) == 8                   # an explicit choice stands
-        b.append(batch)
-        got = b.finish()
+        b.append(masked)
+        got_masked = b.finish()
+        assert b.healed == 0
+        # unmasked maps without holes: no counting pass, the guess holds
+        dense = dd.ViewBatch(depth, params, E)
+        tun = b.fuse_tuning(dense)
+        assert tun & ASSUME and not tun & 4 and tun & DENSE and (tun >> 8) & 63 == K1
+        b.reset(); b.append(dense)
+        got_dense = b.finish()
+        assert b.healed == 0 and b.dense_misses == 0 and len(got_dense) == V * H * W
+        got_dense_points = got_dense.points.clone()
+        # unmasked maps WITH holes: the guess misses once, the batch is redone, and this cloud stops guessing
+        holed = dd.ViewBatch(holes, params, E)
+        assert b.fuse_tuning(holed) & ASSUME
+        b.reset(); b.append(holed)
+        got_holed = b.finish()
+        assert b.healed == 1 and b.dense_misses == 1
+        tun = b.fuse_tuning(holed)
+        assert tun & 4 and not tun & ASSUME
     finally:
         dd.CloudBuilder.INTERLEAVE_MIN_ROWS = old
-    plain = dd.CloudBuilder(batch.max_points, pixel_index=False, placement="first")
-    assert plain.fuse_tuning(batch) == 0
-    plain.append(batch)
+    plain = dd.CloudBuilder(holed.max_points, pixel_index=False, placement="first")
+    assert plain.fuse_tuning(holed) == 0
+    plain.append(holed)
     want = plain.finish()
-    assert len(got) == len(want) and torch.equal(got.view_offsets, want.view_offsets)
-    assert torch.equal(got.points.view(torch.int32), want.points.view(torch.int32))
+    assert len(got_holed) == len(want) and torch.equal(got_holed.view_offsets, want.view_offsets)
+    assert torch.equal(got_holed.points.view(torch.int32), want.points.view(torch.int32))
+    assert len(got_masked) == len(want)
+    plain.reset(); plain.append(dense)
+    want = plain.finish()
+    assert torch.equal(got_dense_points.view(torch.int32), want.points.view(torch.int32))
