@@ -774,7 +774,7 @@ def main() -> None:
         traffic, traffic_source = None, None
         tfile = ROOT / "profiles" / "traffic.json"
         if tfile.exists():
-            tkey = ("mip360conf" if multi else args.workload) + (":bernoulli" if args.mask_kind == "bernoulli" else "") + ("" if single_pass else ":two-pass")
+            tkey = ("mip360conf" if multi else args.workload) + (":bernoulli" if args.mask_kind == "bernoulli" else "") + ("" if single_pass and not speculative else ":two-pass")      # (the speculative call runs the two-pass scatter kernel)
             # (mip360x7 runs the mip360conf kernel scene after scene on the same kind of maps: its bytes per view)
             rec = json.loads(tfile.read_text()).get(tkey)
             if rec:     # PMC bytes were collected on the full workload; a launch over fewer views moves proportionally fewer
