@@ -730,13 +730,14 @@ def main() -> None:
         verified["what"] = "rows of the TIMED cloud (last timed step) vs oracle/densify_oracle.py on this rank's first views and its last one"
 
     # ---- the same kernel on fresh allocations of the cloud (the placement of the output arrays is the one thing that moves it)
-    alloc_ms = []
+    alloc_ms, alloc_how = [], []
     if not multi and single_pass and args.alloc_rounds > 0 and V > 0:
         keep = []
         from depthdensifier_amd import placement as _pl
         cloud_bytes = batch.max_points * (12 + (12 if cfg["normal"] else 0) + (3 if cfg["rgb"] else 0) + (4 if args.pixel_index else 0))
         for r in range(args.alloc_rounds):
             _pl.trim(device)              # no spare chunks from the last round: every round scouts the device's memory anew
+            torch.cuda.empty_cache()      # (blocks torch keeps cached -- the verification's temporaries -- are not free memory to the driver)
             if torch.cuda.mem_get_info(device)[0] < 1.15 * cloud_bytes + (4 << 30):
                 break                     # no room for a second cloud beside the timed one (2000 views on one GPU)
             b2 = dd.CloudBuilder(batch.max_points, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index, device=device,
@@ -751,6 +752,7 @@ def main() -> None:
                 torch.cuda.synchronize(device)
                 ts.append(e0.elapsed_time(e1))
             alloc_ms.append(float(np.median(ts)))
+            alloc_how.append("first" if b2.placement is None else f"{b2.placement.mode[:120]} / {b2.placement.layout}")
             if args.placement == "first":
                 keep.append(torch.empty((r + 1) << 30, dtype=torch.uint8, device=device))    # the next allocation starts elsewhere
             del b2
@@ -835,7 +837,7 @@ def main() -> None:
         if alloc_ms:
             fr = [alg / (t * 1e-3) / 1e9 / HBM_PEAK_GBPS for t in alloc_ms]
             rf.update({"frac_min": round(min(fr), 4), "frac_median": round(float(np.median(fr)), 4), "frac_max": round(max(fr), 4),
-                       "alloc_rounds": len(fr), "kernel_ms_per_allocation": [round(t, 4) for t in alloc_ms],
+                       "alloc_rounds": len(fr), "kernel_ms_per_allocation": [round(t, 4) for t in alloc_ms], "placement_per_allocation": alloc_how,
                        "frac_note": "frac is the driver's timed run; frac_min / median / max re-time the same kernel on this many FRESH allocations "
                                     "of the cloud in the same process (placement as above), median of 5 launches each"})
         if verified is not None:

@@ -72,13 +72,28 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 using ddarena_plan::MAX_CLASSES;
 using ddarena_plan::best_assignment;
 using ddarena_plan::plan_classes;
-constexpr size_t SCOUT_SLOTS = 512;
 constexpr int SCOUT_BATCH = 8;
+// NO VIRTUAL RANGE IS EVER MAPPED TWICE.  On this stack (ROCm 7.2, MI355X) a range that was mapped, unmapped and mapped again --
+// with or without hipMemAddressFree + hipMemAddressReserve in between, which hands the same address out again -- keeps
+// translating to the physical memory of its FIRST mapping: kernels and copies through it read and write the old handle's pages,
+// whoever owns them by then (tools/experiments/ubench_vmm_remap.hip, profiles/r04_ubench_vmm_remap.txt: 20 of 20 repetitions; a
+// bump pointer through one large reservation: 0 of 30).  Rounds 3 and 4 reused scouting slots and freed array ranges; that was
+// right only as long as the chunk that came back to a range was the chunk that had left it, and ended in rare aborts and
+// segmentation faults inside the runtime once clouds were allocated and freed by the hundred (the test suite).  So virtual
+// addresses are taken from large reservations with a bump pointer and never given back before dd_arena_destroy: a scouted chunk
+// costs one chunk of address space, an array its size (47 bits of address space: ~100 000 GiB-sized mappings per process;
+// arrays that are freed and asked for again in the same shape come out of the mapping cache below and cost none).
+constexpr size_t VA_BLOCK_CHUNKS = 1024;      // chunks per reservation (1 TiB at the default chunk size)
+
+struct VaBlock {
+    char *base;
+    size_t bytes, used;
+};
 
 struct Chunk {
     hipMemGenericAllocationHandle_t h;
     int cls;        // -1 = not classified
-    int slot;       // scouting slot it is mapped in, -1 = mapped into an allocation
+    char *scout;    // where it is mapped for scouting, nullptr = mapped into an allocation (or pooled: mapped nowhere)
     bool live;      // handle not yet released
     bool used;      // part of an allocation
     bool anchor;
@@ -86,9 +101,12 @@ struct Chunk {
 
 struct Mapping {
     char *va;
-    size_t bytes;               // reserved (multiple of the chunk size)
+    size_t bytes;               // a multiple of the chunk size
     std::vector<int> chunks;
+    int32_t layout;             // what the caller asked for (a group, DD_ARENA_ROTATED + phase, DD_ARENA_BLOCKED)
+    bool clean;                 // built by a request that had no conflicts: every chunk lies in the class its layout names
 };
+constexpr size_t CACHE_MAX_CHUNKS_PER_ARRAY = 8;     // arrays up to this many chunks are kept mapped when freed (the mapping cache)
 
 }  // namespace
 
@@ -96,10 +114,12 @@ struct DDArena {
     int device;
     size_t chunk;
     size_t rows;                // probe window, rows of 12 bytes
-    char *scout_va;
-    std::vector<int> slot_owner;      // SCOUT_SLOTS entries, chunk index or -1
+    std::vector<VaBlock> va;          // reservations, consumed front to back, never reused
     std::vector<Chunk> chunks;
     std::vector<Mapping> maps;
+    std::vector<Mapping> cache;       // freed arrays kept as they are -- mapped, their chunks marked used -- for the next request of
+                                      // the same shape and layout: a caller that builds a cloud per scene then makes no
+                                      // virtual-memory call at all and consumes no address space (oldest first out; dd_arena_trim empties it)
     int anchors[MAX_CLASSES];
     int n_classes;
     int group_class[MAX_CLASSES];     // class a group was given at its first use (-1 = not yet): sticky, so that arrays of
@@ -111,8 +131,9 @@ struct DDArena {
     hipMemAllocationProp prop;
     std::mutex mu;
     // statistics
-    int64_t created, released, probes, mixed;
+    int64_t created, released, probes, mixed, cache_hits;
     bool debug;                 // DD_ARENA_DEBUG: one line per classified chunk on stderr
+    bool trace;                 // DD_ARENA_TRACE: one line in front of every virtual-memory call of alloc / free on stderr (fault hunting)
     int pool_per_class;         // classified chunks of each class kept (unmapped) when arrays are freed or scouting leaves
                                 // spares, so that the next allocation need not scout again; dd_arena_trim gives them back
     double seconds;
@@ -127,7 +148,27 @@ namespace {
         if (e_ != hipSuccess) return afail_hip(what, e_);  \
     } while (0)
 
-char *slot_ptr(DDArena *A, int slot) { return A->scout_va + (size_t)slot * A->chunk; }
+// `bytes` (a multiple of the chunk size) of address space that no mapping has ever used; nullptr = the reservation failed
+char *va_take(DDArena *A, size_t bytes) {
+    if (A->va.empty() || A->va.back().used + bytes > A->va.back().bytes) {
+        VaBlock b;
+        b.base = nullptr; b.used = 0;
+        b.bytes = std::max(bytes, VA_BLOCK_CHUNKS * A->chunk);
+        if (hipMemAddressReserve(reinterpret_cast<void **>(&b.base), b.bytes, 0, nullptr, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            b.bytes = std::max(bytes, 16 * A->chunk);
+            hipError_t e = hipMemAddressReserve(reinterpret_cast<void **>(&b.base), b.bytes, 0, nullptr, 0);
+            if (e != hipSuccess) { (void)afail_hip("hipMemAddressReserve", e); return nullptr; }
+        }
+        A->va.push_back(b);
+    }
+    VaBlock &b = A->va.back();
+    char *p = b.base + b.used;
+    b.used += bytes;
+    return p;
+}
+
+#define ATRACE(A, ...) do { if ((A)->trace) { fprintf(stderr, "[ddarena] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 
 // median-free timing: the minimum of `reps` runs after one warm-up (disturbances only ever add time)
 int probe_pair(DDArena *A, float *a, float *b, float *ms_out) {
@@ -159,10 +200,9 @@ bool is_same_class(const DDArena *A, float ms) {
 int release_chunk(DDArena *A, int ci) {
     Chunk &c = A->chunks[ci];
     if (!c.live) return DD_OK;
-    if (c.slot >= 0) {
-        AHIP(hipMemUnmap(slot_ptr(A, c.slot), A->chunk), "hipMemUnmap(scout)");
-        A->slot_owner[c.slot] = -1;
-        c.slot = -1;
+    if (c.scout) {
+        AHIP(hipMemUnmap(c.scout, A->chunk), "hipMemUnmap(scout)");
+        c.scout = nullptr;
     }
     AHIP(hipMemRelease(c.h), "hipMemRelease");
     c.live = false;
@@ -170,33 +210,31 @@ int release_chunk(DDArena *A, int ci) {
     return DD_OK;
 }
 
-// One more physical chunk, mapped into a free scouting slot and classified.  DD_ERR_WORKSPACE = the device is out of memory
+// One more physical chunk, mapped at a fresh piece of address space and classified.  DD_ERR_WORKSPACE = the device is out of memory
 // (or out of scouting slots): the caller stops scouting.
 int scout_one(DDArena *A, int *chunk_out) {
-    int slot = -1;
-    for (size_t s = 0; s < SCOUT_SLOTS; ++s)
-        if (A->slot_owner[s] < 0) { slot = (int)s; break; }
-    if (slot < 0) return afail(DD_ERR_WORKSPACE, "arena: no free scouting slot");
     Chunk c;
     memset(&c, 0, sizeof(c));
-    c.cls = -1; c.slot = slot; c.live = true; c.used = false; c.anchor = false;
+    c.cls = -1; c.scout = nullptr; c.live = true; c.used = false; c.anchor = false;
     hipError_t e = hipMemCreate(&c.h, A->chunk, &A->prop, 0);
     if (e != hipSuccess) return afail_hip("hipMemCreate", e);
-    e = hipMemMap(slot_ptr(A, slot), A->chunk, 0, c.h, 0);
+    c.scout = va_take(A, A->chunk);                 // (address space is taken only once the memory is there)
+    if (!c.scout) { (void)hipMemRelease(c.h); return DD_ERR_WORKSPACE; }
+    e = hipMemMap(c.scout, A->chunk, 0, c.h, 0);
     if (e != hipSuccess) { (void)hipMemRelease(c.h); return afail_hip("hipMemMap(scout)", e); }
     hipMemAccessDesc acc;
     memset(&acc, 0, sizeof(acc));
     acc.location = A->prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
-    e = hipMemSetAccess(slot_ptr(A, slot), A->chunk, &acc, 1);
-    if (e != hipSuccess) { (void)hipMemUnmap(slot_ptr(A, slot), A->chunk); (void)hipMemRelease(c.h); return afail_hip("hipMemSetAccess(scout)", e); }
+    e = hipMemSetAccess(c.scout, A->chunk, &acc, 1);
+    if (e != hipSuccess) { (void)hipMemUnmap(c.scout, A->chunk); (void)hipMemRelease(c.h); return afail_hip("hipMemSetAccess(scout)", e); }
     int ci = -1;                                     // entries of released chunks are reused: nothing refers to them any more
     for (size_t i = 0; i < A->chunks.size() && ci < 0; ++i) if (!A->chunks[i].live) ci = (int)i;
     if (ci < 0) { A->chunks.push_back(c); ci = (int)A->chunks.size() - 1; }
     else A->chunks[ci] = c;
-    A->slot_owner[slot] = ci;
     A->created += 1;
-    float *w = reinterpret_cast<float *>(slot_ptr(A, slot));
+    char *const here = c.scout;
+    float *w = reinterpret_cast<float *>(here);
     int rc;
     if (A->n_classes == 0) {
         // the very first chunk: anchor of class 0; windows inside it give the same-class level -- IF it lies inside one class.
@@ -204,8 +242,8 @@ int scout_one(DDArena *A, int *chunk_out) {
         // would set same_ms to the CROSS-class level, every later pair would look "same class" and every allocation would end up
         // in class 0.  Three windows (first, middle, last) must agree pairwise; a chunk in which they do not is set aside as
         // mixed and the next chunk scouted takes its place.
-        float *mid = reinterpret_cast<float *>(slot_ptr(A, slot) + A->chunk / 2);
-        float *last = reinterpret_cast<float *>(slot_ptr(A, slot) + A->chunk - A->rows * 12);
+        float *mid = reinterpret_cast<float *>(here + A->chunk / 2);
+        float *last = reinterpret_cast<float *>(here + A->chunk - A->rows * 12);
         float ms, ms_fl, ms_ml;
         if ((rc = probe_pair(A, w, mid, &ms)) != DD_OK) return rc;
         if ((rc = probe_pair(A, w, last, &ms_fl)) != DD_OK) return rc;
@@ -232,7 +270,7 @@ int scout_one(DDArena *A, int *chunk_out) {
     float t[MAX_CLASSES];
     int cls = -1;
     for (int k = 0; k < A->n_classes; ++k) {
-        float *anchor = reinterpret_cast<float *>(slot_ptr(A, A->chunks[A->anchors[k]].slot));
+        float *anchor = reinterpret_cast<float *>(A->chunks[A->anchors[k]].scout);
         if ((rc = probe_pair(A, anchor, w, &t[k])) != DD_OK) return rc;
         if (t[k] < A->fast_ms) A->fast_ms = t[k];
     }
@@ -241,7 +279,7 @@ int scout_one(DDArena *A, int *chunk_out) {
     // The probes above saw the chunk's first window only.  The classes meet at two places of the physical memory that
     // are not chunk-aligned, so a chunk can change class inside: its first against its last window must be a same-class pair.
     float t_self = 0.f;
-    if ((rc = probe_pair(A, w, reinterpret_cast<float *>(slot_ptr(A, slot) + A->chunk - A->rows * 12), &t_self)) != DD_OK) return rc;
+    if ((rc = probe_pair(A, w, reinterpret_cast<float *>(here + A->chunk - A->rows * 12), &t_self)) != DD_OK) return rc;
     if (!is_same_class(A, t_self)) {
         A->chunks[ci].cls = -1;                      // mixed: never handed out, goes back to the driver with the other spares
         A->mixed += 1;
@@ -274,16 +312,29 @@ int pool_or_release(DDArena *A, int ci) {
     Chunk &c = A->chunks[ci];
     if (!c.live || c.used || c.anchor) return DD_OK;
     int pooled = 0;
-    for (const Chunk &o : A->chunks) if (o.live && !o.used && !o.anchor && o.slot < 0 && o.cls == c.cls) ++pooled;
+    for (const Chunk &o : A->chunks) if (&o != &c && o.live && !o.used && !o.anchor && !o.scout && o.cls == c.cls) ++pooled;
     if (c.cls >= 0 && pooled < A->pool_per_class) {
-        if (c.slot >= 0) {
-            AHIP(hipMemUnmap(slot_ptr(A, c.slot), A->chunk), "hipMemUnmap(scout)");
-            A->slot_owner[c.slot] = -1;
-            c.slot = -1;
+        if (c.scout) {
+            AHIP(hipMemUnmap(c.scout, A->chunk), "hipMemUnmap(scout)");
+            c.scout = nullptr;
         }
         return DD_OK;
     }
     return release_chunk(A, ci);
+}
+
+// a cached mapping goes: unmapped for good, its chunks to the pool or the driver
+int drop_cached(DDArena *A, size_t k) {
+    Mapping m = A->cache[k];
+    A->cache.erase(A->cache.begin() + (long)k);
+    ATRACE(A, "cache: %p leaves (%zu bytes)", (void *)m.va, m.bytes);
+    AHIP(hipMemUnmap(m.va, m.bytes), "hipMemUnmap(array)");
+    for (int ci : m.chunks) {
+        A->chunks[ci].used = false;
+        int rc = pool_or_release(A, ci);
+        if (rc != DD_OK) return rc;
+    }
+    return DD_OK;
 }
 
 int free_count(const DDArena *A, int cls) {
@@ -330,21 +381,21 @@ int dd_arena_create(int32_t device, int64_t chunk_bytes, DDArena **arena_out) {
     A->rows = std::min<size_t>((size_t)32 << 20, A->chunk / 24);      // two windows fit one chunk (the same-class reference)
     A->n_classes = 0;
     A->same_ms = A->fast_ms = 0.f;
-    A->created = A->released = A->probes = A->mixed = 0;
+    A->created = A->released = A->probes = A->mixed = A->cache_hits = 0;
     A->debug = getenv("DD_ARENA_DEBUG") != nullptr;
+    A->trace = getenv("DD_ARENA_TRACE") != nullptr;
     A->pool_per_class = 4;
     A->seconds = 0.0;
     A->degraded = 0;
     for (int k = 0; k < MAX_CLASSES; ++k) A->anchors[k] = A->group_class[k] = -1;
-    A->slot_owner.assign(SCOUT_SLOTS, -1);
     memset(&A->prop, 0, sizeof(A->prop));
     A->prop.type = hipMemAllocationTypePinned;
     A->prop.location.type = hipMemLocationTypeDevice;
     A->prop.location.id = device;
     int rc = DD_OK;
     hipError_t e;
-    A->scout_va = nullptr; A->stream = nullptr; A->e0 = A->e1 = nullptr;
-    if ((e = hipMemAddressReserve(reinterpret_cast<void **>(&A->scout_va), SCOUT_SLOTS * A->chunk, 0, nullptr, 0)) != hipSuccess) rc = afail_hip("hipMemAddressReserve(scout)", e);
+    A->stream = nullptr; A->e0 = A->e1 = nullptr;
+    if (!va_take(A, A->chunk)) rc = DD_ERR_LAUNCH;          // the first reservation: fails here where the virtual-memory API is missing
     if (rc == DD_OK && (e = hipStreamCreateWithFlags(&A->stream, hipStreamNonBlocking)) != hipSuccess) rc = afail_hip("hipStreamCreate", e);
     if (rc == DD_OK && (e = hipEventCreate(&A->e0)) != hipSuccess) rc = afail_hip("hipEventCreate", e);
     if (rc == DD_OK && (e = hipEventCreate(&A->e1)) != hipSuccess) rc = afail_hip("hipEventCreate", e);
@@ -353,7 +404,7 @@ int dd_arena_create(int32_t device, int64_t chunk_bytes, DDArena **arena_out) {
         if (A->e0) (void)hipEventDestroy(A->e0);
         if (A->e1) (void)hipEventDestroy(A->e1);
         if (A->stream) (void)hipStreamDestroy(A->stream);
-        if (A->scout_va) (void)hipMemAddressFree(A->scout_va, SCOUT_SLOTS * A->chunk);
+        for (VaBlock &b : A->va) (void)hipMemAddressFree(b.base, b.bytes);
         delete A;
         return rc;
     }
@@ -378,11 +429,34 @@ int dd_arena_alloc(DDArena *A, int32_t n, const int64_t *sizes, const int32_t *g
         else for (int k = 0; k < nch[i]; ++k) fixed[(L - DD_ARENA_ROTATED + k) % MAX_CLASSES] += 1;
         ptrs_out[i] = nullptr;
     }
+    {   // the mapping cache: every array of the request as it was freed before (same size in chunks, same layout, built cleanly)
+        std::vector<int> hit(n, -1);
+        std::vector<char> taken(A->cache.size(), 0);
+        bool all = true;
+        for (int i = 0; i < n && all; ++i) {
+            for (size_t k = 0; k < A->cache.size() && hit[i] < 0; ++k)
+                if (!taken[k] && A->cache[k].clean && A->cache[k].layout == groups[i] && A->cache[k].chunks.size() == (size_t)nch[i]) { hit[i] = (int)k; taken[k] = 1; }
+            all = hit[i] >= 0;
+        }
+        if (all) {
+            for (int i = 0; i < n; ++i) { A->maps.push_back(A->cache[hit[i]]); ptrs_out[i] = A->cache[hit[i]].va; }
+            std::vector<Mapping> rest;
+            for (size_t k = 0; k < A->cache.size(); ++k) if (!taken[k]) rest.push_back(A->cache[k]);
+            A->cache.swap(rest);
+            A->cache_hits += 1;
+            A->seconds += now_s() - t_start;
+            return DD_OK;
+        }
+    }
     int prev = 0;
     AHIP(hipGetDevice(&prev), "hipGetDevice");
     AHIP(hipSetDevice(A->device), "hipSetDevice");
     struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{prev};
     AHIP(hipDeviceSynchronize(), "hipDeviceSynchronize");          // probes are timed: nothing else should be running
+    while (!A->cache.empty()) {                                     // a request of another shape: what the cache holds becomes spare chunks
+        int rc0 = drop_cached(A, 0);
+        if (rc0 != DD_OK) return rc0;
+    }
     const int total_need = need[0] + need[1] + need[2] + fixed[0] + fixed[1] + fixed[2];
     int perm[MAX_CLASSES] = {0, 1, 2};
     bool oom = false;
@@ -442,32 +516,36 @@ int dd_arena_alloc(DDArena *A, int32_t n, const int64_t *sizes, const int32_t *g
         Mapping m;
         m.bytes = (size_t)nch[i] * A->chunk;
         m.va = nullptr;
-        hipError_t e = hipMemAddressReserve(reinterpret_cast<void **>(&m.va), m.bytes, 0, nullptr, 0);
-        if (e != hipSuccess) { rc = afail_hip("hipMemAddressReserve(array)", e); break; }
+        hipError_t e = hipSuccess;
+        m.va = va_take(A, m.bytes);
+        if (!m.va) { rc = DD_ERR_WORKSPACE; break; }
+        ATRACE(A, "alloc: %p taken, mapping %d chunks", (void *)m.va, nch[i]);
         int mapped = 0;
         for (int k = 0; k < nch[i] && rc == DD_OK; ++k) {
             Chunk &c = A->chunks[chosen[i][k]];
-            if (c.slot >= 0) {              // fresh from scouting (a pooled chunk is not mapped anywhere)
-                if ((e = hipMemUnmap(slot_ptr(A, c.slot), A->chunk)) != hipSuccess) { rc = afail_hip("hipMemUnmap(scout)", e); break; }
-                A->slot_owner[c.slot] = -1;
-                c.slot = -1;
+            if (c.scout) {                  // fresh from scouting (a pooled chunk is not mapped anywhere)
+                if ((e = hipMemUnmap(c.scout, A->chunk)) != hipSuccess) { rc = afail_hip("hipMemUnmap(scout)", e); break; }
+                c.scout = nullptr;
             }
             if ((e = hipMemMap(m.va + (size_t)k * A->chunk, A->chunk, 0, c.h, 0)) != hipSuccess) { rc = afail_hip("hipMemMap(array)", e); break; }
             ++mapped;
         }
+        ATRACE(A, "alloc: %p set access", (void *)m.va);
         if (rc == DD_OK && (e = hipMemSetAccess(m.va, m.bytes, &acc, 1)) != hipSuccess) rc = afail_hip("hipMemSetAccess(array)", e);
+        ATRACE(A, "alloc: %p ready", (void *)m.va);
         if (rc != DD_OK) {
             if (mapped > 0) (void)hipMemUnmap(m.va, (size_t)mapped * A->chunk);
-            (void)hipMemAddressFree(m.va, m.bytes);
             break;
         }
         m.chunks = chosen[i];
+        m.layout = groups[i];
+        m.clean = !degraded;
         built.push_back(m);
     }
     if (rc != DD_OK) {
         char msg[sizeof(g_aerr)];
         snprintf(msg, sizeof(msg), "%s", g_aerr);
-        for (Mapping &m : built) { (void)hipMemUnmap(m.va, m.bytes); (void)hipMemAddressFree(m.va, m.bytes); }
+        for (Mapping &m : built) (void)hipMemUnmap(m.va, m.bytes);
         for (auto &v : chosen) for (int ci : v) A->chunks[ci].used = false;
         for (size_t ci = 0; ci < A->chunks.size(); ++ci) if (A->chunks[ci].live && !A->chunks[ci].used && !A->chunks[ci].anchor) (void)release_chunk(A, (int)ci);
         (void)hipGetLastError();
@@ -499,16 +577,31 @@ int dd_arena_free(DDArena *A, void *ptr) {
         AHIP(hipGetDevice(&prev), "hipGetDevice");
         AHIP(hipSetDevice(A->device), "hipSetDevice");
         struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{prev};
+        ATRACE(A, "free %p: sync", ptr);
         AHIP(hipDeviceSynchronize(), "hipDeviceSynchronize");      // kernels that still use the array must have drained
         Mapping m = A->maps[i];
         A->maps.erase(A->maps.begin() + (long)i);
+        if (m.clean && m.chunks.size() <= CACHE_MAX_CHUNKS_PER_ARRAY && A->pool_per_class > 0) {
+            ATRACE(A, "free %p: kept mapped (cache)", ptr);
+            A->cache.push_back(m);
+            size_t held = 0;
+            for (const Mapping &c : A->cache) held += c.chunks.size();
+            while (held > (size_t)(MAX_CLASSES * A->pool_per_class) && A->cache.size() > 1) {      // oldest first out
+                held -= A->cache.front().chunks.size();
+                int rc = drop_cached(A, 0);
+                if (rc != DD_OK) return rc;
+            }
+            return DD_OK;
+        }
+        ATRACE(A, "free %p: unmap %zu bytes", ptr, m.bytes);
         AHIP(hipMemUnmap(m.va, m.bytes), "hipMemUnmap(array)");
         for (int ci : m.chunks) {
             A->chunks[ci].used = false;
+            ATRACE(A, "free %p: chunk %d to the pool or the driver", ptr, ci);
             int rc = pool_or_release(A, ci);
             if (rc != DD_OK) return rc;
         }
-        AHIP(hipMemAddressFree(m.va, m.bytes), "hipMemAddressFree(array)");
+        ATRACE(A, "free %p: done (its addresses are never used again)", ptr);
         return DD_OK;
     }
     return afail(DD_ERR_INVALID_ARG, "ptr was not allocated by this arena");
@@ -522,6 +615,13 @@ int dd_arena_trim(DDArena *A, int32_t pool_chunks_per_class) {
     AHIP(hipGetDevice(&prev), "hipGetDevice");
     AHIP(hipSetDevice(A->device), "hipSetDevice");
     struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{prev};
+    const int keep = A->pool_per_class;
+    A->pool_per_class = 0;                     // (what leaves the cache goes to the driver, not to the pool)
+    while (!A->cache.empty()) {
+        int rc = drop_cached(A, A->cache.size() - 1);
+        if (rc != DD_OK) { A->pool_per_class = keep; return rc; }
+    }
+    A->pool_per_class = keep;
     for (size_t ci = 0; ci < A->chunks.size(); ++ci) {
         Chunk &c = A->chunks[ci];
         if (c.live && !c.used && !c.anchor) {
@@ -574,6 +674,8 @@ int dd_arena_stats(DDArena *A, DDArenaStats *out) {
             out->chunks_held[c.cls] += 1;
             if (!c.used && !c.anchor) out->chunks_pooled[c.cls] += 1;
         }
+    for (const Mapping &m : A->cache)              // arrays kept mapped for the next request of their shape: spare capacity as well
+        for (int ci : m.chunks) { const int cls = A->chunks[ci].cls; if (cls >= 0 && cls < MAX_CLASSES) out->chunks_pooled[cls] += 1; }
     return DD_OK;
 }
 
@@ -583,16 +685,14 @@ int dd_arena_destroy(DDArena *A) {
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(A->device);
     (void)hipDeviceSynchronize();
-    for (Mapping &m : A->maps) {
-        (void)hipMemUnmap(m.va, m.bytes);
-        (void)hipMemAddressFree(m.va, m.bytes);
-    }
+    for (Mapping &m : A->maps) (void)hipMemUnmap(m.va, m.bytes);
+    for (Mapping &m : A->cache) (void)hipMemUnmap(m.va, m.bytes);
     for (Chunk &c : A->chunks) {
         if (!c.live) continue;
-        if (c.slot >= 0) (void)hipMemUnmap(slot_ptr(A, c.slot), A->chunk);
+        if (c.scout) (void)hipMemUnmap(c.scout, A->chunk);
         (void)hipMemRelease(c.h);
     }
-    (void)hipMemAddressFree(A->scout_va, SCOUT_SLOTS * A->chunk);
+    for (VaBlock &b : A->va) (void)hipMemAddressFree(b.base, b.bytes);
     (void)hipEventDestroy(A->e0);
     (void)hipEventDestroy(A->e1);
     (void)hipStreamDestroy(A->stream);

@@ -692,20 +692,26 @@ class CloudBuilder:
         return offsets
 
     def fuse_tuning(self, batch: "ViewBatch") -> int:
-        """``DDViewBatch.tuning`` with which ``append`` runs ``batch``: the batch's own, plus -- for a placed cloud of points
-        only whose thirds lie in three classes (``placement.layout == "blocked"``), a large batch, and no explicit choice of
-        a path in the batch's tuning -- two-pass with the scatter interleaving ``INTERLEAVE_REGIONS`` stretches of tiles."""
+        """``DDViewBatch.tuning`` with which ``append`` runs ``batch``: the batch's own, plus -- for a large stride-1 batch without
+        an explicit choice of a path in its tuning --
+
+        * a placed cloud of points only whose thirds lie in three classes (``placement.layout == "blocked"``): two-pass with the
+          scatter interleaving ``INTERLEAVE_REGIONS`` stretches of tiles (several store fronts in several classes at once);
+        * a cloud without normals and a batch WITHOUT a mask or a confidence map (a depth map its producer considers complete):
+          the same scatter against a count-free plan (bit 17: every pixel guessed valid, every tile verified by the scatter; a miss
+          is redone by ``check()`` / ``finish()`` like a scan that gave up, once -- then this cloud stops guessing)."""
         t = batch.tuning
-        if (self.placement is not None and self.placement.layout == "blocked" and self.placement.mode.startswith(("probed", "degraded"))
-                and not (t & (1 | 4 | 8 | 0x3F00 | _lib.DD_TUNE_ASSUME_DENSE)) and batch.stride == 1 and batch._knots is None
-                and batch.max_points >= self.INTERLEAVE_MIN_ROWS // 2):
+        if (t & (1 | 4 | 8 | 0x3F00 | _lib.DD_TUNE_ASSUME_DENSE)) or batch.stride != 1 or batch._knots is not None \
+                or batch.max_points < self.INTERLEAVE_MIN_ROWS // 2:
+            return t
+        blocked = (self.placement is not None and self.placement.layout == "blocked"
+                   and self.placement.mode.startswith(("probed", "degraded")))
+        guess = (self.normal is None and batch.mask is None and batch.conf is None and self.speculate_dense and not self.dense_misses)
+        if blocked or guess:
             # (+ bit 128: dense tiles take the list-free path -- in the scatter pass, which waits for no look-back, its smaller
             # instruction count is worth 0.3-1.3 %; in the single-pass kernel it is not, see DESIGN.md section 4)
-            t |= 4 | 128 | ((self.INTERLEAVE_REGIONS - 1) << 8)
-            if batch.mask is None and batch.conf is None and self.speculate_dense and not self.dense_misses:
-                # depth maps without a mask: expected to have no holes.  No counting pass -- the plan is arithmetic and the scatter
-                # pass verifies it; a miss is redone like a scan that gave up (check() / finish()), once, and this cloud stops guessing
-                t = (t & ~4) | _lib.DD_TUNE_ASSUME_DENSE
+            t |= 128 | ((self.INTERLEAVE_REGIONS - 1) << 8)
+            t |= _lib.DD_TUNE_ASSUME_DENSE if guess else 4
         return t
 
     def _out_struct(self) -> DDCloudOut:

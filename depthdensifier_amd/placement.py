@@ -282,6 +282,6 @@ def place_outputs(capacity: int, *, colors: bool, device, mode: Optional[str] = 
                     "more than a cloud this small wins back; placement='probed' forces it)")
     else:
         t, rep = place_arrays(specs, device, mode)
-    if rep.mode == "probed":
+    if rep.mode.startswith(("probed", "degraded")):      # (degraded: some chunks lie outside the class asked for -- the layout still holds mostly)
         rep.layout = layout
     return t["points"], t.get("normals"), t.get("colors"), rep

@@ -339,7 +339,7 @@ typedef struct DDArenaStats {
     int64_t chunks_released;
     int64_t probes;
     int64_t chunks_held[3];     /* live chunks per class (anchors, allocations, pool) */
-    int64_t chunks_pooled[3];   /* of those: spare classified chunks kept for the next allocation (see dd_arena_trim) */
+    int64_t chunks_pooled[3];   /* of those: spare classified chunks kept for the next allocation, unmapped or in cached arrays (see dd_arena_trim) */
     float same_class_ms;        /* probe level inside one chunk */
     float cross_class_ms;       /* fastest pair seen */
     double seconds;             /* time spent inside dd_arena_alloc */
@@ -353,11 +353,15 @@ int dd_arena_create(int32_t device, int64_t chunk_bytes, DDArena **arena_out);
  * probes are timed).  Returns DD_OK, 1 = allocated but two lock-step arrays share a class somewhere (budget or memory too
  * small), or a negative error (DD_ERR_WORKSPACE = out of device memory; nothing of the request stays allocated). */
 int dd_arena_alloc(DDArena *arena, int32_t n, const int64_t *sizes, const int32_t *groups, int64_t max_scout_bytes, void **ptrs_out);
-/* Unmaps one array of dd_arena_alloc; synchronises the device first.  Its chunks go back to the driver, except that up to
- * 4 chunks per class (dd_arena_trim changes that) are kept as classified spares so that the next allocation need not
- * scout again (scouting costs ~27 ms per GiB looked at). */
+/* Gives back one array of dd_arena_alloc; synchronises the device first.  An array of up to 8 chunks whose request was
+ * served without conflicts stays MAPPED in a cache (12 chunks at most, oldest first out): the next request for arrays of
+ * the same sizes in chunks and the same layouts gets them back as they are -- no virtual-memory call, no address space.
+ * Otherwise the array is unmapped and its chunks go back to the driver, except that up to 4 chunks per class (dd_arena_trim
+ * changes that) are kept as classified spares so that the next allocation need not scout again (scouting costs ~27 ms per
+ * GiB looked at).  The arena never maps a virtual range twice (a re-mapped range keeps translating to the physical memory of
+ * its first mapping on this stack, ddarena.hip): address space is consumed, not recycled, until dd_arena_destroy. */
 int dd_arena_free(DDArena *arena, void *ptr);
-/* Gives every spare chunk back to the driver; pool_chunks_per_class >= 0 also sets how many are kept from now on. */
+/* Empties the cache and gives every spare chunk back to the driver; pool_chunks_per_class >= 0 also sets how many are kept from now on. */
 int dd_arena_trim(DDArena *arena, int32_t pool_chunks_per_class);
 /* Class of every chunk behind an array: returns the number of chunks, writes min(that, capacity) entries. */
 int dd_arena_classes(DDArena *arena, const void *ptr, int32_t *classes_out, int32_t capacity);

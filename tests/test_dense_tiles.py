@@ -295,15 +295,18 @@ def test_a_blocked_cloud_of_points_is_filled_in_thirds(dd):
         assert b.healed == 1 and b.dense_misses == 1
         tun = b.fuse_tuning(holed)
         assert tun & 4 and not tun & ASSUME
+        # plainly allocated arrays guess too (an unmasked batch, no normals), and run masked batches in the single pass
+        plain = dd.CloudBuilder(holed.max_points, pixel_index=False, placement="first")
+        assert plain.fuse_tuning(holed) & ASSUME and not plain.fuse_tuning(holed) & 4 and plain.fuse_tuning(masked) == 0
     finally:
         dd.CloudBuilder.INTERLEAVE_MIN_ROWS = old
-    plain = dd.CloudBuilder(holed.max_points, pixel_index=False, placement="first")
-    assert plain.fuse_tuning(holed) == 0
-    plain.append(holed)
+    # the references: the single pass, asked for explicitly
+    plain.append(dd.ViewBatch(holes, params, E, tuning=8))
     want = plain.finish()
+    assert plain.healed == 0
     assert len(got_holed) == len(want) and torch.equal(got_holed.view_offsets, want.view_offsets)
     assert torch.equal(got_holed.points.view(torch.int32), want.points.view(torch.int32))
     assert len(got_masked) == len(want)
-    plain.reset(); plain.append(dense)
+    plain.reset(); plain.append(dd.ViewBatch(depth, params, E, tuning=8))
     want = plain.finish()
     assert torch.equal(got_dense_points.view(torch.int32), want.points.view(torch.int32))

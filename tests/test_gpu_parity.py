@@ -592,10 +592,12 @@ def test_per_gpu_share_of_the_2000_view_scene_with_normals(dd, orc):
     assert torch.equal(packed.colors, rows.colors)
 
 
-def test_12mp_f16_dense_beyond_2_31_rows(dd, orc):
-    """BASELINE configs[4] at scale in its OWN instantiation (f16 depth, no mask, no normals, no colours, xyz out): 180 views
+@pytest.mark.parametrize("tuning", (0, 8))
+def test_12mp_f16_dense_beyond_2_31_rows(dd, orc, tuning):
+    """BASELINE configs[4] at scale in its OWN instantiations (f16 depth, no mask, no normals, no colours, xyz out): 180 views
     of 4032 x 3024 = 2.19 G rows (> 2^31), 26 GB of points.  Every pixel is valid, so the cloud is the pixel grid: length,
-    per-view offsets, pixel_index of a late view == arange, and the LAST view against the oracle."""
+    per-view offsets, pixel_index of a late view == arange, and the LAST view against the oracle.  ``tuning`` 0: the path the
+    builder chooses (an unmasked batch: no counting pass, the scatter verifies -- ``CloudBuilder.fuse_tuning``); 8: the single pass."""
     import torch
     V, H, W = 180, 3024, 4032
     P = H * W
@@ -606,11 +608,12 @@ def test_12mp_f16_dense_beyond_2_31_rows(dd, orc):
         depth[v] = torch.rand((H, W), device="cuda", generator=g) * 7.0 + 1.0          # 1 .. 8 m, all > 0
     params = np.tile([0.8 * W, 0.8 * W, W / 2, H / 2], (V, 1))
     E = _ring_poses(V)
-    batch = dd.ViewBatch(depth, params, E)
+    batch = dd.ViewBatch(depth, params, E, tuning=tuning)
     b = dd.CloudBuilder(batch.max_points, pixel_index=True)
+    assert bool(b.fuse_tuning(batch) & (1 << 17)) == (tuning == 0)
     b.append(batch)
     cloud = b.finish()
-    assert len(cloud) == V * P and b.healed == 0
+    assert len(cloud) == V * P and b.healed == 0 and b.dense_misses == 0
     offs = cloud.view_offsets
     assert torch.equal(offs, torch.arange(V + 1, device="cuda", dtype=torch.int64) * P)
     for v in (0, V // 2, V - 3, V - 1):                                                # rows beyond 2^31 included
