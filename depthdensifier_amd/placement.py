@@ -123,7 +123,12 @@ class ZoneArena:
         nbytes = [int(np.prod(specs[k][0], dtype=np.int64)) * torch.empty((), dtype=specs[k][1]).element_size() for k in names]
         if any(b <= 0 for b in nbytes):
             raise ValueError("arena arrays must not be empty")
-        torch.cuda.empty_cache()       # blocks torch has freed but keeps cached are memory the driver cannot hand to the arena
+        st = self.stats()
+        chunk = max(int(st["chunk_bytes"]), 1)
+        if sum(-(-b // chunk) for b in nbytes) > sum(st["chunks_pooled"]):
+            # physical memory will be needed: blocks torch has freed but keeps cached are memory the driver cannot hand to the arena
+            # (a request the arena's spare chunks and cached arrays cover -- a cloud per scene -- leaves torch's cache alone)
+            torch.cuda.empty_cache()
         if max_scout_bytes is None:
             # a class is a third of the memory and an idle device hands out long stretches of one class (64 GiB seen): finding
             # all three may take a look at ~100 GiB.  Everything scouted and not used is back with the driver when alloc returns.
