@@ -14,8 +14,9 @@
 // lift the xyz-only workloads as well.  But hipMemMap takes no offset into a handle on this runtime, so every piece must be
 // a handle of its own; pieces that small cannot be timed alone, and runs of consecutively created small handles are pure
 // only on an untouched device -- after torch has allocated and freed they are mixtures (profiles/
-// r03_arena_runs_of_32MiB_pieces_are_mixed_after_torch.txt), and re-mapping scouting ranges piece by piece makes
-// hipMemSetAccess fail intermittently.  Handles of 1 GiB always come from ONE class, in every process state seen.
+// r03_arena_runs_of_32MiB_pieces_are_mixed_after_torch.txt), and re-mapping scouting ranges piece by piece made
+// hipMemSetAccess fail intermittently (round 4 found why: a range that is mapped a second time keeps its first physical
+// memory on this stack -- see VA_BLOCK_CHUNKS below).  Handles of 1 GiB always come from ONE class, in every process state seen.
 //
 // What it does.  Physical memory is taken in chunks (default 1 GiB) through the virtual-memory API (hipMemCreate), every
 // new chunk is mapped into a scouting range and classified with the two-stream store probe below against the anchors;

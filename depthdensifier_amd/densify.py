@@ -869,6 +869,8 @@ def unproject_views(depth: ArrayLike, intrinsics: ArrayLike, cam_from_world: Arr
     else:
         cap = int(capacity)
     builder = CloudBuilder(cap, **fields)
+    if cap != batch.max_points:
+        builder.speculate_dense = False          # fewer rows than pixels (counted, or said so by the caller): the maps are known to have holes
     builder.append(batch)
     cloud = builder.finish()
     cloud.rgb_passthrough = batch.rgb_passthrough
@@ -881,6 +883,8 @@ def fuse_batches(batches: Sequence[ViewBatch], capacity: Optional[int] = None, *
         capacity = sum(int(count_valid(b).sum().item()) for b in batches)
     base = 0
     builder = CloudBuilder(capacity, device=batches[0].device, **cloud_fields)
+    if capacity != sum(b.max_points for b in batches):
+        builder.speculate_dense = False          # (as in unproject_views)
     for b in batches:
         b.view_index_base = base
         builder.append(b)
