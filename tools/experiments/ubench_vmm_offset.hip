@@ -85,6 +85,17 @@ int main() {
         printf("8 GiB in %5zu handles of %2zu MiB: create %.1f ms, map %.1f ms, set access %.1f ms, first touch %.1f ms, unmap %.1f ms, release %.1f ms\n",
                n, piece >> 20, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (t5 - t4) * 1e3, (t6 - t5) * 1e3);
     }
+    // (4) how much address space can be reserved: 1 TiB ranges until the runtime says no (the arena never reuses addresses)
+    {
+        std::vector<void *> rs;
+        for (int i = 0; i < 512; ++i) {
+            void *r = nullptr;
+            if (hipMemAddressReserve(&r, (size_t)1 << 40, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); break; }
+            rs.push_back(r);
+        }
+        printf("%zu reservations of 1 TiB succeeded (stopped at 512)\n", rs.size());
+        for (void *r : rs) CK(hipMemAddressFree(r, (size_t)1 << 40));
+    }
     printf("done\n");
     return 0;
 }
