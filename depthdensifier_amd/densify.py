@@ -706,7 +706,8 @@ class CloudBuilder:
             return t
         blocked = (self.placement is not None and self.placement.layout == "blocked"
                    and self.placement.mode.startswith(("probed", "degraded")))
-        guess = (self.normal is None and batch.mask is None and batch.conf is None and self.speculate_dense and not self.dense_misses)
+        guess = (self.normal is None and batch.mask is None and batch.conf is None and self.speculate_dense and not self.dense_misses
+                 and self.capacity >= batch.max_points)       # (a cloud sized below the pixel count says the maps have holes)
         if blocked or guess:
             # (+ bit 128: dense tiles take the list-free path -- in the scatter pass, which waits for no look-back, its smaller
             # instruction count is worth 0.3-1.3 %; in the single-pass kernel it is not)
