@@ -110,7 +110,14 @@ def make_scene(cfg: dict, view_ids: np.ndarray, device) -> dict:
         if rgb is not None:
             rgb[i] = torch.randint(0, 256, (H, W, 3), generator=g, device=device, dtype=torch.uint8)
         if conf is not None:
-            conf[i].uniform_(0.0, 1.0, generator=g)
+            if cfg.get("conf_kind") == "smooth":
+                # a spatially coherent confidence (what a network's confidence map looks like): half of every view above 0.5, in blobs
+                coarse = torch.rand((1, 1, 18, 32), generator=g, device=device)
+                blob = torch.nn.functional.interpolate(coarse, size=(H, W), mode="bicubic", align_corners=False)[0, 0]
+                med = torch.quantile(blob.flatten()[:: max(1, (H * W) // 200000)], 0.5)
+                conf[i] = ((blob - med) * 2.0 + 0.5).clamp(0.0, 1.0)
+            else:
+                conf[i].uniform_(0.0, 1.0, generator=g)     # independent per pixel: every 128-byte line of the attribute maps keeps a survivor
     return dict(depth=depth, mask=mask, normal=normal, rgb=rgb, conf=conf)
 
 
@@ -485,6 +492,8 @@ def main() -> None:
     ap.add_argument("--chunks", type=int, default=5, help="view chunks per rank whose exchange overlaps the next chunk's kernel")
     ap.add_argument("--gather-dst", default="all", choices=("all", "0"), help="gathered legs: every rank receives the whole cloud (all) or only rank 0 does")
     ap.add_argument("--gather-timeout", type=float, default=240.0, help="watchdog for the strong-scaling leg, seconds")
+    ap.add_argument("--conf-kind", default="noise", choices=("noise", "smooth"),
+                    help="confidence maps of the conf workloads: independent per pixel (default; the worst case for the attribute gathers) or spatially coherent blobs")
     ap.add_argument("--mask-kind", default="blob", choices=("blob", "bernoulli"),
                     help="blob: smooth regions (default); bernoulli: independent per-pixel cull, worst case for compaction")
     ap.add_argument("--colmap-path", type=Path, default=ROOT / "data" / "360_v2" / "garden" / "sparse" / "0",
@@ -535,6 +544,7 @@ def main() -> None:
 
     cfg = dict(WORKLOADS[args.workload])
     cfg["mask_kind"] = args.mask_kind
+    cfg["conf_kind"] = args.conf_kind
     strong = args.workload == "scene2000"
     multi = "scenes" in cfg                          # whole scenes back to back, dealt to the ranks
     if args.views:
@@ -776,7 +786,7 @@ def main() -> None:
         traffic, traffic_source = None, None
         tfile = ROOT / "profiles" / "traffic.json"
         if tfile.exists():
-            tkey = ("mip360conf" if multi else args.workload) + (":bernoulli" if args.mask_kind == "bernoulli" else "") + ("" if single_pass and not speculative else ":two-pass")      # (the speculative call runs the two-pass scatter kernel)
+            tkey = ("mip360conf" if multi else args.workload) + (":bernoulli" if args.mask_kind == "bernoulli" else "") + (":smooth" if cfg.get("conf") and args.conf_kind == "smooth" else "") + ("" if single_pass and not speculative else ":two-pass")      # (the speculative call runs the two-pass scatter kernel)
             # (mip360x7 runs the mip360conf kernel scene after scene on the same kind of maps: its bytes per view)
             rec = json.loads(tfile.read_text()).get(tkey)
             if rec:     # PMC bytes were collected on the full workload; a launch over fewer views moves proportionally fewer
@@ -798,6 +808,7 @@ def main() -> None:
             "mpoints_per_s": round(n_total / (elapsed / args.steps) / 1e6, 1),
             "config": {"workload": args.workload, "note": cfg["note"], "views_total": total_views, "views_per_gpu": V,
                        "height": H, "width": W, "downsample_density": 1, "valid_fraction": round(n_local / (V * H * W), 4), "mask_kind": args.mask_kind,
+                       "conf_kind": args.conf_kind if cfg.get("conf") else None,
                        "poses": poses_from,
                        "inputs": "+".join(k for k in ("depth", "mask", "conf", "normal", "rgb") if scene[k] is not None),
                        "outputs": "xyz f32" + (" + normal f32" if cfg["normal"] else "") + (" + rgb u8" if cfg["rgb"] else "")
