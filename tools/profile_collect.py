@@ -43,7 +43,7 @@ def main(src: str, rnd: str, dest: str = "") -> None:
             (prof / f"{rnd}_bench_{tag}_under_rocprof.json").write_text(json.dumps(json.loads(under.read_text()), indent=1) + "\n")
         if (d / "stats").is_dir():
             summarize_prof.main(str(d / "stats"), str(prof / f"{rnd}_{tag}_kernel_stats.csv"),
-                                f"{rnd}: rocprofv3 --kernel-trace --stats -- python3 bench.py {'--workload garden185 --mask-kind bernoulli' if tag == 'bernoulli' else '--workload ' + tag} --cpu-seconds 0 --strong-views 0")
+                                f"{rnd}: rocprofv3 --kernel-trace --stats -- python3 bench.py { {'bernoulli': '--workload garden185 --mask-kind bernoulli', 'mip360conf_smooth': '--workload mip360conf --conf-kind smooth'}.get(tag, '--workload ' + tag) } --cpu-seconds 0 --strong-views 0")
         fetch, nf = mean_counter(d / "pmc" / "FETCH_SIZE", "FETCH_SIZE")
         write, nw = mean_counter(d / "pmc" / "WRITE_SIZE", "WRITE_SIZE")
         if fetch is None or write is None:
@@ -52,7 +52,7 @@ def main(src: str, rnd: str, dest: str = "") -> None:
         cfg = line["config"]
         rb, wb = fetch * 1024 * 2, write * 1024
         alg = line["roofline"]["algorithmic_bytes_per_launch"]
-        key = "garden185:bernoulli" if tag == "bernoulli" else tag
+        key = {"bernoulli": "garden185:bernoulli", "mip360conf_smooth": "mip360conf:smooth"}.get(tag, tag)
         if "dd_scatter" in line["roofline"]["kernel"]:      # the builder chose plan + scatter for this cloud: bench.py looks the scatter up under this key
             key += ":two-pass"
         traffic[key] = {

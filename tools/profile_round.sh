@@ -4,7 +4,7 @@
 #   2. rocprofv3 --kernel-trace --stats of the same command          -> <out>/<tag>/stats/   (+ bench line under the profiler)
 #   3. rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate runs -> <out>/<tag>/pmc/
 # then tools/profile_collect.py condenses them into profiles/ (kernel-stats CSVs, traffic.json).
-#   usage: tools/profile_round.sh <outdir> [workload tags...]      tags: garden185 bernoulli mip360conf roofline12mp scene2000
+#   usage: tools/profile_round.sh <outdir> [workload tags...]      tags: garden185 bernoulli mip360conf mip360conf_smooth roofline12mp scene2000
 set -uo pipefail
 OUT=$(realpath -m "$1"); shift          # (raw traces are large: give a directory under /tmp, not under gpurun_out/ -- only 64 MiB travel back)
 R=$(cd "$(dirname "$0")/.." && pwd)
@@ -14,6 +14,7 @@ cd /tmp
 for tag in $TAGS; do
   case $tag in
     bernoulli) ARGS="--workload garden185 --mask-kind bernoulli" ;;
+    mip360conf_smooth) ARGS="--workload mip360conf --conf-kind smooth" ;;
     *) ARGS="--workload $tag" ;;
   esac
   D="$OUT/$tag"; mkdir -p "$D"
