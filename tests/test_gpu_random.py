@@ -44,6 +44,13 @@ def _case(seed):
         opts["tuning"] |= 32                      # wave runs NOT aligned to 128-byte lines: same bits out
     if np.random.default_rng(30_000 + seed).uniform() < 0.4:
         opts["tuning"] |= 128                     # round 4: dense tiles take the list-free path (needs >= 12 288 dense pixels: DD_RANDOM_SCALE)
+    r4 = np.random.default_rng(40_000 + seed)
+    if r4.uniform() < 0.2:
+        # round 4: the count-free plan (every pixel guessed valid, the scatter verifies).  The random maps have holes and masks, so the
+        # guess misses nearly always: what is tested is that the miss is noticed and the batch redone into the right cloud
+        opts["tuning"] |= 1 << 17
+        if r4.uniform() < 0.5:
+            opts["tuning"] |= int(r4.integers(1, 64)) << 8     # with the tiles of the scatter pass in an interleaved order
     return d, opts
 
 
