@@ -19,7 +19,7 @@
 // memory on this stack -- see VA_BLOCK_CHUNKS below).  Handles of 1 GiB always come from ONE class, in every process state seen.
 //
 // What it does.  Physical memory is taken in chunks (default 1 GiB) through the virtual-memory API (hipMemCreate), every
-// new chunk is mapped into a scouting range and classified with the two-stream store probe below against the anchors;
+// new chunk is mapped at a fresh piece of address space and classified with the two-stream store probe below against the anchors;
 // an allocation request names a GROUP per array, arrays of different groups are built from chunks of different classes
 // (mapped back to back into a fresh virtual range, so the caller sees one contiguous array), chunks that are not needed
 // go straight back to the driver.  Nothing here touches results: the arena only chooses physical pages.
@@ -212,7 +212,7 @@ int release_chunk(DDArena *A, int ci) {
 }
 
 // One more physical chunk, mapped at a fresh piece of address space and classified.  DD_ERR_WORKSPACE = the device is out of memory
-// (or out of scouting slots): the caller stops scouting.
+// (or out of address space): the caller stops scouting.
 int scout_one(DDArena *A, int *chunk_out) {
     Chunk c;
     memset(&c, 0, sizeof(c));
@@ -523,7 +523,7 @@ int dd_arena_alloc(DDArena *A, int32_t n, const int64_t *sizes, const int32_t *g
         for (size_t ci = 0; ci < A->chunks.size(); ++ci) if (A->chunks[ci].live && !A->chunks[ci].used && !A->chunks[ci].anchor) (void)release_chunk(A, (int)ci);
         return rc;
     }
-    // build the arrays: chunks leave the scouting range and are mapped back to back into a fresh range.  On any failure
+    // build the arrays: chunks leave the addresses they were scouted at and are mapped back to back at addresses no mapping has used.  On any failure
     // everything this request has built is undone ("nothing stays allocated").
     hipMemAccessDesc acc;
     memset(&acc, 0, sizeof(acc));
