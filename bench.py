@@ -492,6 +492,8 @@ def main() -> None:
     ap.add_argument("--chunks", type=int, default=5, help="view chunks per rank whose exchange overlaps the next chunk's kernel")
     ap.add_argument("--gather-dst", default="all", choices=("all", "0"), help="gathered legs: every rank receives the whole cloud (all) or only rank 0 does")
     ap.add_argument("--gather-timeout", type=float, default=240.0, help="watchdog for the strong-scaling leg, seconds")
+    ap.add_argument("--no-dense-guess", action="store_true",
+                    help="unmasked batches: count before scattering (CloudBuilder.speculate_dense = False) -- the counted figure of configs[4]")
     ap.add_argument("--conf-kind", default="noise", choices=("noise", "smooth"),
                     help="confidence maps of the conf workloads: independent per pixel (default; the worst case for the attribute gathers) or spatially coherent blobs")
     ap.add_argument("--mask-kind", default="blob", choices=("blob", "bernoulli"),
@@ -607,6 +609,7 @@ def main() -> None:
         # count + scan + unproject + compact, which the fused kernel does in its one pass)
         builder = dd.CloudBuilder(batch.max_points, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index,
                                   device=device, placement=args.placement)
+        builder.speculate_dense = not args.no_dense_guess
 
     ev = []
     state = {"plan": None}
@@ -752,6 +755,7 @@ def main() -> None:
                 break                     # no room for a second cloud beside the timed one (2000 views on one GPU)
             b2 = dd.CloudBuilder(batch.max_points, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index, device=device,
                                  placement=args.placement)
+            b2.speculate_dense = not args.no_dense_guess
             for _ in range(2):
                 b2.reset(); b2.append(batch)
             ts = []
