@@ -531,7 +531,9 @@ class CloudBuilder:
     # workgroups then write three classes at once -- 0.705 instead of 0.66 of the roofline on BASELINE configs[4] with the count
     # pass included, 0.80 for the scatter kernel alone.  Below this many rows (3 GiB of points) the count pass costs more than the interleaving wins back.
     INTERLEAVE_MIN_ROWS = 256 << 20
-    INTERLEAVE_REGIONS = 15          # (3 ... 21 stretches are within 1 % of each other, 30 and more lose 2-4 %: profiles/r04_interleaved_scatter.txt)
+    INTERLEAVE_REGIONS = 8           # = the number of XCDs: workgroup b runs on XCD b mod 8 (round-robin dispatch) and takes a tile of stretch b mod 8, so
+                                     # every XCD writes an eighth of the cloud of its own.  Interleaved A/B in one process (profiles/r04_ab_interleave_count.txt):
+                                     # 8 -> 0.822, 16 -> 0.818, 24 / 32 -> 0.811, 3 ... 15 (no multiple of 8) -> 0.797-0.804, 18 -> 0.785
 
     FIELDS = {"points": ((3,), torch.float32), "normals": ((3,), torch.float32), "colors": ((3,), torch.uint8),
               "pixel_index": ((), torch.int32), "view_index": ((), torch.int32), "packed": ((4,), torch.float32)}
