@@ -528,8 +528,9 @@ class CloudBuilder:
 
     # A cloud that is ONE large row array (points, no normals) and was placed with its thirds in three classes of HBM is
     # filled two-pass with the scatter taking tiles of the three thirds in turn (round 4): consecutive
-    # workgroups then write three classes at once -- 0.705 instead of 0.66 of the roofline on BASELINE configs[4] with the count
-    # pass included, 0.80 for the scatter kernel alone.  Below this many rows (3 GiB of points) the count pass costs more than the interleaving wins back.
+    # workgroups then write three classes at once -- 0.72 instead of 0.66 of the roofline on BASELINE configs[4] with the count
+    # pass included, 0.815 for the scatter kernel alone (0.81 for the whole step where the count pass is guessed away: fuse_tuning).
+    # Below this many rows (3 GiB of points) the count pass costs more than the interleaving wins back.
     INTERLEAVE_MIN_ROWS = 256 << 20
     INTERLEAVE_REGIONS = 8           # = the number of XCDs: workgroup b runs on XCD b mod 8 (round-robin dispatch) and takes a tile of stretch b mod 8, so
                                      # every XCD writes an eighth of the cloud of its own.  Interleaved A/B in one process (profiles/r04_ab_interleave_count.txt):
