@@ -532,6 +532,8 @@ class CloudBuilder:
     # pass included, 0.815 for the scatter kernel alone (0.81 for the whole step where the count pass is guessed away: fuse_tuning).
     # Below this many rows (3 GiB of points) the count pass costs more than the interleaving wins back.
     INTERLEAVE_MIN_ROWS = 256 << 20
+    GUESS_MIN_PIXELS = 4 << 20       # unmasked batches from this size on run count-free (1.41x the single pass at 24 M pixels, 1.22x at 61 M, 1.11x at
+                                     # 244 M, 1.23x at 6.1 G: profiles/r04_ab_count_free_small_batches.txt); below, a launch is a few microseconds either way
     INTERLEAVE_REGIONS = 8           # = the number of XCDs: workgroup b runs on XCD b mod 8 (round-robin dispatch) and takes a tile of stretch b mod 8, so
                                      # every XCD writes an eighth of the cloud of its own.  Interleaved A/B in one process (profiles/r04_ab_interleave_count.txt):
                                      # 8 -> 0.822, 16 -> 0.818, 24 / 32 -> 0.811, 3 ... 15 (no multiple of 8) -> 0.797-0.804, 18 -> 0.785
@@ -698,18 +700,18 @@ class CloudBuilder:
         """``DDViewBatch.tuning`` with which ``append`` runs ``batch``: the batch's own, plus -- for a large stride-1 batch without
         an explicit choice of a path in its tuning --
 
-        * a placed cloud of points only whose thirds lie in three classes (``placement.layout == "blocked"``): two-pass with the
+        * a large batch (half of ``INTERLEAVE_MIN_ROWS`` pixels) into a placed cloud of points only whose thirds lie in three classes (``placement.layout == "blocked"``): two-pass with the
           scatter interleaving ``INTERLEAVE_REGIONS`` stretches of tiles (several store fronts in several classes at once);
         * a cloud without normals and a batch WITHOUT a mask or a confidence map (a depth map its producer considers complete):
           the same scatter against a count-free plan (bit 17: every pixel guessed valid, every tile verified by the scatter; a miss
           is redone by ``check()`` / ``finish()`` like a scan that gave up, once -- then this cloud stops guessing)."""
         t = batch.tuning
-        if (t & (1 | 4 | 8 | 0x3F00 | _lib.DD_TUNE_ASSUME_DENSE)) or batch.stride != 1 or batch._knots is not None \
-                or batch.max_points < self.INTERLEAVE_MIN_ROWS // 2:
+        if (t & (1 | 4 | 8 | 0x3F00 | _lib.DD_TUNE_ASSUME_DENSE)) or batch.stride != 1 or batch._knots is not None:
             return t
         blocked = (self.placement is not None and self.placement.layout == "blocked"
-                   and self.placement.mode.startswith(("probed", "degraded")))
+                   and self.placement.mode.startswith(("probed", "degraded")) and batch.max_points >= self.INTERLEAVE_MIN_ROWS // 2)
         guess = (self.normal is None and batch.mask is None and batch.conf is None and self.speculate_dense and not self.dense_misses
+                 and batch.max_points >= self.GUESS_MIN_PIXELS
                  and self.capacity >= batch.max_points)       # (a cloud sized below the pixel count says the maps have holes)
         if blocked or guess:
             # (+ bit 128: dense tiles take the list-free path -- in the scatter pass, which waits for no look-back, its smaller

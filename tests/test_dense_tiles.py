@@ -274,7 +274,8 @@ def test_a_blocked_cloud_of_points_is_filled_in_thirds(dd):
         assert b.placement.layout == "blocked", b.placement.as_dict()
         tun = b.fuse_tuning(masked)
         assert tun & 4 and not tun & ASSUME and tun & DENSE and (tun >> 8) & 63 == K1
-        assert b.fuse_tuning(dd.ViewBatch(depth[:2], params[:2], E[:2])) == 0                 # a small batch: the fused single pass
+        assert b.fuse_tuning(dd.ViewBatch(depth[:1], params[:1], E[:1])) == 0                 # a small batch (2 M pixels): the fused single pass
+        assert b.fuse_tuning(dd.ViewBatch(depth[:4], params[:4], E[:4], mask=mask[:4])) == 0  # a masked batch below half the threshold: too
         assert b.fuse_tuning(dd.ViewBatch(depth, params, E, tuning=8)) == 8                   # an explicit choice stands
         b.append(masked)
         got_masked = b.finish()
