@@ -230,6 +230,9 @@ class PendingCheck:
             raise OverflowError(f"cloud capacity {b.capacity} < {total} valid points; "
                                 "allocate with capacity=batch.max_points or count_valid() first")
         if b._epoch == self._epoch:
+            if not bad and b._guesses_pending:
+                CloudBuilder.guess_hits += b._guesses_pending      # every guess appended so far held
+                b._guesses_pending = 0
             b._release_retained(total)
         return total
 
@@ -534,6 +537,10 @@ class CloudBuilder:
     INTERLEAVE_MIN_ROWS = 256 << 20
     GUESS_MIN_PIXELS = 4 << 20       # unmasked batches from this size on run count-free (1.41x the single pass at 24 M pixels, 1.22x at 61 M, 1.11x at
                                      # 244 M, 1.23x at 6.1 G: profiles/r04_ab_count_free_small_batches.txt); below, a launch is a few microseconds either way
+    # the guesses of ALL clouds of the process: a scan after scan of sensor depth with holes would otherwise pay one redo per cloud.
+    # A cloud guesses only while the misses so far do not outnumber the guesses that held (0 : 0 at the start: the first one is free)
+    guess_hits = 0
+    guess_misses = 0
     INTERLEAVE_REGIONS = 8           # = the number of XCDs: workgroup b runs on XCD b mod 8 (round-robin dispatch) and takes a tile of stretch b mod 8, so
                                      # every XCD writes an eighth of the cloud of its own.  Interleaved A/B in one process (profiles/r04_ab_interleave_count.txt):
                                      # 8 -> 0.822, 16 -> 0.818, 24 / 32 -> 0.811, 3 ... 15 (no multiple of 8) -> 0.797-0.804, 18 -> 0.785
@@ -607,6 +614,7 @@ class CloudBuilder:
         self._retain_base: Optional[int] = None      # row the retained batches start from (None: the cloud's start)
         self._epoch = 0                              # counts reset(): a PendingCheck knows which cloud it was asked about
         self.healed = 0
+        self._guesses_pending = 0
         self.speculate_dense = True                  # fuse_tuning may run unmasked batches of a blocked cloud without the counting pass
         self.dense_misses = 0                        # ... until one of them was not dense (then never again on this cloud)
 
@@ -620,6 +628,7 @@ class CloudBuilder:
 
     def reset(self) -> None:
         self._epoch += 1
+        self._guesses_pending = 0                    # (guesses nobody looked at are neither hits nor misses)
         self._set_start()
         self._offsets.clear()
         self._workspaces.clear()
@@ -681,6 +690,8 @@ class CloudBuilder:
             return offsets
         saved = batch.tuning
         batch.tuning = self.fuse_tuning(batch)
+        if (batch.tuning & ~saved) & _lib.DD_TUNE_ASSUME_DENSE:
+            self._guesses_pending += 1                # (the policy's guess, not the caller's bit: scored when the status is read)
         try:
             cb = batch.c_struct()
             ws = self._workspace(batch.workspace_bytes())
@@ -711,7 +722,7 @@ class CloudBuilder:
         blocked = (self.placement is not None and self.placement.layout == "blocked"
                    and self.placement.mode.startswith(("probed", "degraded")) and batch.max_points >= self.INTERLEAVE_MIN_ROWS // 2)
         guess = (self.normal is None and batch.mask is None and batch.conf is None and self.speculate_dense and not self.dense_misses
-                 and batch.max_points >= self.GUESS_MIN_PIXELS
+                 and CloudBuilder.guess_misses <= CloudBuilder.guess_hits and batch.max_points >= self.GUESS_MIN_PIXELS
                  and self.capacity >= batch.max_points)       # (a cloud sized below the pixel count says the maps have holes)
         if blocked or guess:
             # (+ bit 128: dense tiles take the list-free path -- in the scatter pass, which waits for no look-back, its smaller
@@ -821,6 +832,9 @@ class CloudBuilder:
         self.healed += 1
         if dense_miss:
             self.dense_misses += 1                           # this cloud stops guessing (fuse_tuning)
+            if self._guesses_pending:                        # (the policy's guess, not a bit the caller set)
+                CloudBuilder.guess_misses += 1
+            self._guesses_pending = 0
         total = int(self.cursor.item())
         if self._scan_gave_up():                             # cannot happen: the two-pass kernels have no look-back
             raise RuntimeError("libddcore: the two-pass redo reported a scan time-out")
