@@ -21,7 +21,7 @@ import torch  # noqa: F401  (load order, see above)
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("DDCORE_LIB", _HERE / "libddcore.so"))
 
-DD_ABI_VERSION = 10
+DD_ABI_VERSION = 11
 DD_OK = 0
 DD_F32, DD_F16 = 0, 1
 DD_VALID_DEPTH_POSITIVE = 0x1

@@ -35,23 +35,47 @@ namespace {
 constexpr int BLOCK = 256;
 constexpr int WAVES = BLOCK / 64;
 
+// A look-back granule: [63:62] status | [61:44] epoch of the call that wrote it | [43:0] value.  The epoch makes every granule
+// of an earlier call read as "not published" without anybody zeroing it: a single-pass call is ONE stream operation (round 5;
+// rounds 1-4 zeroed the granules with a memset in front of every kernel and copied the cursor behind it).
+constexpr int EPOCH_SHIFT = 44, EPOCH_BITS = 18;
+constexpr unsigned EPOCH_MAX = (1u << EPOCH_BITS) - 1u;
 constexpr unsigned long long ST_AGG = 1ull << 62;   // value = number of valid pixels of the tile
 constexpr unsigned long long ST_INCL = 2ull << 62;  // value = slot after the tile's last point
-constexpr unsigned long long VAL_MASK = (1ull << 62) - 1;
+constexpr unsigned long long POISON = 1ull << (EPOCH_SHIFT - 1);      // inclusive granule of a tile that does not know its first row (a look-back
+                                                                      // gave up somewhere before it): whoever reads it does not know its own either
+constexpr unsigned long long VAL_MASK = POISON - 1;                   // rows below 2^43
+constexpr unsigned TAG_AGG = 1u << EPOCH_BITS, TAG_INCL = 2u << EPOCH_BITS;   // granule >> EPOCH_SHIFT == TAG_x | epoch
 constexpr unsigned SPIN_LIMIT = 1u << 21;
 
-struct WsHeader {          // 32 bytes at the start of the workspace
+struct WsHeader {          // 64 bytes at the start of the workspace
     // first 16 bytes: STICKY -- never zeroed by the library.  `error` (int32 word 1 of the workspace) is set when an
     // in-kernel look-back gives up and stays set over later calls on the same workspace until the caller clears
     // it, so a caller that chains many batches through one workspace checks it once at the end.
     unsigned int pad0;
     int error;
     unsigned int pad1[2];
-    // second 16 bytes + the tile granules behind them: zeroed by every single-pass call (one 16-B aligned memset)
+    // state of the single-pass kernel, all zero between calls except `epoch`: the workgroup that is the LAST of a call to
+    // finish its look-back writes the cursor, puts ticket and done back to zero and advances the epoch (when the epoch
+    // wraps -- every 2^18 calls -- it also zeroes every record of the workspace, so a stale tag can never match)
     unsigned int ticket;
-    unsigned int pad2[3];
+    unsigned int done;
+    unsigned int epoch;
+    unsigned int pad2;
+    long long pad3[4];
 };
-constexpr size_t WS_STICKY = 16;   // bytes in front of the per-call state
+static_assert(sizeof(WsHeader) == 64, "workspace header");
+
+// behind the header: the look-back granules of the single-pass kernels, 8 bytes per tile, PACKED (a polling lane fetches two
+// of them with one 16-byte load: a poll costs per request, not per byte -- profiles/r05_streaming_poll_width.txt), then the
+// count / first row of every tile for the two-pass kernels, then 8 bytes per view.  Calls with different tilings lay these
+// regions out differently on the same workspace; whatever a two-pass call leaves where a later single-pass call has its
+// granules reads as "not published": a {count, row} pair has its top two bits clear (rows < 2^30), and so has a view total.
+struct TileCO {
+    unsigned cnt;             // two-pass: valid pixels of the tile
+    unsigned off;             // two-pass: first row of the tile inside its view (< 2^30: see above)
+};
+static_assert(sizeof(TileCO) == 8, "tile record");
 
 struct KArgs {
     const void *depth;
@@ -73,10 +97,10 @@ struct KArgs {
     const long long *cursor;
     long long *cursor_out;        // two-pass: scan_views stores the row after the batch here (may be NULL)
     WsHeader *hdr;
-    unsigned long long *tile_state;
+    unsigned long long *gran;     // look-back granules, one per tile of the single-pass tiling
+    TileCO *tiles;                // two-pass: count and first row of every tile (NULL in dd_count_valid)
+    unsigned long long ws_words;  // 8-byte words of the caller's workspace behind the header (what a wrap of the epoch zeroes)
     unsigned long long *counts;   // per-view counts (dd_count_valid)
-    unsigned *tile_cnt;           // two-pass: valid pixels per tile
-    unsigned *tile_off;           // two-pass: first row of the tile inside its view
     long long *view_tot;          // two-pass: valid pixels per view
     long long hw;                 // H*W
     int V, H, W, stride;
@@ -92,11 +116,20 @@ struct KArgs {
     unsigned spin_limit;          // look-back polls before a tile gives up (SPIN_LIMIT; 0 with the fault-injection tuning bit 64)
     int dense_ok;                 // lean kernels: tiles whose pixels all survive take the list-free path (dense_wave)
     unsigned order_regions;       // two-pass scatter: 1 = tiles in order, K > 1 = K stretches of the batch interleaved (tuning bits 8-13)
+    int static_tiles;             // single-pass: tile = workgroup index instead of a ticket (tuning bit 22)
+    unsigned lb_lanes;            // single-pass: lanes that poll in a look-back round (window of 16 / 32 / 64 tiles)
     int assume_dense;             // scatter pass: the plan was written WITHOUT counting, as if every visited pixel were valid (tuning bit 17);
                                   // a tile that finds otherwise sets the workspace's error word to 2 (the rows are then invalid: redo)
 };
 
 
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+// two neighbouring granules (16-byte aligned pair) with ONE agent-scope load
+__device__ __forceinline__ u32x4_t ld_state_pair(const unsigned long long *p) {
+    u32x4_t v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
 __device__ __forceinline__ unsigned long long ld_state(unsigned long long *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -169,18 +202,60 @@ __device__ __forceinline__ void wave_rank(unsigned bits, int lane, int &lane_pre
     wave_total = tot;
 }
 
+// ---- the end of a single-pass call, inside the kernel ----------------------------------------------
+// The batch's LAST tile (the one with the last ticket) closes the call as soon as its own look-back is over: it writes the
+// cursor, puts the ticket back to zero and advances the epoch.  That is safe because by then every tile of the call
+//   * has drawn its ticket (tickets are drawn in order),
+//   * has read the epoch (its aggregate granule, which the last tile's look-back has seen or summed over, carries it), and
+//   * has read the cursor (load_cursor: the load is complete before the tile publishes anything),
+// and nothing else of what the close changes is read inside a call.  No atomic, no fence, nobody waits.
+// Only when the epoch wraps (every 2^18 calls) the granules themselves must be zeroed, and that has to wait until the LAST
+// look-back of the call is over: in that one call every tile counts itself done (tile_done) and whoever counts last zeroes
+// every record the workspace holds and closes the call.
+__device__ __forceinline__ long long load_cursor(const long long *cursor) {
+    const long long base = *cursor;
+    // the value in scalar registers HERE, and no later memory operation moved in front of this point
+    asm volatile("" ::"s"((unsigned)(unsigned long long)base), "s"((unsigned)((unsigned long long)base >> 32)) : "memory");
+    return base;
+}
+__device__ __forceinline__ void close_call(WsHeader *h, long long *cursor_out, long long row_after_batch, unsigned epoch) {
+    *cursor_out = row_after_batch;          // (garbage if a look-back gave up: the error word says so)
+    h->ticket = 0u;
+    h->epoch = epoch == EPOCH_MAX ? 0u : epoch + 1u;
+}
+// wave 0 of every tile of the call in which the epoch wraps, all 64 lanes, after the tile's look-back
+__device__ __forceinline__ void wrap_call(WsHeader *h, unsigned long long *gran, unsigned long long ws_words, long long *cursor_out,
+                                          unsigned T, int lane) {
+    unsigned before = 0u;
+    if (lane == 0) before = __hip_atomic_fetch_add(&h->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)__builtin_amdgcn_readfirstlane((int)before) != T - 1u) return;
+    unsigned long long last;                // the row after the batch: the inclusive granule of the batch's last tile (stored before
+    do {                                    // that tile counted itself done: on its way if it is not there yet)
+        last = ld_state(&gran[T - 1u]);
+    } while ((unsigned)(last >> EPOCH_SHIFT) != (TAG_INCL | EPOCH_MAX));
+    for (unsigned long long i = (unsigned long long)lane; i < ws_words; i += 64ull) gran[i] = 0ull;
+    if (lane == 0) {
+        h->done = 0u;
+        close_call(h, cursor_out, (long long)(last & VAL_MASK), EPOCH_MAX);
+    }
+}
+
 // ---- decoupled look-back (wave 0 of the workgroup, all 64 lanes) ---------------------------------
-__device__ __forceinline__ long long lookback(unsigned long long *state, unsigned t, long long agg,
-                                              long long base, int lane, int *err) {
-    if (lane == 0) st_state(&state[t], ST_AGG | (unsigned long long)agg);
+__device__ __forceinline__ long long lookback(unsigned long long *gran, unsigned t, long long agg,
+                                              long long base, int lane, int *err, const unsigned epoch) {
+    const unsigned long long tag_agg = (unsigned long long)(TAG_AGG | epoch) << EPOCH_SHIFT;
+    const unsigned long long tag_incl = (unsigned long long)(TAG_INCL | epoch) << EPOCH_SHIFT;
+    if (lane == 0) st_state(&gran[t], tag_agg | (unsigned long long)agg);
     long long excl = 0;
     long long look = (long long)t - 1;   // lane 0 inspects the nearest predecessor
     unsigned spins = 0;
+    bool poisoned = false;               // -> returns -1: the tile's first row is unknown, it must not write anything
     for (;;) {
         const long long idx = look - lane;
         // tiles "before the first" hold the cursor the batch starts from
-        const unsigned long long s = (idx >= 0) ? ld_state(&state[idx]) : (ST_INCL | (unsigned long long)base);
-        const unsigned st = (unsigned)(s >> 62);
+        const unsigned long long s = (idx >= 0) ? ld_state(&gran[idx]) : (tag_incl | (unsigned long long)base);
+        const unsigned tag = (unsigned)(s >> EPOCH_SHIFT);
+        const unsigned st = tag == (TAG_INCL | epoch) ? 2u : tag == (TAG_AGG | epoch) ? 1u : 0u;   // another call's granule: not published
         const unsigned long long incl_b = __ballot(st == 2u);
         const unsigned long long empty_b = __ballot(st == 0u);
         const int first_incl = incl_b ? __builtin_ctzll(incl_b) : 64;
@@ -188,6 +263,7 @@ __device__ __forceinline__ long long lookback(unsigned long long *state, unsigne
         if (empty_b & need) {            // a predecessor we depend on has not published yet
             if (++spins > SPIN_LIMIT) {  // bounded: report and let successors proceed
                 if (lane == 0) atomicExch(err, 1);
+                poisoned = true;
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
@@ -197,11 +273,14 @@ __device__ __forceinline__ long long lookback(unsigned long long *state, unsigne
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) val += __shfl_xor(val, off);
         excl += val;
-        if (incl_b) break;
+        if (incl_b) {
+            poisoned = (__ballot(lane == first_incl && (s & POISON) != 0ull) != 0ull);
+            break;
+        }
         look -= 64;
     }
-    if (lane == 0) st_state(&state[t], ST_INCL | (unsigned long long)(excl + agg));
-    return excl;
+    if (lane == 0) st_state(&gran[t], tag_incl | (poisoned ? POISON : 0ull) | ((unsigned long long)(excl + agg) & VAL_MASK));
+    return poisoned ? -1ll : excl;
 }
 
 // ---- generic scatter kernel (two-pass by default; SINGLE_PASS = ticket + look-back variant) -------
@@ -217,12 +296,15 @@ __global__ __launch_bounds__(BLOCK) void compact_generic(const KArgs a) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
-    unsigned t;
+    unsigned t, epoch = 0u;
+    long long base = 0;
     if constexpr (SINGLE_PASS) {
+        epoch = a.hdr->epoch;
+        base = load_cursor(a.cursor);
         if (tid == 0) s_ticket = atomicAdd(&a.hdr->ticket, 1u);
         __syncthreads();
         t = __builtin_amdgcn_readfirstlane(s_ticket);
-        if (t >= a.num_tiles) return;
+        if (t >= a.num_tiles) return;          // (never: the grid is num_tiles workgroups)
     } else {
         t = blockIdx.x;
     }
@@ -265,19 +347,20 @@ __global__ __launch_bounds__(BLOCK) void compact_generic(const KArgs a) {
 
     if constexpr (SINGLE_PASS) {
         if (wave == 0) {
-            const long long base = *a.cursor;
-            const long long e = lookback(a.tile_state, t, n, base, lane, &a.hdr->error);
+            const long long e = lookback(a.gran, t, n, base, lane, &a.hdr->error, epoch);
             if (lane == 0) {
                 s_excl = e;
                 if (tv == 0) a.view_offsets[v] = e;
                 if (t == a.num_tiles - 1) a.view_offsets[a.V] = e + n;
             }
+            if (epoch == EPOCH_MAX) wrap_call(a.hdr, a.gran, a.ws_words, a.cursor_out, a.num_tiles, lane);
+            else if (lane == 0 && t == a.num_tiles - 1) close_call(a.hdr, a.cursor_out, e + n, epoch);
         }
     }
     __syncthreads();
     long long excl;
     if constexpr (SINGLE_PASS) excl = s_excl;
-    else excl = a.view_offsets[v] + (long long)a.tile_off[t];
+    else excl = a.view_offsets[v] + (long long)a.tiles[t].off;
 
     // ---- one lane per output point ----
     const DDViewParams *vp = a.params + v;
@@ -288,6 +371,7 @@ __global__ __launch_bounds__(BLOCK) void compact_generic(const KArgs a) {
     const bool rotate = a.flags & DD_ROTATE_NORMALS;
     const long long vbase = (long long)v * a.hw;
 
+    if (excl < 0) return;             // single-pass: the tile's first row is unknown (a look-back gave up): nothing is written
     for (int j = tid; j < n; j += BLOCK) {
         const long long slot = excl + j;
         if (slot >= a.capacity) break;
@@ -379,6 +463,19 @@ constexpr int L_TILE = WAVES * L_WSPAN;      // 4096
 #define DD_SP_WAVES 12
 #endif
 constexpr int SP_WAVES = DD_SP_WAVES;         // single-pass variant: 12 waves, 12288-pixel tiles (8: +3 %, 16: +3 %, 4: +7 % time)
+#ifndef DD_SP_PXT_SMALL
+#define DD_SP_PXT_SMALL 8
+#endif
+#ifndef DD_SP_SMALL_BATCH_TILES
+#define DD_SP_SMALL_BATCH_TILES 2048
+#endif
+// A small batch (a streamed view or a few: scripts/test.py:131 densifies one view per loop iteration, pipeline.py eight per launch)
+// does not fill the chip even once, so a tile's lifetime IS the kernel's: 8 pixels per lane instead of 16 -- 6144-pixel tiles -- halve
+// the chain of gather / store sweeps every lane walks through and double the workgroups (profiles/r05_stamps_small_batches.txt:
+// of the 17 us a 12288-pixel tile of a one-view launch lives, 8.5 are those sweeps, 16 times one memory latency that nothing hides).
+constexpr int SP_PXT_SMALL = DD_SP_PXT_SMALL;
+constexpr unsigned long long SP_SMALL_BATCH_TILES = DD_SP_SMALL_BATCH_TILES;   // batches of up to this many 12288-pixel tiles take the small tile
+static_assert(DD_SP_WAVES * 64 * DD_SP_PXT_SMALL >= 4096, "the workspace holds one record per 4096 pixels: the small single-pass tile must not be finer");
 
 typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
 typedef float f32x3 __attribute__((ext_vector_type(3)));
@@ -426,12 +523,13 @@ template <> __device__ __forceinline__ void set_raw<_Float16>(uint4 &d, int k, u
 // the compiler issues them all before the first use: a vector that would cross the end of the view is read from
 // the view's last VEC pixels instead (P >= VEC), and -- only in the wave that holds the end of a view whose pixel
 // count is not a multiple of VEC, a wave-uniform branch -- the one partial vector is re-read element by element.
-template <typename DepthT, bool HAS_MASK, bool NEED_DEPTH>
+template <typename DepthT, bool HAS_MASK, bool NEED_DEPTH, int PXT = L_PXT>
 __device__ __forceinline__ void lean_load_test(const KArgs &a, long long vbase, unsigned qw, int lane,
-                                               uint4 (&d)[L_PXT / (16 / (int)sizeof(DepthT))],
-                                               unsigned (&bits)[L_PXT / (16 / (int)sizeof(DepthT))]) {
+                                               uint4 (&d)[PXT / (16 / (int)sizeof(DepthT))],
+                                               unsigned (&bits)[PXT / (16 / (int)sizeof(DepthT))]) {
     // NEED_DEPTH = false: pass 1 under a mask-only validity rule touches 1 B/px instead of 5
-    constexpr int VEC = 16 / (int)sizeof(DepthT), CH = L_PXT / VEC;
+    constexpr int VEC = 16 / (int)sizeof(DepthT), CH = PXT / VEC;
+    static_assert(PXT % VEC == 0 && CH >= 1, "a lane owns whole vectors");
     unsigned mk[CH][VEC / 4];
     unsigned nvalid[CH];                      // pixels of the vector that exist: VEC, 0, or 1..VEC-1 at a ragged view end
     long long eload[CH];
@@ -482,7 +580,7 @@ __device__ __forceinline__ void lean_load_test(const KArgs &a, long long vbase, 
     }
     // ragged end of a view (P % VEC != 0): this wave holds it iff its span crosses P.  One lane re-reads its
     // partial vector element by element (indices clamped to the view, validity comes from nvalid).
-    if ((a.P % (unsigned)VEC) != 0u && qw < a.P && qw + (unsigned)L_WSPAN > a.P) {
+    if ((a.P % (unsigned)VEC) != 0u && qw < a.P && qw + (unsigned)(64 * PXT) > a.P) {
 #pragma unroll
         for (int ch = 0; ch < CH; ++ch) {
             if (nvalid[ch] != 0u && nvalid[ch] != (unsigned)VEC) {
@@ -536,84 +634,109 @@ __device__ __forceinline__ void lean_load_test(const KArgs &a, long long vbase, 
     }
 }
 
-// Look-back over tile aggregates of at most 16 bits (tiles of <= 12288 pixels).  Every lane inspects LB_K granules (window = 64*LB_K tiles per
-// round trip, nearest tiles in lane 0).  Measured on MI355X (185x1080p): LB_K = 1 -> 3.57 ms, 4 -> 5.50 ms,
-// 8 -> 6.09 ms against 3.45 ms for the dependency-free two-pass path on the same GPU: the sc1 polling
-// loads are served across XCDs through the fabric and compete with the data streams, so a wider window
-// costs more than the round trips it saves.  Narrower is better still: 16 polling lanes (one or two
-// 128-B lines per poll) -> 3.02 ms.  LB_K stays 1, LB_LANES 16.  With 12288-pixel tiles (one look-back per three
-// times the work) and the other waves gathering during the look-back, single-pass then beat two-pass on every
-// workload and became the default of dd_unproject_compact.
-// Aggregates fit 16 bits: their wave sum is taken with bit-sliced ballots (scalar popcounts) and the
+// Look-back over tile aggregates of at most 14 bits (tiles of <= 12288 pixels).  Measured on MI355X in rounds 1-4: a poll costs per
+// REQUEST (one per polling lane), whatever the window: 64 lanes x 1 granule 3.57 ms, x 4 5.50, x 8 6.09 (185 x 1080p, round 1);
+// 16 lanes 3.02; 8 / 4 lanes -7 / -9 %; 32 / 64 lanes: the round takes proportionally longer (round 4).  Round 5: the BYTES of a
+// request are free (a 16-byte poll costs what an 8-byte poll costs, profiles/r05_streaming_poll_width.txt), but fetching an aligned
+// PAIR of the packed granules per lane -- 32 tiles per round with 16 requests, -DDD_LB_PAIR=1 -- is 0.5-2.7 % SLOWER on every
+// workload, and 8 lanes x 2 equals 16 x 1 (profiles/r05_ab_paired_polls.txt): it is the 16 NEAREST predecessors that a round can
+// use, however they are fetched.  DD_LB_PAIR stays 0.
+// Aggregates fit 14 bits: their wave sum is taken with bit-sliced ballots (scalar popcounts) and the
 // single inclusive value with a readlane -- no cross-lane data movement.
-#ifndef DD_LB_K
-#define DD_LB_K 1
-#endif
-constexpr int LB_K = DD_LB_K;
 #ifndef DD_LB_LANES
 #define DD_LB_LANES 16
+#endif
+#ifndef DD_LB_PAIR
+#define DD_LB_PAIR 0
 #endif
 #ifndef DD_LB_SLEEP
 #define DD_LB_SLEEP 1
 #endif
-constexpr int LB_LANES = DD_LB_LANES;   // lanes that actually poll (window = LB_LANES * LB_K tiles)
+constexpr int LB_LANES = DD_LB_LANES;   // lanes that poll in the steady state of a large batch (window = LB_LANES * LB_K tiles; KArgs.lb_lanes)
 
-__device__ __forceinline__ long long lookback13(unsigned long long *state, unsigned t, unsigned agg,
-                                                long long base, int lane, int *err, const unsigned spin_limit) {
+__device__ __forceinline__ long long lookback13(unsigned long long *gran, unsigned t, unsigned agg, long long base, int lane, int *err,
+                                                const unsigned spin_limit, const unsigned epoch, const int lb_lanes, const bool inject_give_up) {
+    // Every polling lane inspects one granule per round (DD_LB_PAIR = 0: the default), or fetches an aligned PAIR with one 16-byte
+    // load, so that a round inspects 2 * lb_lanes tiles: `top` is then the odd index of lane 0's pair, the pair of lane l is
+    // (top - 2l - 1, top - 2l), nearest tile first; in the first round lane 0's pair may hold the tile's own granule (t even): skipped.
+    const unsigned tag_a = TAG_AGG | epoch, tag_i = TAG_INCL | epoch;
+    const unsigned long long none = (unsigned long long)tag_a << EPOCH_SHIFT;      // "aggregate, 0 points": contributes nothing, never blocks
+    const unsigned long long start = ((unsigned long long)tag_i << EPOCH_SHIFT) | (unsigned long long)base;   // tiles "before the first" hold the cursor
+    const long long hi = (long long)t - 1;    // nearest predecessor
+#if DD_LB_PAIR
+    long long top = hi | 1ll;
+#else
+    long long top = hi;
+#endif
     long long excl = 0;
-    long long look = (long long)t - 1;        // nearest predecessor = lane 0, k 0
     unsigned spins = 0;
+    bool poisoned = false;                    // -> returns -1: the tile's first row is unknown, it must not write anything
     for (;;) {
-        unsigned long long s[LB_K];
-#pragma unroll
-        for (int k = 0; k < LB_K; ++k) {
-            const long long idx = look - (long long)(lane * LB_K + k);
-            if (lane < LB_LANES) s[k] = (idx >= 0) ? ld_state(&state[idx]) : (ST_INCL | (unsigned long long)base);
-            else s[k] = ST_AGG;          // lanes outside the window contribute nothing and never block
+        unsigned long long s[2] = {none, none};
+#if !DD_LB_PAIR     // (A/B: one 8-byte granule per polling lane, as in rounds 1-4)
+        if (lane < lb_lanes) s[0] = (top - lane >= 0) ? ld_state(gran + (top - lane)) : start;
+#else
+        if (lane < lb_lanes) {
+            const long long i1 = top - 2ll * lane, i0 = i1 - 1;      // i1 odd, i0 even
+            if (i1 >= 0) {
+                const u32x4_t v = ld_state_pair(gran + i0);
+                s[0] = ((unsigned long long)v.w << 32) | v.z;         // granule i1 (nearer)
+                s[1] = ((unsigned long long)v.y << 32) | v.x;         // granule i0
+                if (i1 > hi) s[0] = none;                             // the tile's own granule
+            } else {
+                s[0] = start;
+            }
         }
-        int incl_k = LB_K;                    // first inclusive granule among this lane's (nearest first)
+#endif
+        int incl_k = 2;                       // first inclusive granule among this lane's (nearest first)
         bool empty_before = false;            // an unpublished granule in front of it
         unsigned agg_before = 0;
         unsigned long long incl_val = 0;
 #pragma unroll
-        for (int k = LB_K - 1; k >= 0; --k) {
-            const unsigned st = (unsigned)(s[k] >> 62);
-            if (st == 2u) { incl_k = k; incl_val = s[k] & VAL_MASK; }
+        for (int k = 1; k >= 0; --k) {
+            if ((unsigned)(s[k] >> EPOCH_SHIFT) == tag_i) { incl_k = k; incl_val = s[k] & (VAL_MASK | POISON); }
         }
 #pragma unroll
-        for (int k = 0; k < LB_K; ++k) {
+        for (int k = 0; k < 2; ++k) {
             if (k < incl_k) {
-                const unsigned st = (unsigned)(s[k] >> 62);
-                empty_before |= (st == 0u);
-                agg_before += (unsigned)s[k];             // aggregates: value bits only (status 1 sits in bit 62)
+                const bool is_agg = (unsigned)(s[k] >> EPOCH_SHIFT) == tag_a;      // anything else (zero, another call's tag): not published
+                empty_before |= !is_agg;
+                agg_before += is_agg ? (unsigned)s[k] : 0u;   // aggregates: value bits only (< 2^14 each)
             }
         }
-        const unsigned long long incl_b = __ballot(incl_k < LB_K);
+        const unsigned long long incl_b = __ballot(incl_k < 2);
         const int L = incl_b ? __builtin_ctzll(incl_b) : 64;
         const unsigned long long need = (L >= 63) ? ~0ull : ((2ull << L) - 1ull);   // lanes 0..L
         if (__ballot(empty_before) & need) {
             if (++spins > spin_limit) {
                 if (lane == 0) atomicExch(err, 1);
+                poisoned = true;
                 break;
             }
             __builtin_amdgcn_s_sleep(DD_LB_SLEEP);
             continue;
         }
-        const unsigned mine = (lane <= L) ? agg_before : 0u;       // <= LB_K * 12288 < 2^16
+        const unsigned mine = (lane <= L) ? agg_before : 0u;       // <= 2 * 12288 < 2^16
         unsigned sum = 0;
 #pragma unroll
         for (int b = 0; b < 16; ++b) sum += (unsigned)__popcll(__ballot((mine >> b) & 1u)) << b;
         excl += sum;
         if (incl_b) {
             const unsigned lo = __builtin_amdgcn_readlane((unsigned)incl_val, L);
-            const unsigned hi = __builtin_amdgcn_readlane((unsigned)(incl_val >> 32), L);
-            excl += (long long)(((unsigned long long)hi << 32) | lo);
+            const unsigned hi32 = __builtin_amdgcn_readlane((unsigned)(incl_val >> 32), L);
+            const unsigned long long iv = ((unsigned long long)hi32 << 32) | lo;
+            poisoned = (iv & POISON) != 0ull;
+            excl += (long long)(iv & VAL_MASK);
             break;
         }
-        look -= LB_LANES * LB_K;
+        top -= (DD_LB_PAIR ? 2ll : 1ll) * lb_lanes;
     }
-    if (lane == 0) st_state(&state[t], ST_INCL | (unsigned long long)(excl + agg));
-    return excl;
+    if (inject_give_up) {                     // tuning bit 64: this tile behaves as if its look-back had given up
+        if (lane == 0) atomicExch(err, 1);
+        poisoned = true;
+    }
+    if (lane == 0) st_state(&gran[t], ((unsigned long long)tag_i << EPOCH_SHIFT) | (poisoned ? POISON : 0ull) | ((unsigned long long)(excl + agg) & VAL_MASK));
+    return poisoned ? -1ll : excl;
 }
 
 // ==================================================================================================
@@ -867,11 +990,17 @@ __device__ __forceinline__ void dense_wave(const KArgs &a, const uint4 (&d)[L_PX
 // (12288-pixel tiles, 2 workgroups x 12 waves per CU) so that one look-back is amortised over three times the work.
 constexpr int REFINE_MAX_KNOTS = 512;
 
-template <typename DepthT, bool HAS_MASK, bool SINGLE_PASS, bool HAS_NORMAL, bool HAS_RGB, int NW, bool REFINE = false>
+// PXT = pixels per lane: 16, or 8 in the single-pass instantiation for small batches (a lane then makes half as many sweeps
+// over the tile's points: the sweeps are a chain of memory latencies that nothing hides when a CU holds one workgroup)
+template <typename DepthT, bool HAS_MASK, bool SINGLE_PASS, bool HAS_NORMAL, bool HAS_RGB, int NW, bool REFINE = false, int PXT = L_PXT>
 __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs a) {
     constexpr int BT = 64 * NW;             // threads per workgroup
-    constexpr int LT = NW * L_WSPAN;        // pixels per tile
-    constexpr int VEC = 16 / (int)sizeof(DepthT), CH = L_PXT / VEC, CSPAN = 64 * VEC;
+    constexpr int WSPAN = 64 * PXT;         // pixels per wave
+    constexpr int LT = NW * WSPAN;          // pixels per tile
+    constexpr int VEC = 16 / (int)sizeof(DepthT), CH = PXT / VEC, CSPAN = 64 * VEC;
+    // rows written past the L2 (non-temporal) in the small-batch instantiation: what a kernel leaves dirty in the L2s is written
+    // back at its end, and a chain of small calls pays that once per call (1 us of 27 per one-view call, profiles/r05_streaming_*.txt)
+    constexpr bool NT_ROWS = DD_NT_STORE != 0 || PXT != L_PXT;
     // the point list: depth (float) + 16-bit pixel per listed point.  One raw block, because the fused refine stage uses
     // the same bytes, BEFORE the list exists, for the transformed values of the tile and its halo (up to LT*6/4 floats)
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[LT * 6];
@@ -889,12 +1018,19 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
 #ifdef DD_X_STAMPS
     const unsigned long long entry_clk = __builtin_amdgcn_s_memtime(), entry_rt = __builtin_amdgcn_s_memrealtime();
 #endif
-    unsigned t;
+    unsigned t, epoch = 0u;
+    long long base = 0;
     if constexpr (SINGLE_PASS) {
-        if (tid == 0) s_ticket = atomicAdd(&a.hdr->ticket, 1u);
-        __syncthreads();
-        t = __builtin_amdgcn_readfirstlane(s_ticket);
-        if (t >= a.num_tiles) return;
+        epoch = a.hdr->epoch;                  // the tag of this call's granules (advanced by close_call)
+        base = load_cursor(a.cursor);          // the row the batch starts from, read before this tile publishes anything
+        if (a.static_tiles) {
+            t = blockIdx.x;
+        } else {
+            if (tid == 0) s_ticket = atomicAdd(&a.hdr->ticket, 1u);
+            __syncthreads();
+            t = __builtin_amdgcn_readfirstlane(s_ticket);
+        }
+        if (t >= a.num_tiles) return;          // (never: the grid is num_tiles workgroups)
     } else {
 #if DD_XCD_SWIZZLE
         {   // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous range of tiles
@@ -920,7 +1056,7 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
     const unsigned tv = t - v * a.tiles_per_view;
     const long long vbase = (long long)v * a.hw;
     const unsigned q0 = tv * (unsigned)LT;
-    const unsigned qw = q0 + (unsigned)wave * L_WSPAN;
+    const unsigned qw = q0 + (unsigned)wave * WSPAN;
 
     uint4 d[CH];
     unsigned bits[CH];
@@ -1001,7 +1137,7 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
         }
         __syncthreads();                               // s_val is dead from here: the point list takes its place
     } else {
-        lean_load_test<DepthT, HAS_MASK, true>(a, vbase, qw, lane, d, bits);
+        lean_load_test<DepthT, HAS_MASK, true, PXT>(a, vbase, qw, lane, d, bits);
     }
 
     int lane_pre[CH], tot[CH], m = 0;
@@ -1023,7 +1159,7 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
         n += s_tot[w];
     }
     if constexpr (SINGLE_PASS) {                       // publish the aggregate as early as possible
-        if (tid == 0) st_state(&a.tile_state[t], ST_AGG | (unsigned long long)n);
+        if (tid == 0) st_state(&a.gran[t], ((unsigned long long)(TAG_AGG | epoch) << EPOCH_SHIFT) | (unsigned long long)n);
     } else {
         // tuning bit 17: the rows of this tile were assigned without a count, on the assumption that every pixel is valid --
         // this pass reads the validity inputs anyway, so it is also the check; one miss voids the batch (error word 2)
@@ -1037,19 +1173,22 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
     }
     // wave 0: the tile's first output row by ticket order (decoupled look-back), the view offsets it defines
     auto look_back = [&]() {
-        long long e = lookback13(a.tile_state, t, n, *a.cursor, lane, &a.hdr->error, a.spin_limit);
-        if (a.spin_limit == 0u && (t & 7u) == 1u) {      // fault injection (tuning bit 64): what a give-up leaves behind --
-            e += 977;                                    // a wrong first row for this tile and the error word set
-            if (lane == 0) atomicExch(&a.hdr->error, 1);
-        }
+        // (fault injection, tuning bit 64: spin_limit is 0 -- a tile that would have to wait gives up at once -- and every eighth
+        // tile behaves as if it had.  A tile whose look-back gave up, or that read the row of one that did, gets -1: it writes
+        // nothing, so the rows of everything that was appended BEFORE stay intact, and its successors learn the same from its granule)
+        const long long e = lookback13(a.gran, t, n, base, lane, &a.hdr->error, a.spin_limit, epoch, (int)a.lb_lanes,
+                                       a.spin_limit == 0u && (t & 7u) == 1u);
         if (lane == 0) {
             s_excl = e;
             if (tv == 0) a.view_offsets[v] = e;
             if (t == a.num_tiles - 1) a.view_offsets[a.V] = e + n;
         }
+        // the end of the call (see close_call): the batch's last tile closes it -- or, when the epoch wraps, whoever finishes last
+        if (epoch == EPOCH_MAX) wrap_call(a.hdr, a.gran, a.ws_words, a.cursor_out, a.num_tiles, lane);
+        else if (lane == 0 && t == a.num_tiles - 1) close_call(a.hdr, a.cursor_out, e + n, epoch);
     };
 #if DD_DENSE
-    if constexpr (!REFINE) {
+    if constexpr (!REFINE && PXT == L_PXT) {
         if (n == (unsigned)LT && a.dense_ok) {         // workgroup-uniform: every pixel of the tile survives -> no list (dense_wave)
             static_assert(DENSE_LDS_PER_WAVE * NW <= LT * 6, "the dense path's staging fits the list's LDS");
             long long e0;
@@ -1058,8 +1197,9 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
                 __syncthreads();
                 if (wave == 5) STAMP(10);
                 e0 = uniform64(s_excl);
+                if (e0 < 0) return;                      // the tile's first row is unknown (a look-back gave up): nothing is written
             } else {
-                e0 = uniform64(a.view_offsets[v] + (long long)a.tile_off[t]);
+                e0 = uniform64(a.view_offsets[v] + (long long)a.tiles[t].off);
             }
             const float *cp = reinterpret_cast<const float *>(a.params + v);
             CamBlock cam;
@@ -1082,7 +1222,7 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 if ((bits[ch] >> k) & 1u) {
-                    s_q[r] = (unsigned short)(wave * L_WSPAN + ch * CSPAN + lane * VEC + k);
+                    s_q[r] = (unsigned short)(wave * WSPAN + ch * CSPAN + lane * VEC + k);
                     s_d[r] = raw_depth<DepthT>(d[ch], k);
                     ++r;
                 }
@@ -1173,11 +1313,8 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
         if (act) {
             f32x3 o; o.x = px; o.y = py; o.z = pz;
             if (a.out_xyz) {
-#if DD_NT_STORE
-                __builtin_nontemporal_store(o, reinterpret_cast<f32x3 *>(xb + uj * 12u));
-#else
-                *reinterpret_cast<f32x3 *>(xb + uj * 12u) = o;
-#endif
+                if constexpr (NT_ROWS) __builtin_nontemporal_store(o, reinterpret_cast<f32x3 *>(xb + uj * 12u));
+                else *reinterpret_cast<f32x3 *>(xb + uj * 12u) = o;
             }
             if (a.out_packed) {     // one aligned 16-byte store per point: a wave writes 1 KiB of whole lines
                 unsigned c = 0xff000000u;
@@ -1197,11 +1334,8 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
                 const float inv = 1.0f / (sqrtf(w0 * w0 + w1 * w1 + w2 * w2) + 1e-8f);
                 nv.x = w0 * inv; nv.y = w1 * inv; nv.z = w2 * inv;
             }
-#if DD_NT_STORE
-            if (act) __builtin_nontemporal_store(nv, reinterpret_cast<f32x3 *>(nb + uj * 12u));
-#else
-            if (act) *reinterpret_cast<f32x3 *>(nb + uj * 12u) = nv;
-#endif
+            if constexpr (NT_ROWS) { if (act) __builtin_nontemporal_store(nv, reinterpret_cast<f32x3 *>(nb + uj * 12u)); }
+            else { if (act) *reinterpret_cast<f32x3 *>(nb + uj * 12u) = nv; }
         }
         if (HAS_RGB && a.out_rgb != nullptr) {
             // rows of 4 consecutive lanes -> 12 contiguous bytes, stored by the quad's first lane
@@ -1246,11 +1380,11 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
         __syncthreads();
         if (wave == 5) STAMP(10);
         excl = uniform64(s_excl);
-        if (n == 0) return;
+        if (n == 0 || excl < 0) return;                      // (excl < 0: the tile's first row is unknown -- a look-back gave up: nothing is written)
         if (wave == 0) prep(0, pa);
     } else {
         __syncthreads();
-        excl = uniform64(a.view_offsets[v] + (long long)a.tile_off[t]);
+        excl = uniform64(a.view_offsets[v] + (long long)a.tiles[t].off);
         if (n == 0) return;
         prep(0, pa);
     }
@@ -1294,8 +1428,8 @@ __global__ __launch_bounds__(256) void plan_dense(const KArgs a, const unsigned 
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
     if (i < a.num_tiles) {
         const unsigned v = i / a.tiles_per_view, tv = i - v * a.tiles_per_view;
-        a.tile_off[i] = tv * tile;
-        a.tile_cnt[i] = a.P - tv * tile < tile ? a.P - tv * tile : tile;
+        a.tiles[i].off = tv * tile;
+        a.tiles[i].cnt = a.P - tv * tile < tile ? a.P - tv * tile : tile;
     }
     if (blockIdx.x == 0) {                            // (the cursor is read by this workgroup only, and written after it has read it)
         const long long c = *a.cursor;
@@ -1330,7 +1464,7 @@ __global__ __launch_bounds__(BLOCK) void count_lean(const KArgs a) {
     if (tid == 0) {
         unsigned n = 0;
         for (int w = 0; w < WAVES; ++w) n += s_tot[w];
-        if (a.tile_cnt) a.tile_cnt[t] = n;
+        if (a.tiles) a.tiles[t].cnt = n;
         if (a.counts && n) atomicAdd(&a.counts[v], (unsigned long long)n);
     }
 }
@@ -1341,13 +1475,12 @@ __global__ __launch_bounds__(BLOCK) void scan_view_tiles(const KArgs a) {
     __shared__ unsigned s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned v = blockIdx.x;
-    const unsigned *cnt = a.tile_cnt + (size_t)v * a.tiles_per_view;
-    unsigned *off = a.tile_off + (size_t)v * a.tiles_per_view;
+    TileCO *rec = a.tiles + (size_t)v * a.tiles_per_view;
     if (tid == 0) s_carry = 0;
     __syncthreads();
     for (unsigned b = 0; b < a.tiles_per_view; b += BLOCK) {
         const unsigned i = b + tid;
-        const unsigned x = i < a.tiles_per_view ? cnt[i] : 0u;
+        const unsigned x = i < a.tiles_per_view ? rec[i].cnt : 0u;
         unsigned incl = x;                           // inclusive scan inside the wave
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -1358,7 +1491,7 @@ __global__ __launch_bounds__(BLOCK) void scan_view_tiles(const KArgs a) {
         __syncthreads();
         unsigned pre = s_carry;
         for (int w = 0; w < wave; ++w) pre += s_w[w];
-        if (i < a.tiles_per_view) off[i] = pre + incl - x;
+        if (i < a.tiles_per_view) rec[i].off = pre + incl - x;
         __syncthreads();
         if (tid == BLOCK - 1) s_carry = pre + incl;
         __syncthreads();
@@ -1405,13 +1538,12 @@ __global__ __launch_bounds__(BLOCK) void scan_small(const KArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_base = *a.cursor;
     for (int v = 0; v < a.V; ++v) {
-        const unsigned *cnt = a.tile_cnt + (size_t)v * a.tiles_per_view;
-        unsigned *off = a.tile_off + (size_t)v * a.tiles_per_view;
+        TileCO *rec = a.tiles + (size_t)v * a.tiles_per_view;
         if (tid == 0) s_carry = 0;
         __syncthreads();
         for (unsigned b = 0; b < a.tiles_per_view; b += BLOCK) {
             const unsigned i = b + tid;
-            const unsigned x = i < a.tiles_per_view ? cnt[i] : 0u;
+            const unsigned x = i < a.tiles_per_view ? rec[i].cnt : 0u;
             unsigned incl = x;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
@@ -1422,7 +1554,7 @@ __global__ __launch_bounds__(BLOCK) void scan_small(const KArgs a) {
             __syncthreads();
             unsigned pre = s_carry;
             for (int w = 0; w < wave; ++w) pre += s_w[w];
-            if (i < a.tiles_per_view) off[i] = pre + incl - x;
+            if (i < a.tiles_per_view) rec[i].off = pre + incl - x;
             __syncthreads();
             if (tid == BLOCK - 1) s_carry = pre + incl;
             __syncthreads();
@@ -1460,7 +1592,7 @@ __global__ __launch_bounds__(BLOCK) void count_generic(const KArgs a) {
     if (tid == 0) {
         int tot = 0;
         for (int w = 0; w < WAVES; ++w) tot += s_part[w];
-        if (a.tile_cnt) a.tile_cnt[t] = (unsigned)tot;
+        if (a.tiles) a.tiles[t].cnt = (unsigned)tot;
         if (a.counts && tot) atomicAdd(&a.counts[v], (unsigned long long)tot);
     }
 }
@@ -1485,6 +1617,7 @@ struct Plan {
     bool lean;      // stride-1 maps (any size >= one vector) -> lean kernels; otherwise the generic scalar kernels
     bool single;    // dd_unproject_compact runs the single-pass kernel
     int tile;
+    int sp_pxt;     // lean single-pass kernel: pixels per lane (the tile is SP_WAVES * 64 * sp_pxt pixels)
 };
 
 int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
@@ -1541,7 +1674,9 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
     p.lean = aligned;
     // fused call: single-pass on the lean path (measured 8-23 % faster than plan + scatter on MI355X with
     // 12288-pixel tiles and a 16-granule look-back window), two-pass on the generic path
-    p.single = (b->tuning & TUNE_SINGLE_PASS) != 0 || (p.lean && (p.refine || !(b->tuning & (TUNE_TWO_PASS | TUNE_ASSUME_DENSE))));
+    // (the scalar kernels run single-pass only on request, and only on views below 2^30 pixels: what a two-pass call leaves in a
+    // workspace must read as "not published" to a later single-pass call -- see TileCO)
+    p.single = ((b->tuning & TUNE_SINGLE_PASS) != 0 && (p.lean || hw < (1ll << 30))) || (p.lean && (p.refine || !(b->tuning & (TUNE_TWO_PASS | TUNE_ASSUME_DENSE))));
     a.align_runs = (b->tuning & 32u) == 0;  // tuning bit 32: rows in list order (A/B of the line-aligned sweeps)
     // tuning bit 128: tiles whose pixels all survive take the list-free path (dense_wave).  Off by default: measured in the
     // real kernel it is the same rows with a third of the instructions, and 0-5 % SLOWER.
@@ -1551,7 +1686,22 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
     a.spin_limit = (b->tuning & 64u) ? 0u : SPIN_LIMIT;   // tuning bit 64: fault injection -- a tile that would have to wait for a
                                                           // predecessor gives up at once, and every eighth tile behaves as if it had:
                                                           // wrong rows, the workspace's error word set (tests of the caller's recovery)
-    p.tile = p.lean ? L_TILE : G_TILE;      // tiling of the two-pass kernels (count / plan / scatter)
+    // the lean single-pass kernel's tile goes by the size of the batch (round 5).  A batch that fills the chip several times over:
+    // 16 pixels per lane, 12288-pixel tiles drawn by ticket (the steady state of DESIGN.md section 4).  A streamed view or a few
+    // (scripts/test.py:131 densifies one view per loop iteration): 8 pixels per lane, 6144-pixel tiles taken by workgroup index
+    // (the workgroups of one XCD are dispatched in index order, so a tile's predecessors are never behind it in a dispatcher's
+    // queue; the ticket counter is one address that every workgroup of the launch hits at once), rows written past the L2.
+    // tuning bits 18-19: 1 / 3 force the small / large tile; bits 20-21: 1 / 2 / 3 = 16 / 32 / 64 polling lanes in the look-back
+    // (default 16: measured best at every batch size, profiles/r05_streaming_*.txt); bit 22: tiles by workgroup index.
+    {
+        const unsigned long long big_tiles = (unsigned long long)((a.P + SP_WAVES * L_WSPAN - 1) / (SP_WAVES * L_WSPAN)) * (unsigned)a.V;
+        const unsigned tsel = (b->tuning >> 18) & 3u, wsel = (b->tuning >> 20) & 3u;
+        const bool small = (tsel == 1u || (tsel == 0u && big_tiles <= SP_SMALL_BATCH_TILES)) && !p.refine;
+        p.sp_pxt = small ? SP_PXT_SMALL : L_PXT;
+        a.static_tiles = ((b->tuning >> 22) & 1u) || (small && tsel == 0u);
+        a.lb_lanes = wsel == 2u ? 32u : wsel == 3u ? 64u : (unsigned)LB_LANES;
+    }
+    p.tile = p.lean ? L_TILE : G_TILE;      // tiling of the two-pass kernels (count / plan / scatter); the finest single-pass tiling is the same
     a.tiles_per_view = (a.P + p.tile - 1) / p.tile;
     const unsigned long long nt = (unsigned long long)a.tiles_per_view * (unsigned)a.V;
     if (nt >= (1ull << 31)) return fail(DD_ERR_UNSUPPORTED, "too many tiles in one batch; split the batch");
@@ -1559,9 +1709,9 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
     return DD_OK;
 }
 
-// workspace: [WsHeader: 16 B sticky + 16 B per-call][8 B per tile, padded to 16: look-back granules | (tile_cnt u32[T], tile_off u32[T])][8 B per view]
+// workspace: [WsHeader: 16 B sticky + 48 B single-pass state][8 B per tile of the FINEST tiling, padded to 16: look-back granules][8 B per tile: count, first row][8 B per view]
 int64_t ws_bytes(const KArgs &a) {
-    return (int64_t)sizeof(WsHeader) + (((int64_t)a.num_tiles * 8 + 15) & ~(int64_t)15) + (int64_t)a.V * 8;
+    return (int64_t)sizeof(WsHeader) + (((int64_t)a.num_tiles * 8 + 15) & ~(int64_t)15) + (int64_t)a.num_tiles * 8 + (int64_t)a.V * 8;
 }
 
 int bind_workspace(KArgs &a, void *workspace, int64_t workspace_bytes) {
@@ -1569,10 +1719,11 @@ int bind_workspace(KArgs &a, void *workspace, int64_t workspace_bytes) {
     if (workspace_bytes < ws_bytes(a)) return fail(DD_ERR_WORKSPACE, "workspace too small (see dd_workspace_bytes)");
     char *w = reinterpret_cast<char *>(workspace);
     a.hdr = reinterpret_cast<WsHeader *>(w);
-    a.tile_state = reinterpret_cast<unsigned long long *>(w + sizeof(WsHeader));
-    a.tile_cnt = reinterpret_cast<unsigned *>(w + sizeof(WsHeader));
-    a.tile_off = a.tile_cnt + a.num_tiles;
-    a.view_tot = reinterpret_cast<long long *>(w + sizeof(WsHeader) + (((size_t)a.num_tiles * 8 + 15) & ~(size_t)15));
+    const size_t gran_bytes = ((size_t)a.num_tiles * 8 + 15) & ~(size_t)15;
+    a.gran = reinterpret_cast<unsigned long long *>(w + sizeof(WsHeader));
+    a.tiles = reinterpret_cast<TileCO *>(w + sizeof(WsHeader) + gran_bytes);
+    a.view_tot = reinterpret_cast<long long *>(w + sizeof(WsHeader) + gran_bytes + (size_t)a.num_tiles * 8);
+    a.ws_words = (unsigned long long)((workspace_bytes - (int64_t)sizeof(WsHeader)) / 8);   // all of it: what other calls left behind, too
     return DD_OK;
 }
 
@@ -1590,22 +1741,33 @@ int bind_output(KArgs &a, const DDViewBatch *batch, const DDCloudOut *out) {
     return DD_OK;
 }
 
-template <typename DepthT, bool SP, bool HM, bool HN>
-void launch_lean3(const KArgs &a, hipStream_t s) {
-    constexpr int NW = SP ? SP_WAVES : WAVES;
+template <typename DepthT, bool SP, bool HM, bool HN, int NW, int PXT>
+void launch_lean4(const KArgs &a, hipStream_t s) {
     const unsigned K = SP ? 1u : a.order_regions;
     const dim3 grid(K * ((a.num_tiles + K - 1u) / K)), block(64 * NW);
-    if (a.rgb && (a.out_rgb || a.out_packed)) hipLaunchKernelGGL((compact_lean<DepthT, HM, SP, HN, true, NW>), grid, block, 0, s, a);   // colours gathered
-    else hipLaunchKernelGGL((compact_lean<DepthT, HM, SP, HN, false, NW>), grid, block, 0, s, a);
+    if (a.rgb && (a.out_rgb || a.out_packed)) hipLaunchKernelGGL((compact_lean<DepthT, HM, SP, HN, true, NW, false, PXT>), grid, block, 0, s, a);   // colours gathered
+    else hipLaunchKernelGGL((compact_lean<DepthT, HM, SP, HN, false, NW, false, PXT>), grid, block, 0, s, a);
+}
+
+// sp_pxt: pixels per lane of the single-pass kernel (the tile is SP_WAVES * 64 * sp_pxt pixels): L_PXT for a batch that fills
+// the chip several times over, SP_PXT_SMALL for a streamed view or a few (make_plan)
+template <typename DepthT, bool SP, bool HM, bool HN>
+void launch_lean3(const KArgs &a, hipStream_t s, int sp_pxt) {
+    if constexpr (SP) {
+        if (sp_pxt == SP_PXT_SMALL) launch_lean4<DepthT, SP, HM, HN, SP_WAVES, SP_PXT_SMALL>(a, s);
+        else launch_lean4<DepthT, SP, HM, HN, SP_WAVES, L_PXT>(a, s);
+    } else {
+        launch_lean4<DepthT, SP, HM, HN, WAVES, L_PXT>(a, s);
+    }
 }
 
 template <typename DepthT, bool SP>
-void launch_lean(const KArgs &a, hipStream_t s) {
+void launch_lean(const KArgs &a, hipStream_t s, int sp_pxt) {
     const bool hm = a.flags & DD_VALID_MASK, hn = a.out_normal != nullptr;
-    if (hm && hn) launch_lean3<DepthT, SP, true, true>(a, s);
-    else if (hm) launch_lean3<DepthT, SP, true, false>(a, s);
-    else if (hn) launch_lean3<DepthT, SP, false, true>(a, s);
-    else launch_lean3<DepthT, SP, false, false>(a, s);
+    if (hm && hn) launch_lean3<DepthT, SP, true, true>(a, s, sp_pxt);
+    else if (hm) launch_lean3<DepthT, SP, true, false>(a, s, sp_pxt);
+    else if (hn) launch_lean3<DepthT, SP, false, true>(a, s, sp_pxt);
+    else launch_lean3<DepthT, SP, false, false>(a, s, sp_pxt);
 }
 
 void launch_refine(const KArgs &a, hipStream_t s) {
@@ -1624,7 +1786,7 @@ void launch_scatter(const Plan &p, const KArgs &a, hipStream_t s) {
         return;
     }
     if (p.lean) {
-        if (p.f16) launch_lean<_Float16, SP>(a, s); else launch_lean<float, SP>(a, s);
+        if (p.f16) launch_lean<_Float16, SP>(a, s, p.sp_pxt); else launch_lean<float, SP>(a, s, p.sp_pxt);
     } else {
         const dim3 grid(a.num_tiles), block(BLOCK);
         if (p.f16) hipLaunchKernelGGL((compact_generic<_Float16, SP>), grid, block, 0, s, a);
@@ -1740,24 +1902,17 @@ int dd_unproject_compact(const DDViewBatch *batch, const DDCloudOut *out, int64_
     a.view_offsets = reinterpret_cast<long long *>(view_offsets_dev);
     a.cursor = reinterpret_cast<const long long *>(cursor_dev);
 
+    a.cursor_out = reinterpret_cast<long long *>(cursor_dev);   // the kernels advance the cursor themselves
     if (p.single) {
-        if (p.lean) {   // the single-pass lean kernel works on SP_WAVES * 1024 = 12288-pixel tiles
-            a.tiles_per_view = (a.P + SP_WAVES * L_WSPAN - 1) / (SP_WAVES * L_WSPAN);
+        if (p.lean) {   // the single-pass lean kernel works on SP_WAVES * 64 * sp_pxt-pixel tiles (12288, or 6144 for a small batch)
+            a.tiles_per_view = (a.P + SP_WAVES * 64 * p.sp_pxt - 1) / (SP_WAVES * 64 * p.sp_pxt);
             a.num_tiles = a.tiles_per_view * (unsigned)a.V;
         }
-        // every look-back granule and the ticket start from zero on every call; the error word is sticky
-        // (16-B aligned start, byte count a multiple of 16: the cheap memset shape)
-        const size_t zero_bytes = (sizeof(WsHeader) - WS_STICKY + (size_t)a.num_tiles * 8 + 15) & ~(size_t)15;
-        if (hipMemsetAsync(reinterpret_cast<char *>(workspace) + WS_STICKY, 0, zero_bytes, s) != hipSuccess)
-            return fail(DD_ERR_LAUNCH, "hipMemsetAsync(workspace) failed");
+        // ONE stream operation: the granules are tagged with the workspace's call epoch (nothing is zeroed), and the last tile
+        // to finish its look-back writes the cursor and closes the call (close_call)
         launch_scatter<true>(p, a, s);
-        if ((rc = check_launch("dd_unproject_compact")) != DD_OK) return rc;
-        // cursor <- row after the batch (kept out of the kernel: its tiles read the old cursor)
-        if (hipMemcpyAsync(cursor_dev, view_offsets_dev + a.V, sizeof(int64_t), hipMemcpyDeviceToDevice, s) != hipSuccess)
-            return fail(DD_ERR_LAUNCH, "hipMemcpyAsync(cursor) failed");
-        return DD_OK;
+        return check_launch("dd_unproject_compact");
     }
-    a.cursor_out = reinterpret_cast<long long *>(cursor_dev);   // the scan kernel advances the cursor itself
     if ((batch->tuning & TUNE_ASSUME_DENSE) && p.lean && !p.refine) {
         // speculation for inputs that are expected to be dense (a depth map without holes and no mask): no counting pass.
         // The plan is arithmetic, the scatter pass -- which reads the validity inputs anyway -- verifies every tile.

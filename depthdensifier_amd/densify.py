@@ -221,7 +221,8 @@ class PendingCheck:
         bad = [w for w, code in words if code != 0]
         if bad:
             for w in bad:
-                w[:16].zero_()                            # sticky word: cleared only here, once seen
+                w.zero_()                                 # sticky word: cleared only here, once seen -- and with it the whole workspace:
+                                                          # after a give-up the single-pass state (epoch, granules) is not to be trusted
             if not heal or b._epoch != self._epoch:
                 raise RuntimeError("libddcore: in-kernel scan timed out in one of the appended batches, or a batch run as 'assume dense' "
                                    "was not dense (workspace error word set); rows are invalid -- append the batches again with tuning=4")
@@ -801,7 +802,7 @@ class CloudBuilder:
         bad = False
         for ws in {id(w): w for w in self._workspaces}.values():
             if int(ws[:8].view(torch.int32)[1].item()) != 0:
-                ws[:16].zero_()                              # sticky word: cleared only here, once seen
+                ws.zero_()                                   # sticky word: cleared only here, once seen (the whole workspace, as above)
                 bad = True
         return bad
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 10
+#define DD_ABI_VERSION 11
 
 enum {
     DD_OK = 0,
@@ -109,7 +109,13 @@ typedef struct DDViewBatch {
                                  v * H * W rows behind the cursor) and the scatter pass, which reads the validity inputs anyway,
                                  verifies every tile; a tile that finds an invalid pixel sets the workspace's error word to 2
                                  and the batch's rows, offsets and cursor are void: redo it with tuning = 4 (what CloudBuilder
-                                 does by itself).  Ignored with tuning 8, DD_REFINE and on strided maps */
+                                 does by itself).  Ignored with tuning 8, DD_REFINE and on strided maps;
+                                 bits 18-19 (ABI 11) = geometry of the single-pass kernel on stride-1 maps: 0 = by the size of the
+                                 batch (up to 2048 tiles of 12288 pixels -- a streamed view or a dozen, scripts/test.py:131 -- 8 pixels
+                                 per lane, 6144-pixel tiles taken by workgroup index, rows written past the L2; above, 16 pixels per
+                                 lane, 12288-pixel tiles drawn by ticket), 1 / 3 = force the small / the large tile; bits 20-21 =
+                                 polling lanes of the look-back: 0 / 1 = 16, 2 = 32, 3 = 64; bit 22 = tiles by workgroup index.
+                                 Same rows whatever these say */
     float *refined_out;       /* DD_REFINE: NULL, or (V,H,W) float32 receiving the refined, mask-zeroed depth -- the map the
                                  reference caches for the multi-view filter (scripts/test.py:194, 197-201) */
 } DDViewBatch;
@@ -177,11 +183,18 @@ int dd_scatter(const DDViewBatch *batch, const DDCloudOut *out, const int64_t *v
  *  view_offsets_dev (V+1) int64, device, out.
  *  workspace        as above.  ((int32_t*)workspace)[1] != 0 after the stream has drained means the
  *                   in-kernel look-back gave up after ~2 s of polling (1: should never happen) or a batch
- *                   run with tuning bit 17 was not dense (2); rows, offsets and the cursor
- *                   are then invalid -- redo the batch with tuning = 4.  The first 16 bytes of the
- *                   workspace are STICKY: the library never zeroes them, so the caller zeroes the
- *                   workspace once before its first use and a set error word survives any number
- *                   of later calls on the same workspace until the caller clears it.
+ *                   run with tuning bit 17 was not dense (2); the rows, offsets and the cursor of THAT batch
+ *                   are then invalid (rows of earlier batches are untouched: a tile that does not know its
+ *                   place writes nothing) -- zero the whole workspace and redo the batch with tuning = 4.
+ *                   The first 16 bytes of the workspace are STICKY: the library never zeroes them, so a set
+ *                   error word survives any number of later calls on the same workspace until the caller
+ *                   clears it.
+ *
+ * ABI 11: the single-pass call is ONE stream operation (one kernel launch; up to ABI 10 a memset of the look-back
+ * granules went in front of it and a copy of the cursor behind it).  The caller zeroes the workspace ONCE, before its
+ * first use; from then on the workspace carries a call epoch that tags the granules (a granule of an earlier call reads as
+ * "not published"), and the batch's last tile writes the cursor and advances the epoch.  One workspace serves one stream
+ * at a time, calls of any kind and size in any order (dd_plan + dd_scatter pairs uninterrupted).
  */
 int dd_unproject_compact(const DDViewBatch *batch, const DDCloudOut *out,
                          int64_t *view_offsets_dev, int64_t *cursor_dev,

@@ -1,0 +1,184 @@
+"""The single-pass call as a streaming caller uses it (scripts/test.py:131, 203-240: one view per loop iteration; pipeline.py:
+eight per launch): ONE stream operation per call -- the look-back granules carry the workspace's call epoch instead of being
+zeroed, the batch's last tile writes the cursor -- and a tile geometry chosen by the size of the batch.  Everything here is
+checked against the oracle or against the same cloud built another way, bit for bit."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+EPOCH_MAX = (1 << 18) - 1
+T_SMALL, T_LARGE, STATIC = 1 << 18, 3 << 18, 1 << 22
+W32, W64 = 2 << 20, 3 << 20
+
+
+@pytest.fixture(scope="module")
+def dd():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import depthdensifier_amd
+    return depthdensifier_amd
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import densify_oracle
+    return densify_oracle
+
+
+def _case(seed, V, H, W, dtype=np.float32, rho=0.8):
+    rng = np.random.default_rng(seed)
+    depth = rng.uniform(0.5, 5.0, (V, H, W)).astype(dtype)
+    depth[rng.uniform(size=depth.shape) < 0.03] = 0.0
+    mask = rng.uniform(size=(V, H, W)) < rho
+    normal = rng.normal(size=(V, H, W, 3)).astype(np.float32)
+    rgb = rng.integers(0, 256, (V, H, W, 3), dtype=np.uint8)
+    params = np.tile([0.8 * W, 0.9 * W, W / 2.0, H / 2.0], (V, 1))
+    E = np.zeros((V, 3, 4))
+    for v in range(V):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        w, x, y, z = q
+        E[v, :, :3] = [[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                       [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                       [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]]
+        E[v, :, 3] = rng.normal(size=3)
+    return depth, mask, normal, rgb, params, E
+
+
+def _oracle(orc, depth, mask, normal, rgb, params, E):
+    return orc.fuse_views([orc.densify_view_script(depth[v], params[v], E[v], mask=mask[v], normal=normal[v], rgb=rgb[v])
+                           for v in range(depth.shape[0])])
+
+
+def _header(builder):
+    h = builder._ws_cache[:64].view(__import__("torch").int32).cpu().numpy()
+    return {"error": int(h[1]), "ticket": int(h[4]), "done": int(h[5]), "epoch": int(h[6])}
+
+
+def _equal(a, b):
+    import torch
+    assert len(a) == len(b) and torch.equal(a.view_offsets, b.view_offsets)
+    for f in ("points", "normals", "colors", "pixel_index"):
+        x, y = getattr(a, f), getattr(b, f)
+        assert (x is None and y is None) or torch.equal(x, y), f
+
+
+@pytest.mark.parametrize("dtype", (np.float32, np.float16))
+@pytest.mark.parametrize("shape", [(3, 67, 129), (2, 128, 256), (1, 255, 257), (2, 200, 331), (9, 96, 172)])
+def test_every_single_pass_geometry_writes_the_oracles_cloud(dd, orc, shape, dtype):
+    """Small tile (8 pixels per lane, 6144) / large tile (16, 12288), tiles by ticket / by workgroup index, 16 / 32 / 64
+    polling lanes: indices, colours and normals bit-exact against the oracle, and the rows of all variants identical."""
+    V, H, W = shape
+    depth, mask, normal, rgb, params, E = _case(11 + H, V, H, W, dtype)
+    ref = _oracle(orc, depth, mask, normal, rgb, params, E)
+    first = None
+    for tuning in (0, T_SMALL, T_SMALL | STATIC | W64, T_LARGE, T_LARGE | STATIC, T_LARGE | W32, 8 | T_LARGE | W64):
+        cloud = dd.unproject_views(depth, params, E, mask=mask, normal=normal, rgb=rgb, capacity="max", tuning=tuning)
+        c = cloud.numpy()
+        assert np.array_equal(c["view_offsets"], ref.view_offsets), tuning
+        assert np.array_equal(c["pixel_index"].astype(np.int64), ref.pixel_index), tuning
+        assert np.array_equal(c["colors"], ref.colors) and np.array_equal(c["normals"], ref.normals), tuning
+        if first is None:
+            first = cloud
+            err = np.abs(c["points"] - ref.points).max() / max(np.abs(ref.points).max(), 1.0)
+            assert err <= 1e-4
+        else:
+            _equal(cloud, first)
+
+
+def test_a_chain_of_calls_on_one_workspace_equals_one_batch(dd, orc):
+    """60 views appended one at a time, then eight at a time, through one workspace that is never zeroed again: the cloud of
+    one 60-view batch, bit for bit; every call advances the workspace's epoch by one and leaves ticket and done at zero."""
+    V, H, W = 60, 72, 200
+    depth, mask, normal, rgb, params, E = _case(5, V, H, W)
+    whole = dd.ViewBatch(depth, params, E, mask=mask, normal=normal, rgb=rgb)
+    b = dd.CloudBuilder(whole.max_points, normals=True, colors=True, pixel_index=True)
+    b.append(whole)
+    want = b.finish()
+    ref = _oracle(orc, depth, mask, normal, rgb, params, E)
+    assert np.array_equal(want.view_offsets.cpu().numpy(), ref.view_offsets)
+    assert np.array_equal(want.pixel_index.cpu().numpy().astype(np.int64), ref.pixel_index)
+    e0 = _header(b)["epoch"]
+    calls = 0
+    for k in (1, 8):
+        b.reset()
+        for lo in range(0, V, k):
+            b.append(whole.slice(lo, min(lo + k, V)))
+            calls += 1
+        _equal(b.finish(), want)
+    h = _header(b)
+    assert h == {"error": 0, "ticket": 0, "done": 0, "epoch": e0 + calls}
+
+
+@pytest.mark.parametrize("tuning", (0, T_LARGE, T_SMALL, 9))
+def test_the_epoch_wraps_without_a_trace(dd, tuning):
+    """The call in which the 18-bit epoch wraps zeroes every record of the workspace (so a granule of 2^18 calls ago can never
+    read as this call's): forced here by setting the epoch by hand, with stale granules planted that carry the tags of the
+    calls to come."""
+    import torch
+    V, H, W = 8, 64, 200
+    depth, mask, normal, rgb, params, E = _case(9, V, H, W)
+    whole = dd.ViewBatch(depth, params, E, mask=mask, normal=normal, rgb=rgb, tuning=tuning)
+    b = dd.CloudBuilder(whole.max_points, normals=True, colors=True, pixel_index=True)
+    b.append(whole)
+    want = b.finish()
+    ws = b._ws_cache
+    # a workspace far larger than these batches need, as after a large batch: records behind the ones in use hold old granules
+    big = torch.zeros(ws.numel() + (1 << 16), dtype=torch.uint8, device=ws.device)
+    b._ws_cache = big
+    words = big[64:64 + ((big.numel() - 64) // 8) * 8].view(torch.int64)
+    b.reset()
+    big[:64].view(torch.int32)[6] = EPOCH_MAX - 1
+    # "inclusive, row 12345" with the tags of the two calls after the wrap (epochs 0 and 1), in every word behind the header
+    for epoch in (0, 1):
+        words[epoch::2] = ((2 << 62) | (epoch << 44) | 12345) - (1 << 64)
+    for lo in range(0, V, 2):              # epochs MAX-1, MAX (wraps: every record zeroed), 0, 1
+        b.append(whole.slice(lo, lo + 2))
+    got = b.finish()
+    _equal(got, want)
+    assert _header(b) == {"error": 0, "ticket": 0, "done": 0, "epoch": 2}
+    assert int((words[words.shape[0] // 2:] != 0).sum()) == 0          # the planted granules behind the part in use are gone
+
+
+def test_two_pass_calls_between_single_pass_calls_share_the_workspace(dd):
+    """plan + scatter (tuning 4) and the count-free plan write their counts and rows beside the granules, never over them."""
+    V, H, W = 8, 80, 160
+    depth, mask, normal, rgb, params, E = _case(21, V, H, W)
+    whole = dd.ViewBatch(depth, params, E, mask=mask, normal=normal, rgb=rgb)
+    b = dd.CloudBuilder(whole.max_points, normals=True, colors=True, pixel_index=True)
+    b.append(whole)
+    want = b.finish()
+    for order in ((0, 4, 0, 4), (4, 0, T_LARGE, 4), (T_LARGE, 4, 4, 0)):
+        b.reset()
+        for i, tuning in enumerate(order):
+            sub = whole.slice(2 * i, 2 * i + 2)
+            sub.tuning = tuning
+            b.append(sub)
+        _equal(b.finish(), want)
+
+
+def test_appends_after_a_healed_give_up_start_from_a_clean_workspace(dd):
+    """A look-back that gives up (fault injection, tuning 64) writes nothing it does not know the place of -- the rows of the
+    batches before it stay intact -- and the redo zeroes the whole workspace, so the single-pass calls after it run as on a new one."""
+    V, H, W = 8, 96, 160
+    depth, mask, normal, rgb, params, E = _case(33, V, H, W)
+    whole = dd.ViewBatch(depth, params, E, mask=mask, normal=normal, rgb=rgb)
+    b = dd.CloudBuilder(whole.max_points, normals=True, colors=True, pixel_index=True)
+    b.append(whole)
+    want = b.finish()
+    b.reset()
+    b.append(whole.slice(0, 2))
+    n2 = b.check()
+    bad = whole.slice(2, 4)
+    bad.tuning = 64
+    b.append(bad)
+    # the sabotaged call has not touched a row of the first batch
+    import torch
+    torch.cuda.synchronize()
+    assert torch.equal(b.xyz[:n2], want.points[:n2]) and torch.equal(b.pix[:n2], want.pixel_index[:n2])
+    assert b.check() == int(want.view_offsets[4]) and b.healed == 1
+    assert _header(b) == {"error": 0, "ticket": 0, "done": 0, "epoch": 0}
+    b.append(whole.slice(4, 8))
+    _equal(b.finish(), want)

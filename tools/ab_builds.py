@@ -99,7 +99,7 @@ def main():
             else:
                 times.append(e0.elapsed_time(e1))
     if a.stamps:
-        tiles = (H * W + 12287) // 12288 * a.views
+        tiles = (H * W + 4095) // 4096 * a.views          # (room for the finest tiling: the small-batch tile is 6144 pixels)
         st = torch.zeros((tiles, 16), dtype=torch.int64, device=dev)
         cb.refined_out = st.data_ptr()
         for tag, lib, _ in libs:
