@@ -243,13 +243,25 @@ def verify_views(dd, cfg: dict, scene: dict, params: np.ndarray, E: np.ndarray, 
             "bit_exact": "per-view counts, pixel_index order, colours, pass-through normals; timed rows == untimed re-run"}
 
 
-def strong_scaling_record(args, dd, D, dist, use_dist, rank, world, device, fence) -> dict:
+def remask_bernoulli(scene: dict, cfg: dict, view_ids: np.ndarray, device) -> None:
+    """The masks of `scene` overwritten IN PLACE with the independent per-pixel cull of SURVEY.md 8d config 3 (rho = cfg["rho"]),
+    exactly the masks make_scene draws with mask_kind = "bernoulli" (same generator, same order of draws)."""
+    H, W = cfg["H"], cfg["W"]
+    for i, vid in enumerate(view_ids):
+        g = torch.Generator(device=device).manual_seed(1000 + int(vid))
+        torch.rand(6, generator=g, device=device); torch.rand(6, generator=g, device=device)      # (phases and frequencies of the depth field)
+        scene["mask"][i] = torch.rand((H, W), generator=g, device=device) < cfg["rho"]
+
+
+def strong_scaling_record(args, dd, D, dist, use_dist, rank, world, device, fence, reuse=None) -> dict:
     """BASELINE configs[2] on the N ranks of this job: `--strong-views` (2000) synthetic 1080p views, rank r holds the
     contiguous shard shard_views(V, N, r), inputs resident in HBM.  Timed three ways (max over ranks, mean of the timed
     passes): "sharded" = one fused kernel over the shard + the all-gather of per-view counts (cloud stays distributed,
     globally indexed); "gathered" = distributed.fuse_replicated, every point written once at its final global row and
     the chunks exchanged in place while the next chunk's kernel runs (xyz + normals + colours, 27 B/point);
-    "gathered_compact" = the same with one 16-byte xyz+rgba record per point."""
+    "gathered_compact" = the same with one 16-byte xyz+rgba record per point; and "bernoulli" = the sharded fuse once more with
+    the blob masks replaced by SURVEY.md 8d's per-pixel Bernoulli cull (the worst case for the compaction).
+    `reuse`: the scene the main workload already holds in HBM (scene2000 at its default size), instead of a second copy."""
     cfg = dict(WORKLOADS["scene2000"])
     cfg["mask_kind"] = args.mask_kind          # blob (default) or the per-pixel Bernoulli cull of SURVEY.md 8d config 3
     V_total = args.strong_views
@@ -257,16 +269,19 @@ def strong_scaling_record(args, dd, D, dist, use_dist, rank, world, device, fenc
     H, W = cfg["H"], cfg["W"]
     ids = np.arange(lo, hi)
     t_gen = time.perf_counter()
-    scene = make_scene(cfg, ids, device)
-    params = np.tile([0.8 * W, 0.8 * W, W / 2.0, H / 2.0], (len(ids), 1))
-    batch = dd.ViewBatch(scene["depth"], params, ring_poses(ids, V_total), mask=scene["mask"], normal=scene["normal"], rgb=scene["rgb"],
-                         view_index_base=int(lo), device=device)
+    if reuse is not None:
+        scene, batch, params = reuse["scene"], reuse["batch"], reuse["params"]
+    else:
+        scene = make_scene(cfg, ids, device)
+        params = np.tile([0.8 * W, 0.8 * W, W / 2.0, H / 2.0], (len(ids), 1))
+        batch = dd.ViewBatch(scene["depth"], params, ring_poses(ids, V_total), mask=scene["mask"], normal=scene["normal"], rgb=scene["rgb"],
+                             view_index_base=int(lo), device=device)
     torch.cuda.synchronize(device)
     t_gen = time.perf_counter() - t_gen
     rec = {"views_total": V_total, "views_per_gpu": len(ids), "height": H, "width": W, "scaling": "strong", "chunks": args.chunks,
            "gather_dst": args.gather_dst, "allgatherv": os.environ.get("DD_ALLGATHERV", "p2p"),
            "mask_kind": args.mask_kind,
-           "scene_generation_s": round(t_gen, 2)}
+           "scene_generation_s": round(t_gen, 2) if reuse is None else "the main workload's scene, already resident"}
 
     def timed(fn, passes):
         fn()                                            # warm-up (allocations, RCCL channels)
@@ -285,34 +300,55 @@ def strong_scaling_record(args, dd, D, dist, use_dist, rank, world, device, fenc
     # -- sharded fuse: the cloud stays distributed; max capacity, no sizing pass
     builder = dd.CloudBuilder(batch.max_points, normals=True, colors=True, pixel_index=False, device=device, placement=args.placement)
     rec["placement"] = None if builder.placement is None else builder.placement.mode
-
-    def sharded():
-        builder.reset()
-        offs = builder.append(batch)
-        counts = offs[1:] - offs[:-1]
-        return D.offsets_from_counts(D.exchange_counts(counts, V_total) if use_dist else counts)
-
-    dt, goffs = timed(sharded, args.strong_steps)
-    builder.check()
-    if len(ids) and not args.no_verify:      # the last view of this rank's shard of the TIMED cloud against the oracle
-        try:
-            local_offs = builder._offsets[-1]
-            v = verify_views(dd, cfg, scene, params, ring_poses(ids, V_total), [len(ids) - 1], local_offs,
-                             {"points": builder.xyz, "normals": builder.normal, "colors": builder.rgb}, device)
-            ok = 1
-        except AssertionError as e:
-            v, ok = {"error": str(e)[:300]}, 0
-        if use_dist:
-            flag = torch.tensor([ok], dtype=torch.int64, device=device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = int(flag.item())
-        rec["verified"] = dict(v, what="last view of every rank's shard of the timed sharded cloud vs the oracle", all_ranks_ok=bool(ok))
-    n_total = int(goffs[-1].item())
-    n_own = int((goffs[hi] - goffs[lo]).item())
     pixels = V_total * H * W
-    rec["points_total"] = n_total
-    rec["sharded"] = {"ms": round(dt * 1e3, 3), "mpixels_per_s": round(pixels / dt / 1e6, 1), "mpoints_per_s": round(n_total / dt / 1e6, 1),
-                      "what": "fused kernel over the shard + all-gather of per-view counts; cloud left distributed, globally indexed"}
+
+    def sharded_leg(kind_cfg):
+        def sharded():
+            builder.reset()
+            offs = builder.append(batch)
+            counts = offs[1:] - offs[:-1]
+            return D.offsets_from_counts(D.exchange_counts(counts, V_total) if use_dist else counts)
+
+        dt, goffs = timed(sharded, args.strong_steps)
+        builder.check()
+        out = {}
+        if len(ids) and not args.no_verify:      # the last view of this rank's shard of the TIMED cloud against the oracle
+            try:
+                local_offs = builder._offsets[-1]
+                v = verify_views(dd, kind_cfg, scene, params, ring_poses(ids, V_total), [len(ids) - 1], local_offs,
+                                 {"points": builder.xyz, "normals": builder.normal, "colors": builder.rgb}, device)
+                ok = 1
+            except AssertionError as e:
+                v, ok = {"error": str(e)[:300]}, 0
+            if use_dist:
+                flag = torch.tensor([ok], dtype=torch.int64, device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            out["verified"] = dict(v, what="last view of every rank's shard of the timed sharded cloud vs the oracle", all_ranks_ok=bool(ok))
+        n_total = int(goffs[-1].item())
+        n_own = int((goffs[hi] - goffs[lo]).item())
+        alg = algorithmic_bytes(kind_cfg, len(ids), n_own, False)
+        out["points_total"] = n_total
+        out["sharded"] = {"ms": round(dt * 1e3, 3), "mpixels_per_s": round(pixels / dt / 1e6, 1), "mpoints_per_s": round(n_total / dt / 1e6, 1),
+                          "whole_step_frac": round(alg / dt / 1e9 / HBM_PEAK_GBPS, 4), "valid_fraction": round(n_own / max(1, len(ids) * H * W), 4),
+                          "what": "fused kernel over the shard + all-gather of per-view counts; cloud left distributed, globally indexed "
+                                  "(whole_step_frac: this rank's algorithmic bytes over the wall time of the step, host included)"}
+        return out, n_total, n_own
+
+    first, n_total, n_own = sharded_leg(cfg)
+    rec.update(first)
+    if args.mask_kind == "blob" and not args.no_bernoulli and len(ids):
+        # SURVEY.md 8d config 3 names a per-pixel Bernoulli variant beside the blob masks: the same scene, masks redrawn in place
+        bcfg = dict(cfg, mask_kind="bernoulli")
+        keep_masks = scene["mask"].clone()
+        remask_bernoulli(scene, bcfg, ids, device)
+        try:
+            bern, _, _ = sharded_leg(bcfg)
+            rec["bernoulli"] = dict(bern, mask_kind="bernoulli", what="the sharded leg with an independent per-pixel cull (rho = 0.8) instead of blob masks")
+        except Exception as e:      # noqa: BLE001
+            rec["bernoulli"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        scene["mask"].copy_(keep_masks)
+        del keep_masks
     del builder
     torch.cuda.empty_cache()
 
@@ -362,6 +398,83 @@ def strong_scaling_record(args, dd, D, dist, use_dist, rank, world, device, fenc
                             "N = 1: count pass + fused kernel per chunk (no wire)"}
         del bufs
         torch.cuda.empty_cache()
+    return rec
+
+
+def streaming_record(args, dd, cfg, scene, params, E, batch, builder, device, view_base: int, alg_bytes: int) -> dict:
+    """The path as the reference calls it: ONE view per loop iteration (scripts/test.py:131, 203-240) -- and eight, as pipeline.py
+    stacks them -- appended call after call to the same cloud, inputs resident in HBM.  Events bracket the whole chain of
+    ceil(V / k) CloudBuilder.append calls (each ONE kernel launch since ABI 11); frac = the workload's algorithmic bytes over that
+    time.  The same chain replayed from a captured HIP graph is timed beside it (the chain is bound by the GPU, not by the host's
+    enqueueing: `host_enqueue_ms`), and the chained cloud is compared with the oracle like the one-batch cloud."""
+    V = batch.num_views
+    rec = {"views": V, "what": "chains of CloudBuilder.append calls of k views each over the whole workload, events around the chain; "
+                              "frac = algorithmic bytes of the workload / chain time / peak", "per_call": {}}
+    # the floor of any chain: dependent launches of a kernel that does nothing
+    tiny = torch.zeros(1, dtype=torch.int64, device=device)
+    fl = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(device); e0.record()
+        for _ in range(100):
+            tiny.add_(1)
+        e1.record(); torch.cuda.synchronize(device)
+        fl.append(1e3 * e0.elapsed_time(e1) / 100)
+    rec["dependent_launch_floor_us"] = round(min(fl), 2)
+    ok_all = True
+    for k in args.streaming:
+        subs = [batch.slice(lo, min(lo + k, V)) for lo in range(0, V, k)]
+
+        def chain():
+            builder.reset()
+            for sb in subs:
+                builder.append(sb)
+
+        chain(); builder.check()
+        ts, hs = [], []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(device)
+            h0 = time.perf_counter()
+            e0.record(); chain(); e1.record()
+            h1 = time.perf_counter()
+            torch.cuda.synchronize(device)
+            ts.append(e0.elapsed_time(e1)); hs.append((h1 - h0) * 1e3)
+        total = builder.check()
+        med = float(np.median(ts))
+        item = {"calls": len(subs), "chain_ms": round(med, 4), "chain_ms_min": round(min(ts), 4), "us_per_call": round(1e3 * med / len(subs), 2),
+                "frac": round(alg_bytes / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "mpixels_per_s": round(V * cfg["H"] * cfg["W"] / (med * 1e-3) / 1e6, 1),
+                "host_enqueue_ms": round(float(np.median(hs)), 3), "redone": {"healed": int(builder.healed), "dense_misses": int(builder.dense_misses)}}
+        if not args.no_verify:
+            try:
+                offs = torch.cat([builder._offsets[0]] + [o[1:] for o in builder._offsets[1:]])
+                views = sorted(set(list(range(min(V, 2))) + [V // 2, V - 1]))
+                v = verify_views(dd, cfg, scene, params, E, views, offs, {"points": builder.xyz, "normals": builder.normal, "colors": builder.rgb},
+                                 device, view_base)
+                v["rows_total"] = total
+                item["verified"] = v
+            except AssertionError as e:
+                item["verified"] = {"error": str(e)[:300]}
+                ok_all = False
+        # the same chain from a captured graph (one graph launch instead of len(subs) kernel launches from Python)
+        try:
+            graph = dd.capture_chain(builder, subs)
+            graph.replay(); torch.cuda.synchronize(device)
+            tg = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize(device)
+                e0.record(); graph.replay(); e1.record()
+                torch.cuda.synchronize(device)
+                tg.append(e0.elapsed_time(e1))
+            item["hip_graph_chain_ms"] = round(float(np.median(tg)), 4)
+            item["hip_graph_rows_equal"] = bool(int(builder.cursor.item()) == total)
+            del graph
+        except Exception as e:      # noqa: BLE001
+            item["hip_graph_chain_ms"] = None
+            item["hip_graph_error"] = f"{type(e).__name__}: {e}"[:200]
+        rec["per_call"][str(k)] = item
+    rec["all_ok"] = ok_all
     return rec
 
 
@@ -474,7 +587,13 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
-                    help="default: garden185 at N = 1 (BASELINE configs[1]), scene2000 at N > 1 (configs[2], strong scaling)")
+                    help="the workload `value` is measured on.  Default: scene2000 (BASELINE configs[2], the scene the metric is quoted on; strong "
+                         "scaling: the 2000 views are split over the N ranks) with, at N = 1, the other single-GPU configurations as sub-records of "
+                         "the same line: garden185 (configs[1]) with its streaming chains, roofline12mp (configs[4]), mip360conf (configs[3])")
+    ap.add_argument("--sub", default="auto", help="sub-records of the default line: auto (all, at N = 1 with the default workload), none, or a comma list")
+    ap.add_argument("--sub-steps", type=int, default=10, help="timed steps of a sub-record (its warm-up: 3)")
+    ap.add_argument("--streaming", default="1,8", help="views per call of the streaming chains timed on garden185 ('' = skip)")
+    ap.add_argument("--no-bernoulli", action="store_true", help="skip the per-pixel Bernoulli leg of the strong2000 record")
     ap.add_argument("--placement", default="probed", choices=("probed", "first"),
                     help="probed: the cloud's points / normals / colours built from different classes of HBM address ranges (the arena of "
                          "depthdensifier_amd/placement.py); first: as the allocator returns them (rounds 1-2)")
@@ -512,8 +631,10 @@ def main() -> None:
             sys.exit("bench.py --gpus N>1 must be launched with: python -m torch.distributed.run --nnodes=1 "
                      "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         args.gpus = world
+    explicit = args.workload is not None
     if args.workload is None:
-        args.workload = "garden185" if world == 1 else "scene2000"
+        args.workload = "scene2000"        # the scene BASELINE.json's metric is quoted on, at every N
+    args.streaming = [int(x) for x in args.streaming.split(",") if x.strip()]
     if os.environ.get("DD_BENCH_SHARE_GPU") == "1":
         args.placement = "first"         # rehearsal ranks share one GPU: no scouting of its memory by several processes at once
     real_out = _claim_stdout()
@@ -544,354 +665,373 @@ def main() -> None:
     import depthdensifier_amd as dd
     from depthdensifier_amd import distributed as D
 
-    cfg = dict(WORKLOADS[args.workload])
-    cfg["mask_kind"] = args.mask_kind
-    cfg["conf_kind"] = args.conf_kind
-    strong = args.workload == "scene2000"
-    multi = "scenes" in cfg                          # whole scenes back to back, dealt to the ranks
-    if args.views:
-        if multi:                                    # scale every scene (quick runs)
-            cfg["scenes"] = [(n, max(1, round(v * args.views / cfg["V"]))) for n, v in cfg["scenes"]]
-        cfg["V"] = args.views
-    scene_sets = None
-    if multi:
-        names, sizes = zip(*cfg["scenes"])
-        owner = deal_scenes(sizes, world)
-        starts = np.concatenate([[0], np.cumsum(sizes)])
-        total_views = int(starts[-1])
-        scene_sets = [(names[k], np.arange(starts[k], starts[k + 1])) for k in range(len(sizes)) if owner[k] == rank]
-        lo, hi = (int(scene_sets[0][1][0]), int(scene_sets[0][1][-1]) + 1) if scene_sets else (0, 0)
-        scaling = "strong"
-    elif strong:
-        total_views = cfg["V"]
-        lo, hi = D.shard_views(total_views, world, rank)
-        scaling = "strong"
-    else:
-        total_views = cfg["V"] * world
-        lo, hi = rank * cfg["V"], (rank + 1) * cfg["V"]
-        scaling = "weak"
-    view_ids = np.arange(lo, hi)
-    V = len(view_ids)
-    H, W = cfg["H"], cfg["W"]
-
-    scene = make_scene(cfg, view_ids, device)
-    params = np.tile([0.8 * W, 0.8 * W, W / 2.0, H / 2.0], (V, 1))
-    E = ring_poses(view_ids, total_views)
-    poses_from = "synthetic ring"
-    if args.workload == "garden185" and (args.colmap_path / "images.bin").exists():
-        # real registered poses / intrinsics when the dataset is on disk; maps stay synthetic
-        from depthdensifier_amd.colmap_io import Reconstruction
-        rec = Reconstruction(args.colmap_path)
-        imgs = [rec.images[i] for i in sorted(rec.images)]
-        if len(imgs) >= hi:
-            for j, vid in enumerate(view_ids):
-                im = imgs[int(vid)]
-                cam = rec.cameras[im.camera_id]
-                E[j] = im.cam_from_world().matrix()
-                params[j] = cam.pinhole_params() * [W / cam.width, H / cam.height, W / cam.width, H / cam.height]
-            poses_from = str(args.colmap_path)
-    def view_batch(sc, pr, Ek, base):
-        return dd.ViewBatch(sc["depth"], pr, Ek, mask=sc["mask"], normal=sc["normal"], rgb=sc["rgb"], conf=sc["conf"],
-                            conf_threshold=cfg.get("conf"), view_index_base=int(base), device=device, tuning=args.tuning)
-
-    if multi:       # this rank's scenes, each its own ring of cameras and its own batch; `scene` stays the first (CPU baseline)
-        batches = []
-        for k, (_, ids) in enumerate(scene_sets):
-            sc = scene if k == 0 else make_scene(cfg, ids, device)
-            batches.append(view_batch(sc, np.tile(params[:1], (len(ids), 1)), ring_poses(np.arange(len(ids)), len(ids)), 0))
-        if scene_sets:
-            E = ring_poses(np.arange(V), V)
-        V = sum(len(ids) for _, ids in scene_sets)
-        batch = builder = None
-    else:
-        batch = view_batch(scene, params, E, lo)
-        # capacity = every visited pixel: no sizing pass exists anywhere, timed or not (SURVEY.md 8d defines the metric over
-        # count + scan + unproject + compact, which the fused kernel does in its one pass)
-        builder = dd.CloudBuilder(batch.max_points, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index,
-                                  device=device, placement=args.placement)
-        builder.speculate_dense = not args.no_dense_guess
-
-    ev = []
-    state = {"plan": None}
-    single_pass = not args.two_pass
-    auto_two_pass = speculative = None
-    if builder is not None and single_pass:
-        # the path CloudBuilder.append would take for this cloud and batch: for ONE large row array placed with its thirds in three
-        # classes of HBM that is plan + scatter with the scatter walking the thirds in turn.  The same calls are made here
-        # separately so that the events bracket the dominant kernel (the scatter) and the count pass on their own.
-        tun = builder.fuse_tuning(batch)
-        if (tun & 4) and not (batch.tuning & 4):
-            batch.tuning, single_pass = tun, False
-            auto_two_pass = f"CloudBuilder.fuse_tuning: two-pass, scatter interleaving {1 + ((tun >> 8) & 63)} stretches of tiles (cloud placed '{builder.placement.layout}')"
-        elif tun & (1 << 17):
-            # unmasked depth maps on a blocked cloud: the fused call runs the scatter against a count-free plan and the scatter verifies
-            # it (DDViewBatch.tuning bit 17); builder.append makes that call itself, builder.check() below redoes the batch on a miss
-            speculative = (f"CloudBuilder.fuse_tuning: no counting pass -- plan_dense + the scatter kernel, which verifies that every pixel is valid; "
-                           f"scatter interleaving {1 + ((tun >> 8) & 63)} stretches of tiles (cloud placed '{builder.placement.layout}')")
-
-    scene_pool, state_placement, big = {}, None, None
-    if multi and batches:
-        # one long-lived set of arrays sized for the largest scene, placed once (outside the timed region) and handed to every
-        # scene's cloud -- what torch's caching allocator did for the per-scene clouds of round 2 anyway (the same memory every
-        # time), now in HBM classes of our choosing
-        big = dd.CloudBuilder(max(b.max_points for b in batches), normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index,
-                              device=device, placement=args.placement)
-        scene_pool = {"points": big.xyz, "normals": big.normal, "colors": big.rgb, "pixel_index": big.pix}
-        state_placement = big.placement
-
-    def step_scenes(record: bool):
-        """mip360x7: this rank's scenes back to back -- per scene a cloud sized for every visited pixel (on the pooled arrays
-        above), the fused call, and the read of the point count and the error word that writing the scene's model needs --
-        asked for behind each scene's kernel (``CloudBuilder.check_async``) and looked at once all scenes are enqueued, so the
-        host never stands between two kernels (round 3 read them scene by scene: 0.58 of the roofline against 0.60 for one scene).
-        The events bracket the whole sequence."""
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if record else None
-        if record:
-            e[0].record()
-        pending = []
-        for b in batches:
-            big.reset()                                 # the next scene's cloud: the same pooled arrays, rows from 0
-            big.append(b)
-            pending.append(big.check_async())           # count + status on their way to the host; the next scene is enqueued meanwhile
-        n = sum(p.result(heal=False) for p in pending)   # (the scenes share the pooled arrays: a redo after the fact has nothing to redo into)
-        if record:
-            e[1].record(); e[2].record()
-            ev.append(e)
-        state["n_local"] = n
-        return None
-
-    def step(record: bool):
-        """One pass of the hot path.  Default: the fused call dd_unproject_compact (one kernel reads the
-        inputs once: cull + unproject + transform + look-back scan + compaction + write).  --two-pass:
-        dd_plan (count + scans) then dd_scatter.  Events bracket the kernels on the launch stream."""
-        if multi:
-            return step_scenes(record)
-        builder.reset()
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if record else None
-        if record:
-            e[0].record()
-        if single_pass:
-            offs = builder.append(batch)
-            if record:
-                e[1].record(); e[2].record()
-        else:
-            state["plan"] = dd.plan_batch(batch, builder.cursor, reuse=state["plan"])
-            if record:
-                e[1].record()
-            offs = builder.scatter(batch, state["plan"])
-            if record:
-                e[2].record()
-        if record:
-            ev.append(e)
-        if use_dist:                               # the fuse exchange: global view offsets on every rank
-            counts = offs[1:] - offs[:-1]
-            return D.offsets_from_counts(D.exchange_counts(counts, total_views))
-        return offs
-
     def fence():
         torch.cuda.synchronize(device)
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
-        step(False)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        goffs = step(True)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    if multi:
-        n_local = state["n_local"]
-        n_total = n_local
-        if use_dist:
-            nt = torch.tensor([n_local], dtype=torch.int64, device=device)
-            dist.all_reduce(nt)
-            n_total = int(nt.item())
-    else:
-        n_local = builder.check()
-        n_total = int(goffs[-1].item())
-    if os.environ.get("DD_BENCH_TRACE_STEPS") and rank == 0:      # per-step kernel times (diagnostic)
-        print("steps_ms", [round(e[0].elapsed_time(e[2]), 3) for e in ev], file=sys.stderr)
-    plan_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-    k_all = [e[1].elapsed_time(e[2]) for e in ev] if not single_pass else [e[0].elapsed_time(e[1]) for e in ev]
-    kernel_ms = float(np.mean(k_all))
-    if single_pass:
-        plan_ms = 0.0
-
-    # ---- the timed cloud against the oracle (untimed; every rank checks views of its own shard)
-    verified = None
-    if not multi and not args.no_verify and V > 0:
-        views = sorted(set(list(range(min(V, args.verify_views))) + [V - 1]))
-        try:
-            verified = verify_views(dd, cfg, scene, params, E, views, builder._offsets[-1],
-                                    {"points": builder.xyz, "normals": builder.normal, "colors": builder.rgb}, device, lo)
-            ok = 1
-        except AssertionError as e:
-            verified, ok = {"error": str(e)[:300]}, 0
-        if use_dist:
-            flag = torch.tensor([ok], dtype=torch.int64, device=device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = int(flag.item())
-        verified["all_ranks_ok"] = bool(ok)
-        verified["what"] = "rows of the TIMED cloud (last timed step) vs oracle/densify_oracle.py on this rank's first views and its last one"
-
-    # ---- the same kernel on fresh allocations of the cloud (the placement of the output arrays is the one thing that moves it)
-    alloc_ms, alloc_how = [], []
-    if not multi and single_pass and args.alloc_rounds > 0 and V > 0:
-        keep = []
-        from depthdensifier_amd import placement as _pl
-        cloud_bytes = batch.max_points * (12 + (12 if cfg["normal"] else 0) + (3 if cfg["rgb"] else 0) + (4 if args.pixel_index else 0))
-        for r in range(args.alloc_rounds):
-            _pl.trim(device)              # no spare chunks from the last round: every round scouts the device's memory anew
-            torch.cuda.empty_cache()      # (blocks torch keeps cached -- the verification's temporaries -- are not free memory to the driver)
-            if torch.cuda.mem_get_info(device)[0] < 1.15 * cloud_bytes + (4 << 30):
-                break                     # no room for a second cloud beside the timed one (2000 views on one GPU)
-            b2 = dd.CloudBuilder(batch.max_points, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index, device=device,
-                                 placement=args.placement)
-            b2.speculate_dense = not args.no_dense_guess
-            for _ in range(2):
-                b2.reset(); b2.append(batch)
-            ts = []
-            for _ in range(5):
-                b2.reset()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(); b2.append(batch); e1.record()
-                torch.cuda.synchronize(device)
-                ts.append(e0.elapsed_time(e1))
-            alloc_ms.append(float(np.median(ts)))
-            alloc_how.append("first" if b2.placement is None else f"{b2.placement.mode[:120]} / {b2.placement.layout}")
-            if args.placement == "first":
-                keep.append(torch.empty((r + 1) << 30, dtype=torch.uint8, device=device))    # the next allocation starts elsewhere
-            del b2
-            torch.cuda.empty_cache()
-        del keep
-
-    devices = None
-    if use_dist:
-        props_r = torch.cuda.get_device_properties(device)
-        mine = f"rank {rank}: {torch.cuda.get_device_name(device)} pci {getattr(props_r, 'pci_bus_id', 0):02x}:{getattr(props_r, 'pci_device_id', 0):02x} uuid {getattr(props_r, 'uuid', '?')}"
-        devices = [None] * world
-        dist.all_gather_object(devices, mine)
-
-    if rank == 0:
-        props = torch.cuda.get_device_properties(device)
-        ms_per_step = elapsed / args.steps * 1e3
-        pixels = total_views * H * W
-        alg = algorithmic_bytes(cfg, V, n_local, args.pixel_index)
-        alg_r = algorithmic_bytes(cfg, V, n_local, args.pixel_index, reads_only=True)
-        achieved = alg / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_source = None, None
-        tfile = ROOT / "profiles" / "traffic.json"
-        if tfile.exists():
-            tkey = ("mip360conf" if multi else args.workload) + (":bernoulli" if args.mask_kind == "bernoulli" else "") + (":smooth" if cfg.get("conf") and args.conf_kind == "smooth" else "") + ("" if single_pass and not speculative else ":two-pass")      # (the speculative call runs the two-pass scatter kernel)
-            # (mip360x7 runs the mip360conf kernel scene after scene on the same kind of maps: its bytes per view)
-            rec = json.loads(tfile.read_text()).get(tkey)
-            if rec:     # PMC bytes were collected on the full workload; a launch over fewer views moves proportionally fewer
-                traffic = int(rec["hbm_bytes_per_launch"] * V / rec["views"])
-                traffic_source = (f"profiles/traffic.json[{tkey}]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this kernel on this workload, "
-                                  "collected in separate profiling runs (tools/pmc_traffic.sh) -- NOT measured in this run")
+    def run_workload(workload: str, steps: int, warmup: int, alloc_rounds: int, views_override: int, cpu_seconds: float):
+        """One workload of WORKLOADS on this job's ranks: scene in HBM, warm-up, the timed steps between two fences, the timed cloud against
+        the oracle, the kernel re-timed on fresh allocations.  Returns (the line rank 0 would print for it, what is still resident)."""
+        cfg = dict(WORKLOADS[workload])
+        cfg["mask_kind"] = args.mask_kind
+        cfg["conf_kind"] = args.conf_kind
+        strong = workload == "scene2000"
+        multi = "scenes" in cfg                          # whole scenes back to back, dealt to the ranks
+        if views_override:
+            if multi:                                    # scale every scene (quick runs)
+                cfg["scenes"] = [(n, max(1, round(v * views_override / cfg["V"]))) for n, v in cfg["scenes"]]
+            cfg["V"] = views_override
+        scene_sets = None
         if multi:
-            cfg_scenes = {"scenes": [f"{n}:{len(i)}" for n, i in scene_sets], "scenes_total": len(cfg["scenes"])}
-        line = {
-            "metric": "Mpixels/s unprojected+fused",
-            "value": round(pixels / (elapsed / args.steps) / 1e6, 1),
-            "unit": "Mpixels/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-            "dtype": "f32" if cfg["depth"] == "float32" else "f16-in/f32-out",
-            "data": "synthetic",
-            "device": f"{torch.cuda.get_device_name(device)} pci {getattr(props, 'pci_bus_id', '?'):02x}:{getattr(props, 'pci_device_id', 0):02x}",
-            "mpoints_per_s": round(n_total / (elapsed / args.steps) / 1e6, 1),
-            "config": {"workload": args.workload, "note": cfg["note"], "views_total": total_views, "views_per_gpu": V,
-                       "height": H, "width": W, "downsample_density": 1, "valid_fraction": round(n_local / (V * H * W), 4), "mask_kind": args.mask_kind,
-                       "conf_kind": args.conf_kind if cfg.get("conf") else None,
-                       "poses": poses_from,
-                       "inputs": "+".join(k for k in ("depth", "mask", "conf", "normal", "rgb") if scene[k] is not None),
-                       "outputs": "xyz f32" + (" + normal f32" if cfg["normal"] else "") + (" + rgb u8" if cfg["rgb"] else "")
-                                  + (" + pixel_index i32" if args.pixel_index else ""),
-                       "fuse": "whole scenes per rank, one cloud per scene (on one pooled set of arrays), no data-path collective" if multi else
-                               "single GPU: one global scan, points written at final slots" if world == 1 else
-                               "sharded: contiguous view shards + RCCL all-gather of per-view counts (global offsets)"},
-            "roofline": {"bound": "hbm",
-                         "kernel": "compact_lean<single-pass> (dd_unproject_compact: cull+unproject+transform+scan+compact+write)"
-                                   if single_pass and not speculative else "compact_lean (dd_scatter: cull+unproject+transform+compact+write)"
-                                   + (f"; {auto_two_pass}" if auto_two_pass else "") + (f"; {speculative}" if speculative else ""),
-                         "achieved": round(achieved, 1),
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "read_frac": round(alg_r / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                         "read_frac_note": "algorithmic READ bytes / kernel time / peak (the other "
-                                           f"{100 * (1 - alg_r / alg):.0f} % of the bytes are writes sharing the same interface)",
-                         "traffic": traffic, "traffic_source": traffic_source,
-                         # the counters' bytes over the same time: what the kernel really moves through the fabric (per-pixel culls
-                         # fetch whole 128-byte lines of the normal / colour maps for one survivor: frac undercounts them)
-                         "traffic_frac": None if not traffic else round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                         "traffic_over_algorithmic": None if traffic is None else round(traffic / alg, 4),
-                         "algorithmic_bytes_per_launch": alg,
-                         "kernel_ms": round(kernel_ms, 4), "kernel_ms_min": round(float(np.min(k_all)), 4),
-                         "kernel_ms_median": round(float(np.median(k_all)), 4),
-                         "timer": "HIP events on the launch stream; achieved uses the mean over the timed steps",
-                         "sizing_pass": "none: the cloud is allocated for every visited pixel (capacity = V*H*W rows)",
-                         "pass1_ms": round(plan_ms, 4),
-                         "pass1_note": "two-pass mode only: count_lean + scan kernels re-read depth+mask (not credited); whole_step_frac and `value` include them",
-                         "whole_step_frac": round(alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
-        }
-        rf = line["roofline"]
-        if builder is not None:                     # redone batches: look-back give-ups and dense speculations that missed (0 / 0 expected)
-            rf["redone"] = {"healed": int(builder.healed), "dense_misses": int(builder.dense_misses)}
-        prep = (builder.placement if builder is not None else state_placement) if (builder is not None or multi) else None
-        rf["placement"] = "first" if prep is None else (args.placement if prep.mode == "probed" else prep.mode)
-        rf["placement_report"] = None if prep is None else prep.as_dict()
-        if alloc_ms:
-            fr = [alg / (t * 1e-3) / 1e9 / HBM_PEAK_GBPS for t in alloc_ms]
-            rf.update({"frac_min": round(min(fr), 4), "frac_median": round(float(np.median(fr)), 4), "frac_max": round(max(fr), 4),
-                       "alloc_rounds": len(fr), "kernel_ms_per_allocation": [round(t, 4) for t in alloc_ms], "placement_per_allocation": alloc_how,
-                       "frac_note": "frac is the driver's timed run; frac_min / median / max re-time the same kernel on this many FRESH allocations "
-                                    "of the cloud in the same process (placement as above), median of 5 launches each"})
-        if verified is not None:
-            line["verified"] = verified
-        if devices is not None:
-            line["devices"] = devices
-            line["rccl_world_size"] = dist.get_world_size()
-            line["collective_backend"] = dist.get_backend()
-        if strong and args.n1_strong_mpix > 0:
-            line["speedup_vs_n1"] = round(line["value"] / args.n1_strong_mpix, 3)
-        if multi:
-            line["config"]["rank0_scenes"] = cfg_scenes["scenes"]
-            line["roofline"]["kernel"] += f"; {len(batches)} launches, the events also bracket the per-scene allocation and host read"
-        if args.cpu_seconds > 0 and world == 1:      # reported at N=1 only, on rank 0
-            line["cpu_baseline"] = cpu_baseline(cfg, scene, params, E, args.cpu_seconds)
-            procs = args.cpu_procs if args.cpu_procs >= 0 else min(len(os.sched_getaffinity(0)), 16)      # a GPU box's CPU share is 16 cores
-            profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
-            if profiled:        # spawned workers would inherit the profiler's preload (and its GPU initialisation): keep to one process
-                line["cpu_baseline"]["all_cores"] = {"skipped": "running under a profiler"}
-            elif procs > 1:
-                try:
-                    line["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(cfg, scene, params, E, args.cpu_seconds / 2,
-                                                                               line["cpu_baseline"]["value"], procs)
-                except Exception as e:      # noqa: BLE001  (a courtesy figure must not cost the result)
-                    line["cpu_baseline"]["all_cores"] = {"error": f"{type(e).__name__}: {e}"[:200]}
-    else:
-        line = None
+            names, sizes = zip(*cfg["scenes"])
+            owner = deal_scenes(sizes, world)
+            starts = np.concatenate([[0], np.cumsum(sizes)])
+            total_views = int(starts[-1])
+            scene_sets = [(names[k], np.arange(starts[k], starts[k + 1])) for k in range(len(sizes)) if owner[k] == rank]
+            lo, hi = (int(scene_sets[0][1][0]), int(scene_sets[0][1][-1]) + 1) if scene_sets else (0, 0)
+            scaling = "strong"
+        elif strong:
+            total_views = cfg["V"]
+            lo, hi = D.shard_views(total_views, world, rank)
+            scaling = "strong"
+        else:
+            total_views = cfg["V"] * world
+            lo, hi = rank * cfg["V"], (rank + 1) * cfg["V"]
+            scaling = "weak"
+        view_ids = np.arange(lo, hi)
+        V = len(view_ids)
+        H, W = cfg["H"], cfg["W"]
 
-    # BASELINE configs[2] (2000-view strong scaling: sharded / gathered / gathered-compact), timed AFTER the main
+        scene = make_scene(cfg, view_ids, device)
+        params = np.tile([0.8 * W, 0.8 * W, W / 2.0, H / 2.0], (V, 1))
+        E = ring_poses(view_ids, total_views)
+        poses_from = "synthetic ring"
+        if workload == "garden185" and (args.colmap_path / "images.bin").exists():
+            # real registered poses / intrinsics when the dataset is on disk (SURVEY.md 8d config 2); maps stay synthetic
+            from depthdensifier_amd.colmap_io import Reconstruction
+            rec = Reconstruction(args.colmap_path)
+            imgs = [rec.images[i] for i in sorted(rec.images)]
+            if len(imgs) >= hi:
+                for j, vid in enumerate(view_ids):
+                    im = imgs[int(vid)]
+                    cam = rec.cameras[im.camera_id]
+                    E[j] = im.cam_from_world().matrix()
+                    params[j] = cam.pinhole_params() * [W / cam.width, H / cam.height, W / cam.width, H / cam.height]
+                poses_from = str(args.colmap_path)
+        def view_batch(sc, pr, Ek, base):
+            return dd.ViewBatch(sc["depth"], pr, Ek, mask=sc["mask"], normal=sc["normal"], rgb=sc["rgb"], conf=sc["conf"],
+                                conf_threshold=cfg.get("conf"), view_index_base=int(base), device=device, tuning=args.tuning)
+
+        if multi:       # this rank's scenes, each its own ring of cameras and its own batch; `scene` stays the first (CPU baseline)
+            batches = []
+            for k, (_, ids) in enumerate(scene_sets):
+                sc = scene if k == 0 else make_scene(cfg, ids, device)
+                batches.append(view_batch(sc, np.tile(params[:1], (len(ids), 1)), ring_poses(np.arange(len(ids)), len(ids)), 0))
+            if scene_sets:
+                E = ring_poses(np.arange(V), V)
+            V = sum(len(ids) for _, ids in scene_sets)
+            batch = builder = None
+        else:
+            batch = view_batch(scene, params, E, lo)
+            # capacity = every visited pixel: no sizing pass exists anywhere, timed or not (SURVEY.md 8d defines the metric over
+            # count + scan + unproject + compact, which the fused kernel does in its one pass)
+            builder = dd.CloudBuilder(batch.max_points, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index,
+                                      device=device, placement=args.placement)
+            builder.speculate_dense = not args.no_dense_guess
+
+        ev = []
+        state = {"plan": None}
+        single_pass = not args.two_pass
+        auto_two_pass = speculative = None
+        if builder is not None and single_pass:
+            # the path CloudBuilder.append would take for this cloud and batch: for ONE large row array placed with its thirds in three
+            # classes of HBM that is plan + scatter with the scatter walking the thirds in turn.  The same calls are made here
+            # separately so that the events bracket the dominant kernel (the scatter) and the count pass on their own.
+            tun = builder.fuse_tuning(batch)
+            if (tun & 4) and not (batch.tuning & 4):
+                batch.tuning, single_pass = tun, False
+                auto_two_pass = f"CloudBuilder.fuse_tuning: two-pass, scatter interleaving {1 + ((tun >> 8) & 63)} stretches of tiles (cloud placed '{builder.placement.layout}')"
+            elif tun & (1 << 17):
+                # unmasked depth maps on a blocked cloud: the fused call runs the scatter against a count-free plan and the scatter verifies
+                # it (DDViewBatch.tuning bit 17); builder.append makes that call itself, builder.check() below redoes the batch on a miss
+                speculative = (f"CloudBuilder.fuse_tuning: no counting pass -- plan_dense + the scatter kernel, which verifies that every pixel is valid; "
+                               f"scatter interleaving {1 + ((tun >> 8) & 63)} stretches of tiles (cloud placed '{builder.placement.layout}')")
+
+        scene_pool, state_placement, big = {}, None, None
+        if multi and batches:
+            # one long-lived set of arrays sized for the largest scene, placed once (outside the timed region) and handed to every
+            # scene's cloud -- what torch's caching allocator did for the per-scene clouds of round 2 anyway (the same memory every
+            # time), now in HBM classes of our choosing
+            big = dd.CloudBuilder(max(b.max_points for b in batches), normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index,
+                                  device=device, placement=args.placement)
+            scene_pool = {"points": big.xyz, "normals": big.normal, "colors": big.rgb, "pixel_index": big.pix}
+            state_placement = big.placement
+
+        def step_scenes(record: bool):
+            """mip360x7: this rank's scenes back to back -- per scene a cloud sized for every visited pixel (on the pooled arrays
+            above), the fused call, and the read of the point count and the error word that writing the scene's model needs --
+            asked for behind each scene's kernel (``CloudBuilder.check_async``) and looked at once all scenes are enqueued, so the
+            host never stands between two kernels (round 3 read them scene by scene: 0.58 of the roofline against 0.60 for one scene).
+            The events bracket the whole sequence."""
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if record else None
+            if record:
+                e[0].record()
+            pending = []
+            for b in batches:
+                big.reset()                                 # the next scene's cloud: the same pooled arrays, rows from 0
+                big.append(b)
+                pending.append(big.check_async())           # count + status on their way to the host; the next scene is enqueued meanwhile
+            n = sum(p.result(heal=False) for p in pending)   # (the scenes share the pooled arrays: a redo after the fact has nothing to redo into)
+            if record:
+                e[1].record(); e[2].record()
+                ev.append(e)
+            state["n_local"] = n
+            return None
+
+        def step(record: bool):
+            """One pass of the hot path.  Default: the fused call dd_unproject_compact (one kernel reads the
+            inputs once: cull + unproject + transform + look-back scan + compaction + write).  --two-pass:
+            dd_plan (count + scans) then dd_scatter.  Events bracket the kernels on the launch stream."""
+            if multi:
+                return step_scenes(record)
+            builder.reset()
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if record else None
+            if record:
+                e[0].record()
+            if single_pass:
+                offs = builder.append(batch)
+                if record:
+                    e[1].record(); e[2].record()
+            else:
+                state["plan"] = dd.plan_batch(batch, builder.cursor, reuse=state["plan"])
+                if record:
+                    e[1].record()
+                offs = builder.scatter(batch, state["plan"])
+                if record:
+                    e[2].record()
+            if record:
+                ev.append(e)
+            if use_dist:                               # the fuse exchange: global view offsets on every rank
+                counts = offs[1:] - offs[:-1]
+                return D.offsets_from_counts(D.exchange_counts(counts, total_views))
+            return offs
+
+        for _ in range(warmup):
+            step(False)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            goffs = step(True)
+        fence()
+        elapsed = time.perf_counter() - t0
+        if use_dist:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+
+        if multi:
+            n_local = state["n_local"]
+            n_total = n_local
+            if use_dist:
+                nt = torch.tensor([n_local], dtype=torch.int64, device=device)
+                dist.all_reduce(nt)
+                n_total = int(nt.item())
+        else:
+            n_local = builder.check()
+            n_total = int(goffs[-1].item())
+        if os.environ.get("DD_BENCH_TRACE_STEPS") and rank == 0:      # per-step kernel times (diagnostic)
+            print("steps_ms", [round(e[0].elapsed_time(e[2]), 3) for e in ev], file=sys.stderr)
+        plan_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        k_all = [e[1].elapsed_time(e[2]) for e in ev] if not single_pass else [e[0].elapsed_time(e[1]) for e in ev]
+        kernel_ms = float(np.mean(k_all))
+        if single_pass:
+            plan_ms = 0.0
+
+        # ---- the timed cloud against the oracle (untimed; every rank checks views of its own shard)
+        verified = None
+        if not multi and not args.no_verify and V > 0:
+            views = sorted(set(list(range(min(V, args.verify_views))) + [V - 1]))
+            try:
+                verified = verify_views(dd, cfg, scene, params, E, views, builder._offsets[-1],
+                                        {"points": builder.xyz, "normals": builder.normal, "colors": builder.rgb}, device, lo)
+                ok = 1
+            except AssertionError as e:
+                verified, ok = {"error": str(e)[:300]}, 0
+            if use_dist:
+                flag = torch.tensor([ok], dtype=torch.int64, device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            verified["all_ranks_ok"] = bool(ok)
+            verified["what"] = "rows of the TIMED cloud (last timed step) vs oracle/densify_oracle.py on this rank's first views and its last one"
+
+        # ---- the same kernel on fresh allocations of the cloud (the placement of the output arrays is the one thing that moves it)
+        alloc_ms, alloc_how = [], []
+        if not multi and single_pass and alloc_rounds > 0 and V > 0:
+            keep = []
+            from depthdensifier_amd import placement as _pl
+            cloud_bytes = batch.max_points * (12 + (12 if cfg["normal"] else 0) + (3 if cfg["rgb"] else 0) + (4 if args.pixel_index else 0))
+            for r in range(alloc_rounds):
+                _pl.trim(device)              # no spare chunks from the last round: every round scouts the device's memory anew
+                torch.cuda.empty_cache()      # (blocks torch keeps cached -- the verification's temporaries -- are not free memory to the driver)
+                if torch.cuda.mem_get_info(device)[0] < 1.15 * cloud_bytes + (4 << 30):
+                    break                     # no room for a second cloud beside the timed one (2000 views on one GPU)
+                b2 = dd.CloudBuilder(batch.max_points, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index, device=device,
+                                     placement=args.placement)
+                b2.speculate_dense = not args.no_dense_guess
+                for _ in range(2):
+                    b2.reset(); b2.append(batch)
+                ts = []
+                for _ in range(5):
+                    b2.reset()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); b2.append(batch); e1.record()
+                    torch.cuda.synchronize(device)
+                    ts.append(e0.elapsed_time(e1))
+                alloc_ms.append(float(np.median(ts)))
+                alloc_how.append("first" if b2.placement is None else f"{b2.placement.mode[:120]} / {b2.placement.layout}")
+                if args.placement == "first":
+                    keep.append(torch.empty((r + 1) << 30, dtype=torch.uint8, device=device))    # the next allocation starts elsewhere
+                del b2
+                torch.cuda.empty_cache()
+            del keep
+
+        devices = None
+        if use_dist:
+            props_r = torch.cuda.get_device_properties(device)
+            mine = f"rank {rank}: {torch.cuda.get_device_name(device)} pci {getattr(props_r, 'pci_bus_id', 0):02x}:{getattr(props_r, 'pci_device_id', 0):02x} uuid {getattr(props_r, 'uuid', '?')}"
+            devices = [None] * world
+            dist.all_gather_object(devices, mine)
+
+        if rank == 0:
+            props = torch.cuda.get_device_properties(device)
+            ms_per_step = elapsed / steps * 1e3
+            pixels = total_views * H * W
+            alg = algorithmic_bytes(cfg, V, n_local, args.pixel_index)
+            alg_r = algorithmic_bytes(cfg, V, n_local, args.pixel_index, reads_only=True)
+            achieved = alg / (kernel_ms * 1e-3) / 1e9
+            traffic, traffic_source = None, None
+            tfile = ROOT / "profiles" / "traffic.json"
+            if tfile.exists():
+                tkey = ("mip360conf" if multi else workload) + (":bernoulli" if args.mask_kind == "bernoulli" else "") + (":smooth" if cfg.get("conf") and args.conf_kind == "smooth" else "") + ("" if single_pass and not speculative else ":two-pass")      # (the speculative call runs the two-pass scatter kernel)
+                # (mip360x7 runs the mip360conf kernel scene after scene on the same kind of maps: its bytes per view)
+                rec = json.loads(tfile.read_text()).get(tkey)
+                if rec:     # PMC bytes were collected on the full workload; a launch over fewer views moves proportionally fewer
+                    traffic = int(rec["hbm_bytes_per_launch"] * V / rec["views"])
+                    traffic_source = (f"profiles/traffic.json[{tkey}]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this kernel on this workload, "
+                                      "collected in separate profiling runs (tools/pmc_traffic.sh) -- NOT measured in this run")
+            if multi:
+                cfg_scenes = {"scenes": [f"{n}:{len(i)}" for n, i in scene_sets], "scenes_total": len(cfg["scenes"])}
+            line = {
+                "metric": "Mpixels/s unprojected+fused",
+                "value": round(pixels / (elapsed / steps) / 1e6, 1),
+                "unit": "Mpixels/s",
+                "n_gpus": world, "steps": steps, "warmup": warmup,
+                "ms_per_step": round(ms_per_step, 4),
+                "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+                "dtype": "f32" if cfg["depth"] == "float32" else "f16-in/f32-out",
+                "data": "synthetic",
+                "device": f"{torch.cuda.get_device_name(device)} pci {getattr(props, 'pci_bus_id', '?'):02x}:{getattr(props, 'pci_device_id', 0):02x}",
+                "mpoints_per_s": round(n_total / (elapsed / steps) / 1e6, 1),
+                "config": {"workload": workload, "note": cfg["note"], "views_total": total_views, "views_per_gpu": V,
+                           "height": H, "width": W, "downsample_density": 1, "valid_fraction": round(n_local / (V * H * W), 4), "mask_kind": args.mask_kind,
+                           "conf_kind": args.conf_kind if cfg.get("conf") else None,
+                           "poses": poses_from,
+                           "inputs": "+".join(k for k in ("depth", "mask", "conf", "normal", "rgb") if scene[k] is not None),
+                           "outputs": "xyz f32" + (" + normal f32" if cfg["normal"] else "") + (" + rgb u8" if cfg["rgb"] else "")
+                                      + (" + pixel_index i32" if args.pixel_index else ""),
+                           "fuse": "whole scenes per rank, one cloud per scene (on one pooled set of arrays), no data-path collective" if multi else
+                                   "single GPU: one global scan, points written at final slots" if world == 1 else
+                                   "sharded: contiguous view shards + RCCL all-gather of per-view counts (global offsets)"},
+                "roofline": {"bound": "hbm",
+                             "kernel": "compact_lean<single-pass> (dd_unproject_compact: cull+unproject+transform+scan+compact+write)"
+                                       if single_pass and not speculative else "compact_lean (dd_scatter: cull+unproject+transform+compact+write)"
+                                       + (f"; {auto_two_pass}" if auto_two_pass else "") + (f"; {speculative}" if speculative else ""),
+                             "achieved": round(achieved, 1),
+                             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                             "read_frac": round(alg_r / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                             "read_frac_note": "algorithmic READ bytes / kernel time / peak (the other "
+                                               f"{100 * (1 - alg_r / alg):.0f} % of the bytes are writes sharing the same interface)",
+                             "traffic": traffic, "traffic_source": traffic_source,
+                             # the counters' bytes over the same time: what the kernel really moves through the fabric (per-pixel culls
+                             # fetch whole 128-byte lines of the normal / colour maps for one survivor: frac undercounts them)
+                             "traffic_frac": None if not traffic else round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                             "traffic_over_algorithmic": None if traffic is None else round(traffic / alg, 4),
+                             "algorithmic_bytes_per_launch": alg,
+                             "kernel_ms": round(kernel_ms, 4), "kernel_ms_min": round(float(np.min(k_all)), 4),
+                             "kernel_ms_median": round(float(np.median(k_all)), 4),
+                             "timer": "HIP events on the launch stream; achieved uses the mean over the timed steps",
+                             "sizing_pass": "none: the cloud is allocated for every visited pixel (capacity = V*H*W rows)",
+                             "pass1_ms": round(plan_ms, 4),
+                             "pass1_note": "two-pass mode only: count_lean + scan kernels re-read depth+mask (not credited); whole_step_frac and `value` include them",
+                             "whole_step_frac": round(alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+            }
+            rf = line["roofline"]
+            if builder is not None:                     # redone batches: look-back give-ups and dense speculations that missed (0 / 0 expected)
+                rf["redone"] = {"healed": int(builder.healed), "dense_misses": int(builder.dense_misses)}
+            prep = (builder.placement if builder is not None else state_placement) if (builder is not None or multi) else None
+            rf["placement"] = "first" if prep is None else (args.placement if prep.mode == "probed" else prep.mode)
+            rf["placement_report"] = None if prep is None else prep.as_dict()
+            if alloc_ms:
+                fr = [alg / (t * 1e-3) / 1e9 / HBM_PEAK_GBPS for t in alloc_ms]
+                rf.update({"frac_min": round(min(fr), 4), "frac_median": round(float(np.median(fr)), 4), "frac_max": round(max(fr), 4),
+                           "alloc_rounds": len(fr), "kernel_ms_per_allocation": [round(t, 4) for t in alloc_ms], "placement_per_allocation": alloc_how,
+                           "frac_note": "frac is the driver's timed run; frac_min / median / max re-time the same kernel on this many FRESH allocations "
+                                        "of the cloud in the same process (placement as above), median of 5 launches each"})
+            if verified is not None:
+                line["verified"] = verified
+            if devices is not None:
+                line["devices"] = devices
+                line["rccl_world_size"] = dist.get_world_size()
+                line["collective_backend"] = dist.get_backend()
+            if strong and args.n1_strong_mpix > 0:
+                line["speedup_vs_n1"] = round(line["value"] / args.n1_strong_mpix, 3)
+            if multi:
+                line["config"]["rank0_scenes"] = cfg_scenes["scenes"]
+                line["roofline"]["kernel"] += f"; {len(batches)} launches, the events also bracket the per-scene allocation and host read"
+            if cpu_seconds > 0 and world == 1:      # reported at N=1 only, on rank 0
+                line["cpu_baseline"] = cpu_baseline(cfg, scene, params, E, cpu_seconds)
+                procs = args.cpu_procs if args.cpu_procs >= 0 else min(len(os.sched_getaffinity(0)), 16)      # a GPU box's CPU share is 16 cores
+                profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+                if profiled:        # spawned workers would inherit the profiler's preload (and its GPU initialisation): keep to one process
+                    line["cpu_baseline"]["all_cores"] = {"skipped": "running under a profiler"}
+                elif procs > 1:
+                    try:
+                        line["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(cfg, scene, params, E, cpu_seconds / 2,
+                                                                                   line["cpu_baseline"]["value"], procs)
+                    except Exception as e:      # noqa: BLE001  (a courtesy figure must not cost the result)
+                        line["cpu_baseline"]["all_cores"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        else:
+            line = None
+        state = dict(cfg=cfg, scene=scene, params=params, E=E, batch=batch, builder=builder, lo=lo, V=V, n_local=n_local, multi=multi,
+                     verified=verified, alg=None if multi else algorithmic_bytes(cfg, V, n_local, args.pixel_index), total_views=total_views)
+        return line, state
+
+
+    line, st = run_workload(args.workload, args.steps, args.warmup, args.alloc_rounds, args.views, args.cpu_seconds)
+    verified, strong = st["verified"], None
+    failed = verified is not None and not verified.get("all_ranks_ok", True)
+
+    # the garden185 streaming chains belong to whichever record holds garden185 (here: the main one, when asked for explicitly)
+    if args.workload == "garden185" and args.streaming and world == 1 and st["builder"] is not None and st["V"] > 0:
+        sr = streaming_record(args, dd, st["cfg"], st["scene"], st["params"], st["E"], st["batch"], st["builder"], device, st["lo"], st["alg"])
+        failed = failed or not sr["all_ok"]
+        if rank == 0:
+            line["streaming"] = sr
+
+    # BASELINE configs[2] (2000-view strong scaling: sharded / gathered / gathered-compact / Bernoulli), timed AFTER the main
     # result exists.  Doubly guarded: an exception is reported in the line; a collective that does not finish within
     # the watchdog's limit makes every rank print the main result and exit NON-ZERO (a hung GPU process is a failed leg).
     if args.strong_views > 0:
         import threading
 
-        del batch, builder, scene
-        if multi:
-            del batches
-            scene_pool.clear()
-            big = None
+        reuse = None
+        if args.workload == "scene2000" and st["total_views"] == args.strong_views and args.tuning == 0 and not st["multi"]:
+            reuse = dict(scene=st["scene"], batch=st["batch"], params=st["params"])      # the same views are resident already
+        st["builder"] = None
+        if reuse is None:
+            st.clear()
         torch.cuda.empty_cache()
 
         def bail():
@@ -912,24 +1052,74 @@ def main() -> None:
         dog.daemon = True
         dog.start()
         try:
-            strong = strong_scaling_record(args, dd, D, dist, use_dist, rank, world, device, fence)
+            strong = strong_scaling_record(args, dd, D, dist, use_dist, rank, world, device, fence, reuse=reuse)
         except Exception as e:      # noqa: BLE001  (reported, not fatal)
             strong = {"error": f"{type(e).__name__}: {e}"[:300]}
         dog.cancel()
         if rank == 0:
             line["strong2000"] = strong
+        reuse = None
+    st.clear()
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+
+    # the other single-GPU configurations of BASELINE.json as sub-records of the default line (N = 1 only: every one of them is a
+    # one-GPU workload; the driver's N > 1 runs measure the scaling curve of the main workload)
+    subs = []
+    if args.sub == "auto":
+        subs = ["garden185", "roofline12mp", "mip360conf"] if (world == 1 and not explicit and not use_dist) else []
+    elif args.sub != "none":
+        subs = [x for x in args.sub.split(",") if x.strip()]
+    for name in subs:
+        if name == args.workload or name not in WORKLOADS or "scenes" in WORKLOADS[name]:
+            continue
+        try:
+            from depthdensifier_amd import placement as _pl
+            _pl.trim(device)
+            torch.cuda.empty_cache()
+            v_sub = min(args.views, WORKLOADS[name]["V"]) if args.views else 0
+            sub_line, sst = run_workload(name, args.sub_steps, 3, min(args.alloc_rounds, 3), v_sub, 0.0)
+            rec = None
+            if rank == 0:
+                r = sub_line["roofline"]
+                rec = {"workload": name, "note": WORKLOADS[name]["note"], "value": sub_line["value"], "unit": sub_line["unit"], "ms_per_step": sub_line["ms_per_step"],
+                       "mpoints_per_s": sub_line["mpoints_per_s"], "steps": args.sub_steps, "warmup": 3, "dtype": sub_line["dtype"],
+                       "config": {k: sub_line["config"][k] for k in ("views_total", "height", "width", "valid_fraction", "mask_kind", "conf_kind", "inputs", "outputs")},
+                       "roofline": {k: r.get(k) for k in ("kernel", "achieved", "frac", "whole_step_frac", "traffic_frac", "traffic_over_algorithmic", "read_frac",
+                                                          "algorithmic_bytes_per_launch", "kernel_ms", "kernel_ms_min", "pass1_ms", "frac_min", "frac_median",
+                                                          "frac_max", "alloc_rounds", "redone", "placement")},
+                       "verified": sub_line.get("verified")}
+            sv = sst["verified"]
+            failed = failed or (sv is not None and not sv.get("all_ranks_ok", True))
+            if name == "garden185" and args.streaming and sst["builder"] is not None and sst["V"] > 0:
+                sr = streaming_record(args, dd, sst["cfg"], sst["scene"], sst["params"], sst["E"], sst["batch"], sst["builder"], device, sst["lo"], sst["alg"])
+                failed = failed or not sr["all_ok"]
+                if rank == 0:
+                    rec["streaming"] = sr
+            sst.clear()
+            del sst
+            gc.collect()
+        except Exception as e:      # noqa: BLE001  (one sub-record failing must not cost the line)
+            rec = {"workload": name, "error": f"{type(e).__name__}: {e}"[:300]}
+            failed = True
+        if rank == 0:
+            line[name] = rec
+        torch.cuda.empty_cache()
+
     if rank == 0:
         print(json.dumps(line), file=real_out, flush=True)
         _release_line_guard(guard)
 
-    failed = verified is not None and not verified.get("all_ranks_ok", True)
-    if isinstance(strong, dict) and isinstance(strong.get("verified"), dict) and not strong["verified"].get("all_ranks_ok", True):
-        failed = True
+    if isinstance(strong, dict):
+        for leg in (strong, strong.get("bernoulli") or {}):
+            if isinstance(leg.get("verified"), dict) and not leg["verified"].get("all_ranks_ok", True):
+                failed = True
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if failed:
-        sys.exit("bench.py: the timed cloud does NOT match the oracle (see the \"verified\" records of the line)")
+        sys.exit("bench.py: a timed cloud does NOT match the oracle, or a sub-record failed (see the \"verified\" / \"error\" records of the line)")
 
 
 if __name__ == "__main__":

@@ -12,10 +12,12 @@ __version__ = "0.1.0"
 from ._lib import DDCoreError  # noqa: F401
 from .densify import (  # noqa: F401
     BatchPlan,
+    CapturedChain,
     CloudBuilder,
     FusedCloud,
     ViewBatch,
     camera_blocks,
+    capture_chain,
     count_valid,
     fuse_batches,
     intrinsics_matrix,
@@ -29,5 +31,5 @@ from .filtering import FilteringConfig, compact_cloud, filter_cameras, filter_fl
 __all__ = [
     "DepthRefiner", "RefinerConfig", "FilteringConfig", "compact_cloud", "filter_cameras", "filter_floaters", "floater_votes",
     "CloudBuilder", "FusedCloud", "ViewBatch", "camera_blocks", "count_valid", "fuse_batches",
-    "intrinsics_matrix", "plan_batch", "BatchPlan", "unproject_views", "DDCoreError", "__version__",
+    "intrinsics_matrix", "plan_batch", "BatchPlan", "unproject_views", "DDCoreError", "__version__", "CapturedChain", "capture_chain",
 ]

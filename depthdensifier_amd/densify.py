@@ -898,6 +898,38 @@ def unproject_views(depth: ArrayLike, intrinsics: ArrayLike, cam_from_world: Arr
     return cloud
 
 
+class CapturedChain:
+    """``builder.reset()`` + ``builder.append(b)`` for every batch of ``batches``, captured ONCE in a HIP graph: ``replay()`` enqueues
+    the whole chain with one graph launch (on the current stream) instead of one kernel launch per call from Python.  Possible
+    since ABI 11: a single-pass call is one kernel whose per-call state (look-back epoch, cursor) lives on the device, so a replay
+    finds it as any later call would.  For a caller that feeds the same resident buffers again and again (a fixed ring of staging
+    stacks); the maps of the batches must stay where they are, and every replay rebuilds the cloud from the builder's first row.
+    Measured (``bench.py`` ``streaming``, ``profiles/r05_streaming_*.txt``): the chain takes the same GPU time either way -- it is
+    bound by the dependent launches on the GPU (4-5 us each), not by the host's enqueueing."""
+
+    def __init__(self, builder: "CloudBuilder", batches: Sequence["ViewBatch"]):
+        dev = builder.device
+        builder._workspace(max([b.workspace_bytes() for b in batches if b.num_views] + [1024]))      # (allocated outside the capture)
+        self.builder, self.batches = builder, list(batches)
+        self.graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(dev)
+        torch.cuda.synchronize(dev)
+        with torch.cuda.stream(side):
+            self.graph.capture_begin()
+            builder.reset()
+            for b in self.batches:
+                builder.append(b)
+            self.graph.capture_end()
+        torch.cuda.synchronize(dev)
+
+    def replay(self) -> None:
+        self.graph.replay()
+
+
+def capture_chain(builder: "CloudBuilder", batches: Sequence["ViewBatch"]) -> CapturedChain:
+    return CapturedChain(builder, batches)
+
+
 def fuse_batches(batches: Sequence[ViewBatch], capacity: Optional[int] = None, **cloud_fields) -> FusedCloud:
     """Fuse several batches (e.g. views of different resolutions) into one cloud, in order."""
     if capacity is None:

@@ -41,15 +41,18 @@ def _check(line, n_gpus, steps, warmup):
 
 
 def test_single_gpu_line():
-    line = _run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--views", "6", "--strong-views", "8", "--strong-steps", "1",
-                 "--cpu-seconds", "1", "--cpu-procs", "2", "--alloc-rounds", "2"])
+    """The driver's N = 1 command with small sizes: `value` on scene2000 (the scene BASELINE.json's metric is quoted on) and the other
+    single-GPU configurations -- garden185 with its streaming chains, roofline12mp, mip360conf -- as sub-records of the same line."""
+    line = _run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--views", "6", "--strong-views", "6", "--strong-steps", "1",
+                 "--cpu-seconds", "1", "--cpu-procs", "2", "--alloc-rounds", "2", "--sub-steps", "2"], timeout=420)
     _check(line, 1, 3, 1)
-    assert line["scaling"] == "weak" and line["config"]["workload"] == "garden185"
+    assert line["scaling"] == "strong" and line["config"]["workload"] == "scene2000" and line["config"]["views_total"] == 6
     cpu = line["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cpu) and cpu["cores"] == 1 and cpu["kind"] == "port" and cpu["value"] > 0
     assert cpu["reference_formulation"]["value"] > 0
     s = line["strong2000"]
-    assert s["views_total"] == 8 and all(s[k]["ms"] > 0 for k in ("sharded", "gathered", "gathered_compact")), s
+    assert s["views_total"] == 6 and all(s[k]["ms"] > 0 for k in ("sharded", "gathered", "gathered_compact")), s
+    assert s["bernoulli"]["sharded"]["ms"] > 0 and s["bernoulli"]["verified"]["all_ranks_ok"] and 0.7 < s["bernoulli"]["sharded"]["valid_fraction"] < 0.9
     # round 3: the timed cloud is checked against the oracle inside the bench, and the kernel is re-timed on fresh allocations
     v = line["verified"]
     assert v["all_ranks_ok"] and v["views"] >= 2 and v["points"] > 0 and v["xyz_max_rel"] <= 1e-4, v
@@ -57,6 +60,24 @@ def test_single_gpu_line():
     r = line["roofline"]
     assert r["placement"] in ("probed", "first") or r["placement"].startswith(("skipped", "degraded")), r["placement"]
     assert r["alloc_rounds"] == 2 and r["frac_min"] <= r["frac_median"] <= r["frac_max"] and len(r["kernel_ms_per_allocation"]) == 2
+    # round 5: every single-GPU configuration in the driver-run line
+    for name in ("garden185", "roofline12mp", "mip360conf"):
+        sub = line[name]
+        assert "error" not in sub, sub
+        assert sub["value"] > 0 and 0 < sub["roofline"]["frac"] < 1 and 0 < sub["roofline"]["whole_step_frac"] < 1, sub
+        assert sub["verified"]["all_ranks_ok"] and sub["roofline"]["redone"] == {"healed": 0, "dense_misses": 0}, sub
+    st = line["garden185"]["streaming"]
+    assert st["all_ok"] and set(st["per_call"]) == {"1", "8"} and st["dependent_launch_floor_us"] > 0
+    for k, item in st["per_call"].items():
+        assert item["calls"] == -(-6 // int(k)) and 0 < item["frac"] < 1 and item["verified"]["points"] > 0 and item["hip_graph_rows_equal"], item
+
+
+def test_an_explicit_workload_prints_that_workload_only():
+    line = _run([sys.executable, "bench.py", "--workload", "garden185", "--steps", "2", "--warmup", "1", "--views", "5", "--strong-views", "0",
+                 "--cpu-seconds", "0", "--alloc-rounds", "0"])
+    _check(line, 1, 2, 1)
+    assert line["scaling"] == "weak" and line["config"]["workload"] == "garden185" and "roofline12mp" not in line and "strong2000" not in line
+    assert set(line["streaming"]["per_call"]) == {"1", "8"}
 
 
 def test_two_ranks_sharing_the_gpu():
