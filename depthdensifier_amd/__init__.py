@@ -15,6 +15,7 @@ from .densify import (  # noqa: F401
     CapturedChain,
     CloudBuilder,
     FusedCloud,
+    GuessPolicy,
     ViewBatch,
     camera_blocks,
     capture_chain,
@@ -31,5 +32,5 @@ from .filtering import FilteringConfig, compact_cloud, filter_cameras, filter_fl
 __all__ = [
     "DepthRefiner", "RefinerConfig", "FilteringConfig", "compact_cloud", "filter_cameras", "filter_floaters", "floater_votes",
     "CloudBuilder", "FusedCloud", "ViewBatch", "camera_blocks", "count_valid", "fuse_batches",
-    "intrinsics_matrix", "plan_batch", "BatchPlan", "unproject_views", "DDCoreError", "__version__", "CapturedChain", "capture_chain",
+    "intrinsics_matrix", "plan_batch", "BatchPlan", "unproject_views", "DDCoreError", "__version__", "CapturedChain", "capture_chain", "GuessPolicy",
 ]

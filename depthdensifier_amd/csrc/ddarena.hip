@@ -98,6 +98,8 @@ struct Chunk {
     bool live;      // handle not yet released
     bool used;      // part of an allocation
     bool anchor;
+    bool mixed;     // two classes inside: handed out only when the device is exhausted (as class 0, the allocation reported as not apart),
+                    // never pooled as a classified spare -- it goes back to the driver when its array is freed
 };
 
 struct Mapping {
@@ -252,6 +254,7 @@ int scout_one(DDArena *A, int *chunk_out) {
         const float lo = fminf(ms, fminf(ms_fl, ms_ml)), hi = fmaxf(ms, fmaxf(ms_fl, ms_ml));
         if (lo < 0.91f * hi) {
             A->chunks[ci].cls = -1;
+            A->chunks[ci].mixed = true;
             A->mixed += 1;
             if (A->debug) fprintf(stderr, "[ddarena] chunk %d: the first, windows %.4f / %.4f / %.4f ms -> two classes inside, not used\n", ci, ms, ms_fl, ms_ml);
             *chunk_out = ci;
@@ -288,6 +291,7 @@ int scout_one(DDArena *A, int *chunk_out) {
     }
     if (!is_same_class(A, t_self)) {
         A->chunks[ci].cls = -1;                      // mixed: never handed out, goes back to the driver with the other spares
+        A->chunks[ci].mixed = true;
         A->mixed += 1;
         if (A->debug) fprintf(stderr, "[ddarena] chunk %d: first vs last window %.4f ms -> two classes inside, not used\n", ci, t_self);
         *chunk_out = ci;
@@ -319,7 +323,7 @@ int pool_or_release(DDArena *A, int ci) {
     if (!c.live || c.used || c.anchor) return DD_OK;
     int pooled = 0;
     for (const Chunk &o : A->chunks) if (&o != &c && o.live && !o.used && !o.anchor && !o.scout && o.cls == c.cls) ++pooled;
-    if (c.cls >= 0 && pooled < A->pool_per_class) {
+    if (c.cls >= 0 && !c.mixed && pooled < A->pool_per_class) {
         if (c.scout) {
             AHIP(hipMemUnmap(c.scout, A->chunk), "hipMemUnmap(scout)");
             c.scout = nullptr;

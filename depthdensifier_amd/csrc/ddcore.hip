@@ -45,6 +45,8 @@ constexpr unsigned long long ST_INCL = 2ull << 62;  // value = slot after the ti
 constexpr unsigned long long POISON = 1ull << (EPOCH_SHIFT - 1);      // inclusive granule of a tile that does not know its first row (a look-back
                                                                       // gave up somewhere before it): whoever reads it does not know its own either
 constexpr unsigned long long VAL_MASK = POISON - 1;                   // rows below 2^43
+constexpr long long POISON_ROW = 1ll << 42;   // the cursor a call leaves behind when its last tile does not know the row after the batch: beyond any
+                                              // capacity, so that calls chained behind it count their points and write nothing (the error word is set)
 constexpr unsigned TAG_AGG = 1u << EPOCH_BITS, TAG_INCL = 2u << EPOCH_BITS;   // granule >> EPOCH_SHIFT == TAG_x | epoch
 constexpr unsigned SPIN_LIMIT = 1u << 21;
 
@@ -219,7 +221,7 @@ __device__ __forceinline__ long long load_cursor(const long long *cursor) {
     return base;
 }
 __device__ __forceinline__ void close_call(WsHeader *h, long long *cursor_out, long long row_after_batch, unsigned epoch) {
-    *cursor_out = row_after_batch;          // (garbage if a look-back gave up: the error word says so)
+    *cursor_out = row_after_batch;          // (POISON_ROW if a look-back gave up: the error word says so)
     h->ticket = 0u;
     h->epoch = epoch == EPOCH_MAX ? 0u : epoch + 1u;
 }
@@ -236,7 +238,7 @@ __device__ __forceinline__ void wrap_call(WsHeader *h, unsigned long long *gran,
     for (unsigned long long i = (unsigned long long)lane; i < ws_words; i += 64ull) gran[i] = 0ull;
     if (lane == 0) {
         h->done = 0u;
-        close_call(h, cursor_out, (long long)(last & VAL_MASK), EPOCH_MAX);
+        close_call(h, cursor_out, (last & POISON) ? POISON_ROW : (long long)(last & VAL_MASK), EPOCH_MAX);
     }
 }
 
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(BLOCK) void compact_generic(const KArgs a) {
                 if (t == a.num_tiles - 1) a.view_offsets[a.V] = e + n;
             }
             if (epoch == EPOCH_MAX) wrap_call(a.hdr, a.gran, a.ws_words, a.cursor_out, a.num_tiles, lane);
-            else if (lane == 0 && t == a.num_tiles - 1) close_call(a.hdr, a.cursor_out, e + n, epoch);
+            else if (lane == 0 && t == a.num_tiles - 1) close_call(a.hdr, a.cursor_out, e < 0 ? POISON_ROW : e + n, epoch);
         }
     }
     __syncthreads();
@@ -1185,7 +1187,7 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
         }
         // the end of the call (see close_call): the batch's last tile closes it -- or, when the epoch wraps, whoever finishes last
         if (epoch == EPOCH_MAX) wrap_call(a.hdr, a.gran, a.ws_words, a.cursor_out, a.num_tiles, lane);
-        else if (lane == 0 && t == a.num_tiles - 1) close_call(a.hdr, a.cursor_out, e + n, epoch);
+        else if (lane == 0 && t == a.num_tiles - 1) close_call(a.hdr, a.cursor_out, e < 0 ? POISON_ROW : e + n, epoch);
     };
 #if DD_DENSE
     if constexpr (!REFINE && PXT == L_PXT) {

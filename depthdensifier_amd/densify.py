@@ -179,62 +179,124 @@ _small = _PinnedRing()
 
 class _HostSlots:
     """Page-locked slots of 8 int64 for results on their way BACK from the GPU (a cloud's row count and the scan status words):
-    the copies are enqueued without making the host wait, an event behind them says when the slot can be read."""
+    the copies are enqueued without making the host wait, an event behind them says when the slot can be read.  A slot belongs to
+    its ``PendingCheck`` until that has been read (or dropped); a caller that asks for many checks before reading any -- scene after
+    scene, results at the end -- makes the ring grow instead of coming round onto a slot that is still waited for."""
 
     def __init__(self, slots: int = 128, words: int = 8):
-        self.slots, self.words = slots, words
-        self._block = None
-        self._events = [None] * slots
+        self.block, self.words = slots, words
+        self._slots: list = []             # page-locked (words,) int64 views
+        self._owned: list = []
         self._next = 0
+        import threading
+        self._lock = threading.Lock()
+
+    def _grow(self) -> None:
+        block = torch.zeros(self.block * self.words, dtype=torch.int64, pin_memory=True)
+        self._slots += [block[i * self.words:(i + 1) * self.words] for i in range(self.block)]
+        self._owned += [False] * self.block
 
     def take(self):
-        if self._block is None:
-            self._block = torch.zeros(self.slots * self.words, dtype=torch.int64, pin_memory=True)
-        k = self._next % self.slots
-        self._next += 1
-        if self._events[k] is not None:
-            self._events[k].synchronize()              # a slot comes round again only after ~128 checks: long done
-        return k, self._block[k * self.words:(k + 1) * self.words]
+        with self._lock:
+            n = len(self._slots)
+            for i in range(n):
+                k = (self._next + i) % n
+                if not self._owned[k]:
+                    break
+            else:
+                k = n
+                self._grow()
+            self._owned[k] = True
+            self._next = k + 1
+            return k, self._slots[k]
 
-    def stamp(self, k: int, event) -> None:
-        self._events[k] = event
+    def release(self, k: int) -> None:
+        with self._lock:
+            self._owned[k] = False
 
 
 _results = _HostSlots()
 
 
-class PendingCheck:
-    """A ``CloudBuilder.check_async()`` in flight: the row count and the scan status of everything appended so far are on
-    their way to the host; ``result()`` waits for them (only for them: kernels enqueued later keep running) and does what
-    ``check()`` does."""
+class GuessPolicy:
+    """The score of the "no holes" guesses (``CloudBuilder.fuse_tuning``) of the clouds that share this object: a cloud guesses only
+    while the misses do not outnumber the guesses that held, so a caller that builds cloud after cloud from sensor depth with holes
+    pays one redo, not one per cloud.  Every ``CloudBuilder`` has a policy of its own unless the caller hands one in
+    (``CloudBuilder(..., guess_policy=p)``: the batch driver does, for the clouds of its scans); nothing is shared behind the
+    caller's back.  Thread-safe."""
 
-    def __init__(self, builder: "CloudBuilder", slot: torch.Tensor, nws: int, workspaces: list, event, late=()):
-        self._b, self._slot, self._nws, self._ws, self._event, self._late = builder, slot, nws, workspaces, event, list(late)
+    def __init__(self):
+        import threading
+        self.hits = 0
+        self.misses = 0
+        self._lock = threading.Lock()
+
+    def allows(self) -> bool:
+        return self.misses <= self.hits
+
+    def held(self, n: int = 1) -> None:
+        with self._lock:
+            self.hits += n
+
+    def missed(self) -> None:
+        with self._lock:
+            self.misses += 1
+
+
+class PendingCheck:
+    """A ``CloudBuilder.check_async()`` in flight: the row count and the scan status of everything appended UP TO THAT CALL are on
+    their way to the host; ``result()`` waits for them (only for them: kernels enqueued later keep running) and does what
+    ``check()`` does -- for those batches.  Batches appended after the call are neither verified nor released by it."""
+
+    def __init__(self, builder: "CloudBuilder", key: int, slot: torch.Tensor, nws: int, workspaces: list, event, late=()):
+        self._b, self._key, self._slot, self._nws, self._ws, self._event, self._late = builder, key, slot, nws, workspaces, event, list(late)
         self._epoch = builder._epoch                 # reset() since then: the cloud asked about is no longer the builder's
+        self._retained_then = len(builder._retained)        # the batches this check covers ...
+        self._appends_then = builder._appends                # ... (all of them, if nothing was appended since)
+        self._guesses_then = builder._guesses_pending
+        self._done = False
+
+    def __del__(self):
+        try:
+            if not self._done:
+                _results.release(self._key)
+        except Exception:      # noqa: BLE001  (interpreter shutdown)
+            pass
 
     def result(self, heal: bool = True) -> int:
         self._event.synchronize()
         b = self._b
         total = int(self._slot[0])
         words = [(w, v >> 32) for w, v in zip(self._ws, self._slot[1:1 + self._nws].tolist())]
+        if not self._done:
+            self._done = True
+            _results.release(self._key)
         words += [(w, int(w[:8].view(torch.int32)[1].item())) for w in self._late]
         bad = [w for w, code in words if code != 0]
+        stale = b._epoch != self._epoch
         if bad:
+            dense_miss = any(code == 2 for _, code in words)          # (2: a batch run as 'assume dense' was not)
             for w in bad:
                 w.zero_()                                 # sticky word: cleared only here, once seen -- and with it the whole workspace:
                                                           # after a give-up the single-pass state (epoch, granules) is not to be trusted
-            if not heal or b._epoch != self._epoch:
-                raise RuntimeError("libddcore: in-kernel scan timed out in one of the appended batches, or a batch run as 'assume dense' "
-                                   "was not dense (workspace error word set); rows are invalid -- append the batches again with tuning=4")
-            total = b._heal(dense_miss=any(code == 2 for _, code in words))       # (2: a batch run as 'assume dense' was not)
+            what = ("a batch run without a counting pass ('assume dense', tuning bit 17) was not dense" if dense_miss
+                    else "an in-kernel scan timed out in one of the appended batches")
+            if stale:
+                raise RuntimeError(f"libddcore: {what} (workspace error word set), and the builder was reset() since this check was asked "
+                                   "for: the rows it is about are gone -- nothing to redo")
+            if not heal:
+                raise RuntimeError(f"libddcore: {what} (workspace error word set); rows are invalid -- append the batches again with tuning=4")
+            total = b._heal(dense_miss=dense_miss)
+            self._retained_then, self._appends_then, self._guesses_then = len(b._retained), b._appends, 0      # the redo covered everything held
         if total > b.capacity:
             raise OverflowError(f"cloud capacity {b.capacity} < {total} valid points; "
                                 "allocate with capacity=batch.max_points or count_valid() first")
-        if b._epoch == self._epoch:
-            if not bad and b._guesses_pending:
-                CloudBuilder.guess_hits += b._guesses_pending      # every guess appended so far held
-                b._guesses_pending = 0
-            b._release_retained(total)
+        if not stale:
+            if not bad and self._guesses_then:
+                b.guess_policy.held(self._guesses_then)      # every guess appended before the check held
+                b._guesses_pending = max(0, b._guesses_pending - self._guesses_then)
+                self._guesses_then = 0
+            b._release_retained(total, self._retained_then, self._appends_then)
         return total
 
 
@@ -538,10 +600,6 @@ class CloudBuilder:
     INTERLEAVE_MIN_ROWS = 256 << 20
     GUESS_MIN_PIXELS = 4 << 20       # unmasked batches from this size on run count-free (1.41x the single pass at 24 M pixels, 1.22x at 61 M, 1.11x at
                                      # 244 M, 1.23x at 6.1 G: profiles/r04_ab_count_free_small_batches.txt); below, a launch is a few microseconds either way
-    # the guesses of ALL clouds of the process: a scan after scan of sensor depth with holes would otherwise pay one redo per cloud.
-    # A cloud guesses only while the misses so far do not outnumber the guesses that held (0 : 0 at the start: the first one is free)
-    guess_hits = 0
-    guess_misses = 0
     INTERLEAVE_REGIONS = 8           # = the number of XCDs: workgroup b runs on XCD b mod 8 (round-robin dispatch) and takes a tile of stretch b mod 8, so
                                      # every XCD writes an eighth of the cloud of its own.  Interleaved A/B in one process (profiles/r04_ab_interleave_count.txt):
                                      # 8 -> 0.822, 16 -> 0.818, 24 / 32 -> 0.811, 3 ... 15 (no multiple of 8) -> 0.797-0.804, 18 -> 0.785
@@ -551,7 +609,8 @@ class CloudBuilder:
 
     def __init__(self, capacity: int, *, normals: bool = False, colors: bool = False,
                  pixel_index: bool = True, view_index: bool = False, packed: bool = False, points: bool = True,
-                 buffers: Optional[dict] = None, start=None, device=None, placement: Optional[str] = None):
+                 buffers: Optional[dict] = None, start=None, device=None, placement: Optional[str] = None,
+                 guess_policy: Optional[GuessPolicy] = None):
         """``packed``: also (or, with ``points=False``, only) write the 16-byte ``x, y, z, rgba`` record per point
         (``DDCloudOut.xyz_rgba``).  ``buffers``: caller-owned tensors to write into instead of allocating, keyed like
         ``FIELDS`` -- the multi-GPU fuse hands in the GLOBAL cloud so that every point is written once, at its final
@@ -560,7 +619,8 @@ class CloudBuilder:
         allocation below; ``"probed"`` builds the row arrays from physical chunks spread over the three classes of HBM
         address ranges whatever the size, so that points and normals -- written in lock step -- never share a class
         (``placement.place_outputs``; ``self.placement`` reports what was done); ``"first"`` takes the arrays as the
-        allocator returns them.
+        allocator returns them.  ``guess_policy``: the score of the "no holes" guesses (``fuse_tuning``) this cloud shares with the
+        caller's other clouds; default: one of its own.
 
         The builder keeps the batches it is given (and with them their maps) until the next ``check()`` / ``finish()`` /
         ``reset()`` so that it can redo them if an in-kernel scan gives up (``self.healed``); it stops keeping them once they
@@ -616,6 +676,8 @@ class CloudBuilder:
         self._epoch = 0                              # counts reset(): a PendingCheck knows which cloud it was asked about
         self.healed = 0
         self._guesses_pending = 0
+        self._appends = 0                            # append() calls since the last reset(): what a PendingCheck covers
+        self.guess_policy = guess_policy if guess_policy is not None else GuessPolicy()
         self.speculate_dense = True                  # fuse_tuning may run unmasked batches of a blocked cloud without the counting pass
         self.dense_misses = 0                        # ... until one of them was not dense (then never again on this cloud)
 
@@ -629,6 +691,7 @@ class CloudBuilder:
 
     def reset(self) -> None:
         self._epoch += 1
+        self._appends = 0
         self._guesses_pending = 0                    # (guesses nobody looked at are neither hits nor misses)
         self._set_start()
         self._offsets.clear()
@@ -638,17 +701,24 @@ class CloudBuilder:
         self._retain_complete = True
         self._retain_base = None
 
+    def _retain_cost(self, batch: "ViewBatch") -> int:
+        """Bytes of maps that holding ``batch`` for a redo keeps alive beyond what is held already."""
+        if self._retained and self._retained[-1][0] is batch:          # the same batch again (a timing loop): nothing new is held
+            return 0
+        return sum(t.numel() * t.element_size() for t in (batch.depth, batch.mask, batch.conf, batch.normal, batch.rgb) if t is not None)
+
+    def _will_retain(self, batch: "ViewBatch") -> bool:
+        return self._retain_complete and self._retained_bytes + self._retain_cost(batch) <= self._retain_limit
+
     def _retain(self, batch: "ViewBatch", offsets: torch.Tensor) -> None:
         if not self._retain_complete:
             return
-        nbytes = sum(t.numel() * t.element_size() for t in (batch.depth, batch.mask, batch.conf, batch.normal, batch.rgb) if t is not None)
-        if self._retained and self._retained[-1][0] is batch:          # the same batch again (a timing loop): nothing new is held
-            nbytes = 0
+        nbytes = self._retain_cost(batch)
         if self._retained_bytes + nbytes > self._retain_limit:
             self._retain_complete = False
             self._retained.clear()
             return
-        self._retained.append((batch, offsets, self._versions(batch)))
+        self._retained.append((batch, offsets, self._versions(batch), nbytes))
         self._retained_bytes += nbytes
 
     @staticmethod
@@ -682,6 +752,8 @@ class CloudBuilder:
         if self.rgb is not None and batch.rgb is None:
             raise ValueError("this cloud carries colours but the batch has no rgb image")
         redo = _offsets is not None
+        if not redo:
+            self._appends += 1
         if batch.num_views == 0:                       # an empty chunk of views: nothing to enqueue, the cursor stays
             offsets = _offsets if redo else self._offsets_slice(1)
             offsets.copy_(self.cursor, non_blocking=True)
@@ -723,8 +795,9 @@ class CloudBuilder:
         blocked = (self.placement is not None and self.placement.layout == "blocked"
                    and self.placement.mode.startswith(("probed", "degraded")) and batch.max_points >= self.INTERLEAVE_MIN_ROWS // 2)
         guess = (self.normal is None and batch.mask is None and batch.conf is None and self.speculate_dense and not self.dense_misses
-                 and CloudBuilder.guess_misses <= CloudBuilder.guess_hits and batch.max_points >= self.GUESS_MIN_PIXELS
-                 and self.capacity >= batch.max_points)       # (a cloud sized below the pixel count says the maps have holes)
+                 and self.guess_policy.allows() and batch.max_points >= self.GUESS_MIN_PIXELS
+                 and self.capacity >= batch.max_points        # (a cloud sized below the pixel count says the maps have holes)
+                 and self._will_retain(batch))                # (a guess that misses is redone from the batch: only if it will be held)
         if blocked or guess:
             # (+ bit 128: dense tiles take the list-free path -- in the scatter pass, which waits for no look-back, its smaller
             # instruction count is worth 0.3-1.3 %; in the single-pass kernel it is not)
@@ -774,15 +847,23 @@ class CloudBuilder:
             slot[1 + i:2 + i].copy_(w[:8].view(torch.int64), non_blocking=True)      # bytes 4..7 = the error word
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
-        _results.stamp(k, ev)
-        return PendingCheck(self, slot, len(ws), ws, ev, late)
+        return PendingCheck(self, k, slot, len(ws), ws, ev, late)
 
-    def _release_retained(self, total: int) -> None:
-        # everything appended so far is final: the batches (and their maps) need not be held any longer; a later redo starts here
-        self._retained.clear()
-        self._retained_bytes = 0
-        self._retain_complete = True
-        self._retain_base = total
+    def _release_retained(self, total: int, covered: Optional[int] = None, appends_then: Optional[int] = None) -> None:
+        """Everything a check covered is final: those batches (and their maps) need not be held any longer, a later redo starts
+        behind them.  ``covered`` / ``appends_then``: how many retained batches / append() calls the check saw; batches appended
+        after it stay held (or stay not held, if retention had given up by then) -- the check says nothing about them."""
+        if appends_then is None or appends_then == self._appends:
+            self._retained.clear()                    # nothing was appended since: the whole cloud so far is final
+            self._retained_bytes = 0
+            self._retain_complete = True
+            self._retain_base = total
+            return
+        if not self._retain_complete:
+            return                                    # batches behind the check are not held: a redo of them stays impossible
+        del self._retained[:covered]
+        self._retained_bytes = sum(e[3] for e in self._retained)
+        self._retain_base = total                     # the row the first batch behind the check starts from
 
     def finish(self, name: str = "Dense Cloud") -> FusedCloud:
         """Synchronise once, check the scan status words and the capacity, return exact-size views."""
@@ -810,20 +891,22 @@ class CloudBuilder:
         """A look-back of the single-pass kernel timed out (a workgroup was parked for ~2 s: another tenant, ranks sharing
         the GPU): every batch appended since the last reset is run again through dd_plan + dd_scatter (``tuning`` bit 4),
         whose workgroups do not depend on each other, writing the same rows and the same offset tensors."""
+        what = ("a batch run without a counting pass ('assume dense', tuning bit 17) was not dense" if dense_miss
+                else "an in-kernel scan timed out in one of the appended batches")
         if not self._retain_complete or not self._retained:
-            raise RuntimeError("libddcore: in-kernel scan timed out in one of the appended batches (workspace error word set) "
+            raise RuntimeError(f"libddcore: {what} (workspace error word set) "
                                "and the batches are no longer held (more than a quarter of the device's memory): rows are "
                                "invalid -- append the batches again with tuning=4")
-        for batch, _, versions in self._retained:
+        for batch, _, versions, _ in self._retained:
             if self._versions(batch) != versions:
-                raise RuntimeError("libddcore: in-kernel scan timed out in one of the appended batches (workspace error word set) and "
+                raise RuntimeError(f"libddcore: {what} (workspace error word set) and "
                                    "one of its maps was modified in place after append(): the rows cannot be redone -- append the "
                                    "batches again with tuning=4 (inputs must stay unmodified until check() / finish())")
         if self._retain_base is None:
             self._set_start()
         else:
             self.cursor.fill_(self._retain_base)
-        for batch, offsets, _ in self._retained:
+        for batch, offsets, _, _ in self._retained:
             saved = batch.tuning
             batch.tuning = (saved | 4) & ~(8 | 64 | _lib.DD_TUNE_ASSUME_DENSE)
             try:
@@ -834,7 +917,7 @@ class CloudBuilder:
         if dense_miss:
             self.dense_misses += 1                           # this cloud stops guessing (fuse_tuning)
             if self._guesses_pending:                        # (the policy's guess, not a bit the caller set)
-                CloudBuilder.guess_misses += 1
+                self.guess_policy.missed()
             self._guesses_pending = 0
         total = int(self.cursor.item())
         if self._scan_gave_up():                             # cannot happen: the two-pass kernels have no look-back

@@ -327,6 +327,9 @@ def fuse_replicated(batch, num_views_total: int, *, normals: bool = True, colors
     builder = CloudBuilder(cap, points=rows, normals=normals and rows, colors=colors and rows, pixel_index=pixel_index,
                            view_index=view_index, packed=not rows, buffers=buffers, start=own_lo - base, device=batch.device,
                            placement="first")      # these arrays go over RCCL: plain allocations (arena memory is not IPC-exportable)
+    # the counts are KNOWN here (plan_fuse): nothing to guess -- and a guess that missed would scatter rows beyond this rank's
+    # [own_lo, own_hi) into regions of the shared buffers that RCCL is receiving the peers' rows into
+    builder.speculate_dense = False
     moved = [t for t in (builder.xyz, builder.normal, builder.rgb, builder.pix, builder.view, builder.packed) if t is not None]
     work = []
     for (lo, hi), ranges in zip(plan.chunk_views, plan.chunk_rows):

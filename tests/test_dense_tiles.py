@@ -266,7 +266,6 @@ def test_a_blocked_cloud_of_points_is_filled_in_thirds(dd):
     mask[:, 100:300, 200:900] = False
     old = dd.CloudBuilder.INTERLEAVE_MIN_ROWS
     dd.CloudBuilder.INTERLEAVE_MIN_ROWS = 64 << 20
-    dd.CloudBuilder.guess_hits = dd.CloudBuilder.guess_misses = 0          # (the process-wide score of the guesses: a fresh start)
     K1 = dd.CloudBuilder.INTERLEAVE_REGIONS - 1
     try:
         # a masked batch: counted, the scatter interleaved
@@ -297,12 +296,13 @@ def test_a_blocked_cloud_of_points_is_filled_in_thirds(dd):
         assert b.healed == 1 and b.dense_misses == 1
         tun = b.fuse_tuning(holed)
         assert tun & 4 and not tun & ASSUME
-        assert (dd.CloudBuilder.guess_hits, dd.CloudBuilder.guess_misses) == (1, 1)
-        # the score is the process's: one more miss than hits and NO cloud guesses any more
-        dd.CloudBuilder.guess_misses = 2
-        other = dd.CloudBuilder(dense.max_points, pixel_index=False, placement="first")
+        assert (b.guess_policy.hits, b.guess_policy.misses) == (1, 1)
+        # the score belongs to whoever owns the policy object: a cloud that SHARES it stops guessing once the misses outnumber the
+        # guesses that held; a cloud with a policy of its own (the default) knows nothing of it
+        b.guess_policy.missed()
+        other = dd.CloudBuilder(dense.max_points, pixel_index=False, placement="first", guess_policy=b.guess_policy)
         assert not other.fuse_tuning(dense) & ASSUME
-        dd.CloudBuilder.guess_misses = 1
+        assert dd.CloudBuilder(dense.max_points, pixel_index=False, placement="first").fuse_tuning(dense) & ASSUME
         # plainly allocated arrays guess too (an unmasked batch, no normals), and run masked batches in the single pass
         plain = dd.CloudBuilder(holed.max_points, pixel_index=False, placement="first")
         assert plain.fuse_tuning(holed) & ASSUME and not plain.fuse_tuning(holed) & 4 and plain.fuse_tuning(masked) == 0

@@ -609,7 +609,6 @@ def test_12mp_f16_dense_beyond_2_31_rows(dd, orc, tuning):
     params = np.tile([0.8 * W, 0.8 * W, W / 2, H / 2], (V, 1))
     E = _ring_poses(V)
     batch = dd.ViewBatch(depth, params, E, tuning=tuning)
-    dd.CloudBuilder.guess_hits = dd.CloudBuilder.guess_misses = 0          # (the process-wide score of the guesses: a fresh start)
     b = dd.CloudBuilder(batch.max_points, pixel_index=True)
     assert bool(b.fuse_tuning(batch) & (1 << 17)) == (tuning == 0)
     b.append(batch)

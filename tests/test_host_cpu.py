@@ -167,7 +167,7 @@ def test_product_never_imports_oracle():
         owner = re.findall(r"^def (\w+)\(", bench_src[:u], re.M)[-1]
         assert owner in ("cpu_baseline", "_cpu_worker", "verify_views"), f"bench.py uses the oracle in {owner}()"
     # verify_views is a checker: it runs after the timed region and its result never feeds the product path
-    timed = bench_src[bench_src.index("t0 = time.perf_counter()\n    for _ in range(args.steps):"):bench_src.index("elapsed = time.perf_counter() - t0")]
+    timed = bench_src[bench_src.index("t0 = time.perf_counter()\n        for _ in range(steps):"):bench_src.index("elapsed = time.perf_counter() - t0")]
     assert "verify_views" not in timed and "oracle" not in timed
 
 

@@ -182,3 +182,104 @@ def test_appends_after_a_healed_give_up_start_from_a_clean_workspace(dd):
     assert _header(b) == {"error": 0, "ticket": 0, "done": 0, "epoch": 0}
     b.append(whole.slice(4, 8))
     _equal(b.finish(), want)
+
+
+def test_a_check_covers_what_was_appended_when_it_was_asked_for(dd):
+    """append(A); p = check_async(); append(B); p.result(): A is verified and released, B is neither -- it stays held, and a
+    give-up inside B that a LATER check sees is redone from the row behind A (result() used to treat B as verified,
+    dropped it, and a later redo wrote the batch after it over B's rows)."""
+    import torch
+    V, H, W = 9, 96, 160
+    depth, mask, normal, rgb, params, E = _case(41, V, H, W)
+    whole = dd.ViewBatch(depth, params, E, mask=mask, normal=normal, rgb=rgb)
+    b = dd.CloudBuilder(whole.max_points, normals=True, colors=True, pixel_index=True)
+    b.append(whole)
+    want = b.finish()
+    b.reset()
+    A, B, Cc = whole.slice(0, 3), whole.slice(3, 6), whole.slice(6, 9)
+    B.tuning = 64                                    # every look-back of B that has to wait gives up
+    b.append(A)
+    p = b.check_async()
+    b.append(B)
+    assert p.result() == int(want.view_offsets[3])   # the count behind A; B's error is not this check's business ...
+    assert len(b._retained) == 1 and b._retained[0][0] is B and b._retain_base == int(want.view_offsets[3]) and b.healed == 0
+    b.append(Cc)
+    got = b.finish()                                 # ... it is this one's: B and C are redone from the row behind A
+    assert b.healed == 1
+    _equal(got, want)
+    # the same with the fault in A: the redo covers everything held, the answer is the count behind all of it
+    b.reset()
+    A.tuning, B.tuning = 64, 0
+    b.append(A)
+    p = b.check_async()
+    b.append(B)
+    assert p.result() == int(want.view_offsets[6]) and b.healed == 2 and not b._retained
+    b.append(Cc)
+    _equal(b.finish(), want)
+    # a reader that comes after a reset() finds nothing to redo: an error that says so
+    A.tuning = 64
+    b.reset(); b.append(A)
+    p = b.check_async()
+    b.reset(); b.append(B)
+    with pytest.raises(RuntimeError, match="reset"):
+        p.result()
+    b.append(Cc)
+    assert b.check() == int(want.view_offsets[9] - want.view_offsets[3])
+
+
+def test_more_checks_in_flight_than_the_ring_had_slots(dd):
+    """300 check_async() before the first result() is read (scene after scene, results at the end): every answer is its own."""
+    V, H, W = 2, 40, 96
+    depth, mask, normal, rgb, params, E = _case(43, V, H, W)
+    one = dd.ViewBatch(depth[:1], params[:1], E[:1], mask=mask[:1])
+    n1 = int((mask[0] & (depth[0] > 0)).sum())
+    b = dd.CloudBuilder(400 * one.max_points, pixel_index=False)
+    pending = []
+    for i in range(300):
+        b.append(one)
+        pending.append(b.check_async())
+    assert [p.result() for p in pending] == [n1 * (i + 1) for i in range(300)]
+
+
+def test_no_guess_without_a_way_back_and_policies_are_the_callers(dd):
+    """A batch is run count-free ("no holes") only if the builder will hold it for the redo a miss needs; the score of the guesses
+    lives in an object the caller owns -- two builders in two threads, each with its own, do not see each other's misses."""
+    import threading
+    import torch
+    V, H, W = 3, 1080, 1920                          # 6.2 M pixels: above GUESS_MIN_PIXELS
+    g = torch.Generator(device="cuda").manual_seed(3)
+    depth = torch.empty((V, H, W), device="cuda", dtype=torch.float16).uniform_(0.5, 8.0, generator=g)
+    holes = depth.clone()
+    holes[:, 500:520, 100:900] = 0
+    params = np.tile([0.8 * W, 0.8 * W, W / 2, H / 2], (V, 1))
+    E = np.tile(np.eye(4)[:3], (V, 1, 1))
+    dense, holed = dd.ViewBatch(depth, params, E), dd.ViewBatch(holes, params, E)
+    b = dd.CloudBuilder(dense.max_points, pixel_index=False, placement="first")
+    assert b.fuse_tuning(dense) & (1 << 17)
+    b._retain_limit = 1 << 20                        # (a device with little memory left: the maps of a batch will not be held)
+    assert not b.fuse_tuning(dense) & (1 << 17)
+    b.append(holed)                                  # ... so the batch with holes runs counted, and finishes without a redo
+    assert b.check() == int((holes > 0).sum()) and b.healed == 0
+    ref = dd.CloudBuilder(dense.max_points, pixel_index=False, placement="first")
+    ref.append(dd.ViewBatch(holes, params, E, tuning=8))
+    want = ref.finish()
+
+    results = {}
+
+    def worker(name, batch, rounds):
+        torch.cuda.set_device(0)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            mine = dd.CloudBuilder(batch.max_points, pixel_index=False, placement="first")
+            for _ in range(rounds):
+                mine.reset()
+                mine.append(batch)
+                n = mine.check()
+            results[name] = (n, mine.guess_policy.hits, mine.guess_policy.misses, mine.healed, mine.xyz[:n].clone())
+
+    t1 = threading.Thread(target=worker, args=("dense", dd.ViewBatch(depth, params, E), 4))
+    t2 = threading.Thread(target=worker, args=("holed", dd.ViewBatch(holes, params, E), 4))
+    t1.start(); t2.start(); t1.join(); t2.join()
+    assert results["dense"][:4] == (V * H * W, 4, 0, 0)                     # four guesses, all held
+    assert results["holed"][:4] == (len(want), 0, 1, 1)                     # one miss, one redo, then counted
+    assert torch.equal(results["holed"][4], want.points)
+    assert not hasattr(dd.CloudBuilder, "guess_hits") and not hasattr(dd.CloudBuilder, "guess_misses")
