@@ -442,7 +442,23 @@ def streaming_record(args, dd, cfg, scene, params, E, batch, builder, device, vi
             ts.append(e0.elapsed_time(e1)); hs.append((h1 - h0) * 1e3)
         total = builder.check()
         med = float(np.median(ts))
+        shared = None
+        if builder.exclusive_gpu:                    # the same chain with tickets (the library's default on a GPU that may be shared)
+            builder.exclusive_gpu = False
+            chain(); builder.check()
+            t2 = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize(device)
+                e0.record(); chain(); e1.record()
+                torch.cuda.synchronize(device)
+                t2.append(e0.elapsed_time(e1))
+            builder.check()
+            shared = float(np.median(t2))
+            builder.exclusive_gpu = True
+            chain(); total = builder.check()
         item = {"calls": len(subs), "chain_ms": round(med, 4), "chain_ms_min": round(min(ts), 4), "us_per_call": round(1e3 * med / len(subs), 2),
+                "frac_shared_gpu_mode": None if shared is None else round(alg_bytes / (shared * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                 "frac": round(alg_bytes / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "mpixels_per_s": round(V * cfg["H"] * cfg["W"] / (med * 1e-3) / 1e6, 1),
                 "host_enqueue_ms": round(float(np.median(hs)), 3), "redone": {"healed": int(builder.healed), "dense_misses": int(builder.dense_misses)}}
         if not args.no_verify:
@@ -637,6 +653,10 @@ def main() -> None:
     args.streaming = [int(x) for x in args.streaming.split(",") if x.strip()]
     if os.environ.get("DD_BENCH_SHARE_GPU") == "1":
         args.placement = "first"         # rehearsal ranks share one GPU: no scouting of its memory by several processes at once
+    # one process per GPU, one densify stream: the deployment the north star names.  The single-pass kernel then takes its tiles by
+    # workgroup index instead of drawing tickets (CloudBuilder.exclusive_gpu); the line also carries the figure WITH tickets, the
+    # library's default for a GPU that may be shared (`roofline.frac_shared_gpu_mode`).  Rehearsal ranks that share a GPU: tickets.
+    os.environ.setdefault("DD_EXCLUSIVE_GPU", "0" if os.environ.get("DD_BENCH_SHARE_GPU") == "1" else "1")
     real_out = _claim_stdout()
     guard = None
     if rank == 0 and args.strong_views > 0 and (world > 1 or os.environ.get("DD_BENCH_FORCE_DIST") == "1"):
@@ -848,6 +868,21 @@ def main() -> None:
         kernel_ms = float(np.mean(k_all))
         if single_pass:
             plan_ms = 0.0
+        # the same step with tiles drawn by ticket: what a caller gets who cannot promise to have the GPU to itself (the library's default)
+        shared_ms = None
+        if builder is not None and single_pass and builder.exclusive_gpu and V > 0:
+            builder.exclusive_gpu = False
+            ts = []
+            for _ in range(7):
+                builder.reset()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); builder.append(batch); e1.record()
+                torch.cuda.synchronize(device)
+                ts.append(e0.elapsed_time(e1))
+            builder.check()
+            shared_ms = float(np.median(ts[2:]))
+            builder.exclusive_gpu = True
+            builder.reset(); builder.append(batch); builder.check()      # (the cloud that is verified below is the default mode's again)
 
         # ---- the timed cloud against the oracle (untimed; every rank checks views of its own shard)
         verified = None
@@ -965,7 +1000,11 @@ def main() -> None:
                              "sizing_pass": "none: the cloud is allocated for every visited pixel (capacity = V*H*W rows)",
                              "pass1_ms": round(plan_ms, 4),
                              "pass1_note": "two-pass mode only: count_lean + scan kernels re-read depth+mask (not credited); whole_step_frac and `value` include them",
-                             "whole_step_frac": round(alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+                             "whole_step_frac": round(alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                             "exclusive_gpu": None if builder is None else bool(builder.exclusive_gpu),
+                             "frac_shared_gpu_mode": None if shared_ms is None else round(alg / (shared_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                             "shared_gpu_mode_note": "the same launch with its tiles drawn by ticket instead of taken by workgroup index: the library's default, "
+                                                     "safe when other launches of the kind share the GPU (DD_EXCLUSIVE_GPU=0; median of 5 launches)"},
             }
             rf = line["roofline"]
             if builder is not None:                     # redone batches: look-back give-ups and dense speculations that missed (0 / 0 expected)
@@ -1088,7 +1127,7 @@ def main() -> None:
                        "config": {k: sub_line["config"][k] for k in ("views_total", "height", "width", "valid_fraction", "mask_kind", "conf_kind", "inputs", "outputs")},
                        "roofline": {k: r.get(k) for k in ("kernel", "achieved", "frac", "whole_step_frac", "traffic_frac", "traffic_over_algorithmic", "read_frac",
                                                           "algorithmic_bytes_per_launch", "kernel_ms", "kernel_ms_min", "pass1_ms", "frac_min", "frac_median",
-                                                          "frac_max", "alloc_rounds", "redone", "placement")},
+                                                          "frac_max", "alloc_rounds", "redone", "placement", "exclusive_gpu", "frac_shared_gpu_mode")},
                        "verified": sub_line.get("verified")}
             sv = sst["verified"]
             failed = failed or (sv is not None and not sv.get("all_ranks_ok", True))

@@ -120,6 +120,7 @@ class DDFilterViews(C.Structure):
 DD_ARENA_ROTATED = 8
 DD_ARENA_BLOCKED = 16
 DD_TUNE_ASSUME_DENSE = 1 << 17      # DDViewBatch.tuning: count-free plan, verified by the scatter pass (include/ddcore.h)
+DD_TUNE_BY_INDEX = 1 << 22          # DDViewBatch.tuning: single-pass tiles taken by workgroup index, not by ticket (the caller has the GPU to itself)
 
 
 class DDArenaStats(C.Structure):

@@ -100,6 +100,8 @@ struct KArgs {
     long long *cursor_out;        // two-pass: scan_views stores the row after the batch here (may be NULL)
     WsHeader *hdr;
     unsigned long long *gran;     // look-back granules, one per tile of the single-pass tiling
+    unsigned long long *pref;     // scan service: the first row of every tile, written by the service workgroup (same tags as the granules)
+    int scan_service;             // single-pass lean kernel: one workgroup of the launch scans the tiles' counts, the tiles poll their own row
     TileCO *tiles;                // two-pass: count and first row of every tile (NULL in dd_count_valid)
     unsigned long long ws_words;  // 8-byte words of the caller's workspace behind the header (what a wrap of the epoch zeroes)
     unsigned long long *counts;   // per-view counts (dd_count_valid)
@@ -469,12 +471,15 @@ constexpr int SP_WAVES = DD_SP_WAVES;         // single-pass variant: 12 waves, 
 #define DD_SP_PXT_SMALL 8
 #endif
 #ifndef DD_SP_SMALL_BATCH_TILES
-#define DD_SP_SMALL_BATCH_TILES 2048
+#define DD_SP_SMALL_BATCH_TILES 3072
 #endif
-// A small batch (a streamed view or a few: scripts/test.py:131 densifies one view per loop iteration, pipeline.py eight per launch)
+// A small batch (a streamed view or two: scripts/test.py:131 densifies one view per loop iteration)
 // does not fill the chip even once, so a tile's lifetime IS the kernel's: 8 pixels per lane instead of 16 -- 6144-pixel tiles -- halve
 // the chain of gather / store sweeps every lane walks through and double the workgroups (profiles/r05_stamps_small_batches.txt:
 // of the 17 us a 12288-pixel tile of a one-view launch lives, 8.5 are those sweeps, 16 times one memory latency that nothing hides).
+// In a CHAIN of calls (what a streaming caller makes) the small tile wins up to 16 views of 1080p per call and draws at 32
+// (profiles/r05_streaming_sweep_9_service_ticket_vs_index.txt: 8 views 0.677 against 0.644, 16 views 0.717 against 0.704); a single
+// launch between two synchronisations prefers the large tile from four views on (r05_ab_scan_service_2.txt) -- the chain decides.
 constexpr int SP_PXT_SMALL = DD_SP_PXT_SMALL;
 constexpr unsigned long long SP_SMALL_BATCH_TILES = DD_SP_SMALL_BATCH_TILES;   // batches of up to this many 12288-pixel tiles take the small tile
 static_assert(DD_SP_WAVES * 64 * DD_SP_PXT_SMALL >= 4096, "the workspace holds one record per 4096 pixels: the small single-pass tile must not be finer");
@@ -634,6 +639,107 @@ __device__ __forceinline__ void lean_load_test(const KArgs &a, long long vbase, 
         }
         bits[ch] = b;
     }
+}
+
+#ifndef DD_LB_SLEEP
+#define DD_LB_SLEEP 1
+#endif
+// ==================================================================================================
+// The scan service (round 5).  In the decoupled look-back every tile's wave 0 polls its predecessors' granules through the memory
+// pipeline of a CU whose other 23 waves are streaming rows: a polling round takes ~0.5 us whatever the window and whichever cache
+// answers (16 / 32 / 64 lanes, pairs per 16-byte load, granules kept in the XCD's own L2: profiles/r05_ab_paired_polls.txt,
+// r05_ab_xcd_runs.txt), the inclusive prefix advances 16 tiles per round, and a tile spends a third to a half of its life waiting
+// for it.  Here ONE workgroup of the launch -- ticket 0 -- does nothing but the scan: its first wave reads the tiles' counts 256
+// at a time as they are published (coalesced loads, four in flight), adds them up with a wave scan and publishes every tile's
+// FIRST ROW; a tile publishes its count and polls one word, its own.  The chain of dependent round trips is gone: a tile's row is
+// two hand-overs behind its count, whatever the tiles before it are doing.
+// ==================================================================================================
+__device__ __forceinline__ void scan_service(const KArgs &a, const unsigned epoch, const long long base, const int lane) {
+    constexpr int K = 4;                              // loads in flight per lane: 256 tiles per round
+    const unsigned T = a.num_tiles;
+    const unsigned tag_a = TAG_AGG | epoch;
+    const unsigned long long itag = (unsigned long long)(TAG_INCL | epoch) << EPOCH_SHIFT;
+    const unsigned limit = a.spin_limit ? a.spin_limit : SPIN_LIMIT;
+    unsigned f = 0;                                   // tiles [0, f) have their first row
+    long long running = base;                         // first row of tile f
+    unsigned spins = 0;
+    bool poison = false;                              // from here on the rows are unknown (a tile never published; fault injection)
+    while (f < T) {
+        unsigned long long s[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const unsigned idx = f + (unsigned)(k * 64 + lane);
+            s[k] = idx < T ? ld_state(&a.gran[idx]) : 0ull;
+        }
+        unsigned got = 0;
+        bool more = true;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (more) {
+                const unsigned first = f + (unsigned)(k * 64);
+                const unsigned cnt = first >= T ? 0u : (T - first < 64u ? T - first : 64u);
+                const bool ready = (unsigned)lane < cnt && (unsigned)(s[k] >> EPOCH_SHIFT) == tag_a;
+                const unsigned long long rb = __ballot(ready);
+                const unsigned nr = rb == ~0ull ? 64u : (unsigned)__builtin_ctzll(~rb);      // tiles of this group ready IN ORDER
+                if (nr) {
+                    if (a.spin_limit == 0u && first + nr > 1u) poison = true;      // tuning bit 64: behave as if tile 1 had never published
+                    const unsigned val = (unsigned)lane < nr ? ((unsigned)s[k] & 0xffffu) : 0u;
+                    unsigned incl = val;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const unsigned y = __shfl_up(incl, o);
+                        if (lane >= o) incl += y;
+                    }
+                    const bool bad = poison && !(a.spin_limit == 0u && first + (unsigned)lane == 0u);      // (injection: tile 0 keeps its row)
+                    if ((unsigned)lane < nr)
+                        st_state(&a.pref[first + (unsigned)lane], itag | (bad ? POISON : 0ull) | ((unsigned long long)(running + (long long)(incl - val)) & VAL_MASK));
+                    running += (long long)(unsigned)__shfl((int)incl, (int)nr - 1);
+                    got += nr;
+                }
+                more = nr == cnt && cnt == 64u;
+            }
+        }
+        f += got;
+        if (got) { spins = 0; continue; }
+        if (++spins > limit) {                        // a tile never published its count: everything from here on is unknown
+            poison = true;
+            for (unsigned i = f + (unsigned)lane; i < T; i += 64u) st_state(&a.pref[i], itag | POISON);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(DD_LB_SLEEP);
+    }
+    if (poison && lane == 0) atomicExch(&a.hdr->error, 1);
+    // the end of the call: nobody reads the cursor or the epoch any more (every tile has published its count with this epoch's tag);
+    // when the epoch wraps, every word of the workspace is zeroed first -- once every tile has READ its row (tiles count themselves done)
+    if (epoch == EPOCH_MAX) {
+        unsigned patience = 0;
+        while (__hip_atomic_load(&a.hdr->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < T && ++patience < (1u << 24)) __builtin_amdgcn_s_sleep(8);
+        for (unsigned long long i = (unsigned long long)lane; i < a.ws_words; i += 64ull) a.gran[i] = 0ull;
+        if (lane == 0) a.hdr->done = 0u;
+    }
+    if (lane == 0) {
+        a.view_offsets[a.V] = poison ? -1ll : running;
+        close_call(a.hdr, a.cursor_out, poison ? POISON_ROW : running, epoch);
+    }
+}
+// a tile's side of it: wave 0 polls the tile's own word (all lanes the same address: one request)
+__device__ __forceinline__ long long service_row(const KArgs &a, const unsigned t, const unsigned epoch, const int lane) {
+    const unsigned tag_i = TAG_INCL | epoch;
+    const unsigned limit = a.spin_limit ? a.spin_limit : SPIN_LIMIT;
+    unsigned spins = 0;
+    unsigned long long g;
+    for (;;) {
+        g = ld_state(&a.pref[t]);
+        if ((unsigned)(g >> EPOCH_SHIFT) == tag_i) break;
+        if (++spins > limit) {                        // the service never answered (its workgroup was parked for ~2 s)
+            if (lane == 0) atomicExch(&a.hdr->error, 1);
+            g = POISON;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(DD_LB_SLEEP);
+    }
+    if (epoch == EPOCH_MAX && lane == 0) __hip_atomic_fetch_add(&a.hdr->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (g & POISON) ? -1ll : (long long)(g & VAL_MASK);
 }
 
 // Look-back over tile aggregates of at most 14 bits (tiles of <= 12288 pixels).  Measured on MI355X in rounds 1-4: a poll costs per
@@ -1032,6 +1138,13 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
             __syncthreads();
             t = __builtin_amdgcn_readfirstlane(s_ticket);
         }
+        if (a.scan_service) {                  // the launch has one workgroup more than tiles: the first one is the scan service
+            if (t == 0u) {
+                if (wave == 0) scan_service(a, epoch, base, lane);
+                return;
+            }
+            t -= 1u;
+        }
         if (t >= a.num_tiles) return;          // (never: the grid is num_tiles workgroups)
     } else {
 #if DD_XCD_SWIZZLE
@@ -1178,6 +1291,14 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
         // (fault injection, tuning bit 64: spin_limit is 0 -- a tile that would have to wait gives up at once -- and every eighth
         // tile behaves as if it had.  A tile whose look-back gave up, or that read the row of one that did, gets -1: it writes
         // nothing, so the rows of everything that was appended BEFORE stay intact, and its successors learn the same from its granule)
+        if (a.scan_service) {                  // the tile's row comes from the service workgroup, which also closes the call
+            const long long e = service_row(a, t, epoch, lane);
+            if (lane == 0) {
+                s_excl = e;
+                if (tv == 0) a.view_offsets[v] = e;
+            }
+            return;
+        }
         const long long e = lookback13(a.gran, t, n, base, lane, &a.hdr->error, a.spin_limit, epoch, (int)a.lb_lanes,
                                        a.spin_limit == 0u && (t & 7u) == 1u);
         if (lane == 0) {
@@ -1688,19 +1809,25 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
     a.spin_limit = (b->tuning & 64u) ? 0u : SPIN_LIMIT;   // tuning bit 64: fault injection -- a tile that would have to wait for a
                                                           // predecessor gives up at once, and every eighth tile behaves as if it had:
                                                           // wrong rows, the workspace's error word set (tests of the caller's recovery)
-    // the lean single-pass kernel's tile goes by the size of the batch (round 5).  A batch that fills the chip several times over:
-    // 16 pixels per lane, 12288-pixel tiles drawn by ticket (the steady state of DESIGN.md section 4).  A streamed view or a few
-    // (scripts/test.py:131 densifies one view per loop iteration): 8 pixels per lane, 6144-pixel tiles taken by workgroup index
-    // (the workgroups of one XCD are dispatched in index order, so a tile's predecessors are never behind it in a dispatcher's
-    // queue; the ticket counter is one address that every workgroup of the launch hits at once), rows written past the L2.
-    // tuning bits 18-19: 1 / 3 force the small / large tile; bits 20-21: 1 / 2 / 3 = 16 / 32 / 64 polling lanes in the look-back
-    // (default 16: measured best at every batch size, profiles/r05_streaming_*.txt); bit 22: tiles by workgroup index.
+    // The lean single-pass kernel (round 5).  The tiles' first rows come from the scan service: one workgroup of the launch -- the one
+    // that draws ticket 0 -- scans the counts, every tile polls its own row (scan_service).  Tiles are drawn by TICKET, so a tile only
+    // ever waits for workgroups that are running: safe whatever else shares the GPU.  (tuning bit 22 takes tiles by workgroup index
+    // instead -- the ticket counter is one address that every workgroup of the launch hits: 2.5 % on 185 x 1080p -- but then a
+    // resident tile can wait for a workgroup that has no slot yet, and two such launches on one GPU, two processes or two streams,
+    // can hold each other's slots until the spin limit ends it: three ranks sharing a box's GPU did exactly that.)
+    // tuning bit 26 = the decoupled look-back of rounds 1-4 instead of the service (bits 20-21: 2 / 3 = 32 / 64 polling lanes instead
+    // of 16).  The tile goes by the size of the batch: 16 pixels per lane, 12288-pixel tiles -- or, for a streamed view or a few
+    // (scripts/test.py:131 densifies one view per loop iteration: the launch does not fill the chip and a tile's lifetime IS the
+    // kernel's), 8 pixels per lane, 6144-pixel tiles, rows written past the L2.  tuning bits 18-19: 1 / 3 force the small / the large
+    // tile.  profiles/r05_ab_scan_service*.txt (service + workgroup index against the look-back of round 4): 1.02-1.03x on 185 x 1080p,
+    // 1.06x on a per-pixel confidence cull, 1.09x on 100 x 12 MP, 1.05-1.2x on 8 views, 1.14x on one.
     {
         const unsigned long long big_tiles = (unsigned long long)((a.P + SP_WAVES * L_WSPAN - 1) / (SP_WAVES * L_WSPAN)) * (unsigned)a.V;
         const unsigned tsel = (b->tuning >> 18) & 3u, wsel = (b->tuning >> 20) & 3u;
         const bool small = (tsel == 1u || (tsel == 0u && big_tiles <= SP_SMALL_BATCH_TILES)) && !p.refine;
         p.sp_pxt = small ? SP_PXT_SMALL : L_PXT;
-        a.static_tiles = ((b->tuning >> 22) & 1u) || (small && tsel == 0u);
+        a.scan_service = p.lean && ((b->tuning >> 26) & 1u) == 0u;
+        a.static_tiles = (int)((b->tuning >> 22) & 1u);
         a.lb_lanes = wsel == 2u ? 32u : wsel == 3u ? 64u : (unsigned)LB_LANES;
     }
     p.tile = p.lean ? L_TILE : G_TILE;      // tiling of the two-pass kernels (count / plan / scatter); the finest single-pass tiling is the same
@@ -1711,9 +1838,10 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
     return DD_OK;
 }
 
-// workspace: [WsHeader: 16 B sticky + 48 B single-pass state][8 B per tile of the FINEST tiling, padded to 16: look-back granules][8 B per tile: count, first row][8 B per view]
+// workspace: [WsHeader: 16 B sticky + 48 B single-pass state][8 B per tile of the FINEST tiling, padded to 16: look-back granules][the same again: the
+// tiles' first rows from the scan service][8 B per tile: count, first row][8 B per view]
 int64_t ws_bytes(const KArgs &a) {
-    return (int64_t)sizeof(WsHeader) + (((int64_t)a.num_tiles * 8 + 15) & ~(int64_t)15) + (int64_t)a.num_tiles * 8 + (int64_t)a.V * 8;
+    return (int64_t)sizeof(WsHeader) + 2 * (((int64_t)a.num_tiles * 8 + 15) & ~(int64_t)15) + (int64_t)a.num_tiles * 8 + (int64_t)a.V * 8;
 }
 
 int bind_workspace(KArgs &a, void *workspace, int64_t workspace_bytes) {
@@ -1723,8 +1851,9 @@ int bind_workspace(KArgs &a, void *workspace, int64_t workspace_bytes) {
     a.hdr = reinterpret_cast<WsHeader *>(w);
     const size_t gran_bytes = ((size_t)a.num_tiles * 8 + 15) & ~(size_t)15;
     a.gran = reinterpret_cast<unsigned long long *>(w + sizeof(WsHeader));
-    a.tiles = reinterpret_cast<TileCO *>(w + sizeof(WsHeader) + gran_bytes);
-    a.view_tot = reinterpret_cast<long long *>(w + sizeof(WsHeader) + gran_bytes + (size_t)a.num_tiles * 8);
+    a.pref = reinterpret_cast<unsigned long long *>(w + sizeof(WsHeader) + gran_bytes);
+    a.tiles = reinterpret_cast<TileCO *>(w + sizeof(WsHeader) + 2 * gran_bytes);
+    a.view_tot = reinterpret_cast<long long *>(w + sizeof(WsHeader) + 2 * gran_bytes + (size_t)a.num_tiles * 8);
     a.ws_words = (unsigned long long)((workspace_bytes - (int64_t)sizeof(WsHeader)) / 8);   // all of it: what other calls left behind, too
     return DD_OK;
 }
@@ -1746,7 +1875,7 @@ int bind_output(KArgs &a, const DDViewBatch *batch, const DDCloudOut *out) {
 template <typename DepthT, bool SP, bool HM, bool HN, int NW, int PXT>
 void launch_lean4(const KArgs &a, hipStream_t s) {
     const unsigned K = SP ? 1u : a.order_regions;
-    const dim3 grid(K * ((a.num_tiles + K - 1u) / K)), block(64 * NW);
+    const dim3 grid(K * ((a.num_tiles + K - 1u) / K) + (SP && a.scan_service ? 1u : 0u)), block(64 * NW);
     if (a.rgb && (a.out_rgb || a.out_packed)) hipLaunchKernelGGL((compact_lean<DepthT, HM, SP, HN, true, NW, false, PXT>), grid, block, 0, s, a);   // colours gathered
     else hipLaunchKernelGGL((compact_lean<DepthT, HM, SP, HN, false, NW, false, PXT>), grid, block, 0, s, a);
 }
@@ -1773,7 +1902,7 @@ void launch_lean(const KArgs &a, hipStream_t s, int sp_pxt) {
 }
 
 void launch_refine(const KArgs &a, hipStream_t s) {
-    const dim3 grid(a.num_tiles), block(64 * SP_WAVES);
+    const dim3 grid(a.num_tiles + (a.scan_service ? 1u : 0u)), block(64 * SP_WAVES);
     const bool hn = a.out_normal != nullptr, hc = a.rgb && (a.out_rgb || a.out_packed);
     if (hn && hc) hipLaunchKernelGGL((compact_lean<float, false, true, true, true, SP_WAVES, true>), grid, block, 0, s, a);
     else if (hn) hipLaunchKernelGGL((compact_lean<float, false, true, true, false, SP_WAVES, true>), grid, block, 0, s, a);

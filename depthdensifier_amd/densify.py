@@ -610,7 +610,7 @@ class CloudBuilder:
     def __init__(self, capacity: int, *, normals: bool = False, colors: bool = False,
                  pixel_index: bool = True, view_index: bool = False, packed: bool = False, points: bool = True,
                  buffers: Optional[dict] = None, start=None, device=None, placement: Optional[str] = None,
-                 guess_policy: Optional[GuessPolicy] = None):
+                 guess_policy: Optional[GuessPolicy] = None, exclusive_gpu: Optional[bool] = None):
         """``packed``: also (or, with ``points=False``, only) write the 16-byte ``x, y, z, rgba`` record per point
         (``DDCloudOut.xyz_rgba``).  ``buffers``: caller-owned tensors to write into instead of allocating, keyed like
         ``FIELDS`` -- the multi-GPU fuse hands in the GLOBAL cloud so that every point is written once, at its final
@@ -620,7 +620,12 @@ class CloudBuilder:
         address ranges whatever the size, so that points and normals -- written in lock step -- never share a class
         (``placement.place_outputs``; ``self.placement`` reports what was done); ``"first"`` takes the arrays as the
         allocator returns them.  ``guess_policy``: the score of the "no holes" guesses (``fuse_tuning``) this cloud shares with the
-        caller's other clouds; default: one of its own.
+        caller's other clouds; default: one of its own.  ``exclusive_gpu``: this process's densify stream has the GPU to itself (one
+        process per GPU, the deployment of ``scripts/run_batch.py`` under ``torchrun``; default: the environment's ``DD_EXCLUSIVE_GPU``
+        = 1, else False).  The single-pass kernel then takes its tiles by workgroup index instead of drawing tickets from one
+        contended counter (``DDViewBatch.tuning`` bit 22): 2-8 % faster -- but on a GPU that another launch of the kind shares
+        (a second process, a second stream) two launches can hold each other's slots until a spin limit ends it and the batches
+        are redone, so it is never assumed.
 
         The builder keeps the batches it is given (and with them their maps) until the next ``check()`` / ``finish()`` /
         ``reset()`` so that it can redo them if an in-kernel scan gives up (``self.healed``); it stops keeping them once they
@@ -678,6 +683,8 @@ class CloudBuilder:
         self._guesses_pending = 0
         self._appends = 0                            # append() calls since the last reset(): what a PendingCheck covers
         self.guess_policy = guess_policy if guess_policy is not None else GuessPolicy()
+        import os
+        self.exclusive_gpu = (os.environ.get("DD_EXCLUSIVE_GPU", "0") == "1") if exclusive_gpu is None else bool(exclusive_gpu)
         self.speculate_dense = True                  # fuse_tuning may run unmasked batches of a blocked cloud without the counting pass
         self.dense_misses = 0                        # ... until one of them was not dense (then never again on this cloud)
 
@@ -790,6 +797,8 @@ class CloudBuilder:
           the same scatter against a count-free plan (bit 17: every pixel guessed valid, every tile verified by the scatter; a miss
           is redone by ``check()`` / ``finish()`` like a scan that gave up, once -- then this cloud stops guessing)."""
         t = batch.tuning
+        if self.exclusive_gpu and not (t & (1 | 4)):
+            t |= _lib.DD_TUNE_BY_INDEX       # (the fused refine stage and an explicit single pass included)
         if (t & (1 | 4 | 8 | 0x3F00 | _lib.DD_TUNE_ASSUME_DENSE)) or batch.stride != 1 or batch._knots is not None:
             return t
         blocked = (self.placement is not None and self.placement.layout == "blocked"
@@ -798,6 +807,9 @@ class CloudBuilder:
                  and self.guess_policy.allows() and batch.max_points >= self.GUESS_MIN_PIXELS
                  and self.capacity >= batch.max_points        # (a cloud sized below the pixel count says the maps have holes)
                  and self._will_retain(batch))                # (a guess that misses is redone from the batch: only if it will be held)
+        if self.normal is None and self.packed is None and not batch.rotate_normals:
+            t |= 128        # a cloud of points (and colours): tiles whose pixels all survive take the list-free path -- 1.5 % on 100 x 12 MP now
+                            # that the single pass no longer waits for a look-back (profiles/r05_ab_scan_service_3.txt); nothing with normals
         if blocked or guess:
             # (+ bit 128: dense tiles take the list-free path -- in the scatter pass, which waits for no look-back, its smaller
             # instruction count is worth 0.3-1.3 %; in the single-pass kernel it is not)

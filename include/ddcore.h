@@ -110,12 +110,13 @@ typedef struct DDViewBatch {
                                  verifies every tile; a tile that finds an invalid pixel sets the workspace's error word to 2
                                  and the batch's rows, offsets and cursor are void: redo it with tuning = 4 (what CloudBuilder
                                  does by itself).  Ignored with tuning 8, DD_REFINE and on strided maps;
-                                 bits 18-19 (ABI 11) = geometry of the single-pass kernel on stride-1 maps: 0 = by the size of the
-                                 batch (up to 2048 tiles of 12288 pixels -- a streamed view or a dozen, scripts/test.py:131 -- 8 pixels
-                                 per lane, 6144-pixel tiles taken by workgroup index, rows written past the L2; above, 16 pixels per
-                                 lane, 12288-pixel tiles drawn by ticket), 1 / 3 = force the small / the large tile; bits 20-21 =
-                                 polling lanes of the look-back: 0 / 1 = 16, 2 = 32, 3 = 64; bit 22 = tiles by workgroup index.
-                                 Same rows whatever these say */
+                                 bits 18-19 (ABI 11) = tile of the single-pass kernel on stride-1 maps: 0 = by the size of the batch
+                                 (up to 3072 tiles of 12288 pixels -- a streamed view or a dozen, scripts/test.py:131 -- 8 pixels per lane,
+                                 6144-pixel tiles, rows written past the L2; above, 16 pixels per lane, 12288-pixel tiles), 1 / 3 =
+                                 force the small / the large tile; bit 26 = the decoupled look-back of ABI <= 10 instead of the scan
+                                 service (one workgroup of the launch scans the tiles' counts, a tile polls its own first row), with
+                                 bits 20-21 = its polling lanes (0 / 1 = 16, 2 = 32, 3 = 64) and bit 22 = tiles by workgroup index
+                                 instead of by ticket.  Same rows whatever these say */
     float *refined_out;       /* DD_REFINE: NULL, or (V,H,W) float32 receiving the refined, mask-zeroed depth -- the map the
                                  reference caches for the multi-view filter (scripts/test.py:194, 197-201) */
 } DDViewBatch;

@@ -274,8 +274,9 @@ def test_a_blocked_cloud_of_points_is_filled_in_thirds(dd):
         assert b.placement.layout == "blocked", b.placement.as_dict()
         tun = b.fuse_tuning(masked)
         assert tun & 4 and not tun & ASSUME and tun & DENSE and (tun >> 8) & 63 == K1
-        assert b.fuse_tuning(dd.ViewBatch(depth[:1], params[:1], E[:1])) == 0                 # a small batch (2 M pixels): the fused single pass
-        assert b.fuse_tuning(dd.ViewBatch(depth[:4], params[:4], E[:4], mask=mask[:4])) == 0  # a masked batch below half the threshold: too
+        # (bit 128 -- dense tiles without a list -- is set for every batch into a cloud of points only since round 5)
+        assert b.fuse_tuning(dd.ViewBatch(depth[:1], params[:1], E[:1])) == DENSE             # a small batch (2 M pixels): the fused single pass
+        assert b.fuse_tuning(dd.ViewBatch(depth[:4], params[:4], E[:4], mask=mask[:4])) == DENSE  # a masked batch below half the threshold: too
         assert b.fuse_tuning(dd.ViewBatch(depth, params, E, tuning=8)) == 8                   # an explicit choice stands
         b.append(masked)
         got_masked = b.finish()
@@ -305,7 +306,7 @@ def test_a_blocked_cloud_of_points_is_filled_in_thirds(dd):
         assert dd.CloudBuilder(dense.max_points, pixel_index=False, placement="first").fuse_tuning(dense) & ASSUME
         # plainly allocated arrays guess too (an unmasked batch, no normals), and run masked batches in the single pass
         plain = dd.CloudBuilder(holed.max_points, pixel_index=False, placement="first")
-        assert plain.fuse_tuning(holed) & ASSUME and not plain.fuse_tuning(holed) & 4 and plain.fuse_tuning(masked) == 0
+        assert plain.fuse_tuning(holed) & ASSUME and not plain.fuse_tuning(holed) & 4 and plain.fuse_tuning(masked) == DENSE
     finally:
         dd.CloudBuilder.INTERLEAVE_MIN_ROWS = old
     # the references: the single pass, asked for explicitly

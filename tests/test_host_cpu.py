@@ -106,8 +106,9 @@ def test_workspace_size_and_null_outputs(libmod):
     b = _batch(libmod, height=1080, width=1920, num_views=3)
     n = libmod.lib.dd_workspace_bytes(C.byref(b))
     tiles = -(-1080 * 1920 // 4096) * 3
-    # 16 B sticky + 48 B single-pass state, look-back granules (8 B per tile, padded to 16), count + first row (8 B per tile), 8 B per view
-    assert n == 64 + (8 * tiles + 15) // 16 * 16 + 8 * tiles + 8 * 3
+    # 16 B sticky + 48 B single-pass state, look-back granules (8 B per tile, padded to 16), the tiles' first rows from the scan service
+    # (the same again), count + first row for the two-pass kernels (8 B per tile), 8 B per view
+    assert n == 64 + 2 * ((8 * tiles + 15) // 16 * 16) + 8 * tiles + 8 * 3
     out = libmod.DDCloudOut(capacity=10)
     assert libmod.lib.dd_unproject_compact(C.byref(b), C.byref(out), None, None, None, 0, None) == -1
     assert "xyz" in libmod.lib.dd_last_error().decode()

@@ -11,6 +11,8 @@ pytestmark = pytest.mark.gpu
 EPOCH_MAX = (1 << 18) - 1
 T_SMALL, T_LARGE, STATIC = 1 << 18, 3 << 18, 1 << 22
 W32, W64 = 2 << 20, 3 << 20
+CLASSIC = 1 << 26          # the decoupled look-back of rounds 1-4 (default since round 5: the scan service -- one workgroup of the launch
+                           # scans the tiles' counts, the tiles poll their own row)
 
 
 @pytest.fixture(scope="module")
@@ -66,7 +68,7 @@ def _equal(a, b):
 
 
 @pytest.mark.parametrize("dtype", (np.float32, np.float16))
-@pytest.mark.parametrize("shape", [(3, 67, 129), (2, 128, 256), (1, 255, 257), (2, 200, 331), (9, 96, 172)])
+@pytest.mark.parametrize("shape", [(3, 67, 129), (2, 128, 256), (1, 255, 257), (2, 200, 331), (9, 96, 172), (70, 216, 384)])
 def test_every_single_pass_geometry_writes_the_oracles_cloud(dd, orc, shape, dtype):
     """Small tile (8 pixels per lane, 6144) / large tile (16, 12288), tiles by ticket / by workgroup index, 16 / 32 / 64
     polling lanes: indices, colours and normals bit-exact against the oracle, and the rows of all variants identical."""
@@ -74,7 +76,8 @@ def test_every_single_pass_geometry_writes_the_oracles_cloud(dd, orc, shape, dty
     depth, mask, normal, rgb, params, E = _case(11 + H, V, H, W, dtype)
     ref = _oracle(orc, depth, mask, normal, rgb, params, E)
     first = None
-    for tuning in (0, T_SMALL, T_SMALL | STATIC | W64, T_LARGE, T_LARGE | STATIC, T_LARGE | W32, 8 | T_LARGE | W64):
+    for tuning in (0, T_SMALL, T_LARGE, 8 | T_LARGE, CLASSIC, CLASSIC | T_SMALL, CLASSIC | T_SMALL | STATIC | W64, CLASSIC | T_LARGE,
+                   CLASSIC | T_LARGE | STATIC, CLASSIC | T_LARGE | W32, CLASSIC | 8 | T_LARGE | W64):
         cloud = dd.unproject_views(depth, params, E, mask=mask, normal=normal, rgb=rgb, capacity="max", tuning=tuning)
         c = cloud.numpy()
         assert np.array_equal(c["view_offsets"], ref.view_offsets), tuning
@@ -112,7 +115,7 @@ def test_a_chain_of_calls_on_one_workspace_equals_one_batch(dd, orc):
     assert h == {"error": 0, "ticket": 0, "done": 0, "epoch": e0 + calls}
 
 
-@pytest.mark.parametrize("tuning", (0, T_LARGE, T_SMALL, 9))
+@pytest.mark.parametrize("tuning", (0, T_LARGE, T_SMALL, 9, CLASSIC, CLASSIC | T_LARGE, CLASSIC | T_SMALL))
 def test_the_epoch_wraps_without_a_trace(dd, tuning):
     """The call in which the 18-bit epoch wraps zeroes every record of the workspace (so a granule of 2^18 calls ago can never
     read as this call's): forced here by setting the epoch by hand, with stale granules planted that carry the tags of the
@@ -150,7 +153,7 @@ def test_two_pass_calls_between_single_pass_calls_share_the_workspace(dd):
     b = dd.CloudBuilder(whole.max_points, normals=True, colors=True, pixel_index=True)
     b.append(whole)
     want = b.finish()
-    for order in ((0, 4, 0, 4), (4, 0, T_LARGE, 4), (T_LARGE, 4, 4, 0)):
+    for order in ((0, 4, 0, 4), (4, 0, T_LARGE, 4), (T_LARGE, 4, 4, 0), (CLASSIC, 4, 0, CLASSIC | T_LARGE)):
         b.reset()
         for i, tuning in enumerate(order):
             sub = whole.slice(2 * i, 2 * i + 2)
@@ -159,7 +162,8 @@ def test_two_pass_calls_between_single_pass_calls_share_the_workspace(dd):
         _equal(b.finish(), want)
 
 
-def test_appends_after_a_healed_give_up_start_from_a_clean_workspace(dd):
+@pytest.mark.parametrize("how", (0, CLASSIC))
+def test_appends_after_a_healed_give_up_start_from_a_clean_workspace(dd, how):
     """A look-back that gives up (fault injection, tuning 64) writes nothing it does not know the place of -- the rows of the
     batches before it stay intact -- and the redo zeroes the whole workspace, so the single-pass calls after it run as on a new one."""
     V, H, W = 8, 96, 160
@@ -172,7 +176,7 @@ def test_appends_after_a_healed_give_up_start_from_a_clean_workspace(dd):
     b.append(whole.slice(0, 2))
     n2 = b.check()
     bad = whole.slice(2, 4)
-    bad.tuning = 64
+    bad.tuning = 64 | how
     b.append(bad)
     # the sabotaged call has not touched a row of the first batch
     import torch

@@ -8,7 +8,7 @@ For every k and every variant: the whole chain of ceil(V / k) dd_unproject_compa
 HBM), three ways -- CloudBuilder.append (the product's host path), the bare C-ABI call with structs built beforehand (what
 the host path costs on top), and the same chain replayed from a captured HIP graph.  A variant is a DDViewBatch.tuning word:
 tN = bits 18-19 (1 small tile, 3 large tile), wN = bits 20-21 (1 / 2 / 3 = 16 / 32 / 64 polling lanes), s1 = bit 22 (tiles by
-workgroup index, no tickets), pN = plain tuning N.  --libs tag:-Dflag,-Dflag ...: experiment builds of csrc/ddcore.hip
+workgroup index, no tickets), c1 = bit 26 (the decoupled look-back instead of the scan service), pN = plain tuning N.  --libs tag:-Dflag,-Dflag ...: experiment builds of csrc/ddcore.hip
 (tools/ab_builds.py builds them), timed through the bare C-ABI call beside the product library.
 """
 import argparse
@@ -38,7 +38,7 @@ def tuning_of(tag: str) -> int:
         while j < len(tag) and tag[j].isdigit():
             j += 1
         n = int(tag[i + 1:j])
-        t |= (n << 18) if c == "t" else (n << 20) if c == "w" else (n << 22) if c == "s" else n
+        t |= (n << 18) if c == "t" else (n << 20) if c == "w" else (n << 22) if c == "s" else (n << 26) if c == "c" else n
         i = j
     return t
 
