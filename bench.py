@@ -1071,6 +1071,8 @@ def main() -> None:
         st["builder"] = None
         if reuse is None:
             st.clear()
+        import gc
+        gc.collect()                     # (the main cloud -- 112 GB of arena memory on the default workload -- goes back to the driver NOW)
         torch.cuda.empty_cache()
 
         def bail():
@@ -1102,6 +1104,9 @@ def main() -> None:
     import gc
     gc.collect()
     torch.cuda.empty_cache()
+    if torch.cuda.is_available() and world == 1:
+        from depthdensifier_amd import placement as _pl0
+        _pl0.trim(device)                # spare chunks of the arena go back too: the sub-records start from an empty device
 
     # the other single-GPU configurations of BASELINE.json as sub-records of the default line (N = 1 only: every one of them is a
     # one-GPU workload; the driver's N > 1 runs measure the scaling curve of the main workload)
