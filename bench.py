@@ -685,6 +685,15 @@ def main() -> None:
     import depthdensifier_amd as dd
     from depthdensifier_amd import distributed as D
 
+    # under rocprofv3 a physical allocation of the virtual-memory API that is released does not come back to the device: the arena
+    # keeps every chunk it is given back in its pool instead (the next workload's cloud is built from them), and the fresh-allocation
+    # rounds -- which release and scout anew by design -- are left out (roofline.frac_min / median / max absent in a profiled run)
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+    if profiled and args.placement == "probed":
+        from depthdensifier_amd import placement as _plp
+        _plp.keep_everything(device)
+        args.alloc_rounds = 0
+
     def fence():
         torch.cuda.synchronize(device)
         if use_dist:
@@ -1104,7 +1113,7 @@ def main() -> None:
     import gc
     gc.collect()
     torch.cuda.empty_cache()
-    if torch.cuda.is_available() and world == 1:
+    if torch.cuda.is_available() and world == 1 and not profiled:
         from depthdensifier_amd import placement as _pl0
         _pl0.trim(device)                # spare chunks of the arena go back too: the sub-records start from an empty device
 
@@ -1120,7 +1129,8 @@ def main() -> None:
             continue
         try:
             from depthdensifier_amd import placement as _pl
-            _pl.trim(device)
+            if not profiled:
+                _pl.trim(device)
             torch.cuda.empty_cache()
             v_sub = min(args.views, WORKLOADS[name]["V"]) if args.views else 0
             sub_line, sst = run_workload(name, args.sub_steps, 3, min(args.alloc_rounds, 3), v_sub, 0.0)

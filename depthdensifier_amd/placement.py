@@ -190,6 +190,14 @@ def get_arena(device) -> ZoneArena:
         return a
 
 
+def keep_everything(device) -> None:
+    """From now on the device's arena gives NO chunk back to the driver: freed chunks stay in its pool, classified, and serve the next
+    request.  For a process under ``rocprofv3``: with the profiler loaded ``hipMemRelease`` does not return the memory to the device
+    (measured: ``tools/arena_free_probe.py``, ``profiles/r05_arena_free_under_rocprofv3.txt``), so a chunk that is released is lost
+    until the process ends, while a pooled one is used again."""
+    get_arena(device).trim(1 << 20)
+
+
 def trim(device=None) -> None:
     """Give the spare chunks of the device's arena (if one exists) back to the driver, e.g. before a large plain allocation."""
     with _arenas_lock:
