@@ -1833,7 +1833,7 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
     p.tile = p.lean ? L_TILE : G_TILE;      // tiling of the two-pass kernels (count / plan / scatter); the finest single-pass tiling is the same
     a.tiles_per_view = (a.P + p.tile - 1) / p.tile;
     const unsigned long long nt = (unsigned long long)a.tiles_per_view * (unsigned)a.V;
-    if (nt >= (1ull << 31)) return fail(DD_ERR_UNSUPPORTED, "too many tiles in one batch; split the batch");
+    if (nt >= (1ull << 31) - 1ull) return fail(DD_ERR_UNSUPPORTED, "too many tiles in one batch; split the batch");      // (+ 1 workgroup: the scan service)
     a.num_tiles = (unsigned)nt;
     return DD_OK;
 }

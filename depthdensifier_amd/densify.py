@@ -926,6 +926,10 @@ class CloudBuilder:
             finally:
                 batch.tuning = saved
         self.healed += 1
+        if not dense_miss and self.exclusive_gpu:
+            # a scan that timed out while tiles were taken by workgroup index: the GPU was not this stream's alone after all (two
+            # launches holding each other's workgroup slots is the one way that order can stall) -- tickets from here on
+            self.exclusive_gpu = False
         if dense_miss:
             self.dense_misses += 1                           # this cloud stops guessing (fuse_tuning)
             if self._guesses_pending:                        # (the policy's guess, not a bit the caller set)

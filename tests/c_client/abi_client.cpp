@@ -98,7 +98,9 @@ int main() {
     // mode 2 writes into arrays handed out by the HBM zone arena (dd_arena_*): ordinary device pointers for every entry point
     DDArena *arena = NULL;
     void *aptr[3] = {NULL, NULL, NULL};
-    for (int mode = 0; mode < 3; ++mode) {       // 0: dd_plan + dd_scatter, 1: fused dd_unproject_compact, 2: fused, into arena arrays
+    for (int mode = 0; mode < 4; ++mode) {       // 0: dd_plan + dd_scatter, 1: fused dd_unproject_compact, 2: fused, into arena arrays,
+                                                 // 3: the reference's loop (scripts/test.py:131): ONE VIEW PER CALL, chained through one
+                                                 //    cursor and one workspace that is never zeroed again (ABI 11: a call is one kernel launch)
         if (mode == 2) {
             if (dd_arena_create(0, 0, &arena) != DD_OK) { printf("dd_arena_create: %s\n", dd_arena_last_error()); return 6; }
             const int64_t sizes[3] = {(int64_t)N * 12, (int64_t)N * 12, (int64_t)N * 3};
@@ -116,6 +118,24 @@ int main() {
         if (mode == 0) {
             DD(dd_plan(&b, (const int64_t *)d_cur, (int64_t *)d_off, d_ws, wsb, stream));
             DD(dd_scatter(&b, &out, (const int64_t *)d_off, d_ws, wsb, stream));
+        } else if (mode == 3) {
+            for (int rep = 0; rep < 3; ++rep) {          // three scans back to back: 3 V calls on the same workspace
+                CK(hipMemsetAsync(d_cur, 0, 8, stream));
+                for (int v = 0; v < V; ++v) {
+                    DDViewBatch one = b;
+                    one.num_views = 1; one.view_index_base = v;
+                    one.depth = (const char *)d_depth + (size_t)v * P * 4; one.mask = (const uint8_t *)d_mask + (size_t)v * P;
+                    one.normal = (const float *)d_normal + (size_t)v * P * 3; one.rgb = (const uint8_t *)d_rgb + (size_t)v * P * 3;
+                    one.params = (const DDViewParams *)d_params + v;
+                    // a view's two offsets land in d_off[v], d_off[v + 1]: the next call rewrites d_off[v + 1] with the same row
+                    DD(dd_unproject_compact(&one, &out, (int64_t *)d_off + v, (int64_t *)d_cur, d_ws, wsb, stream));
+                }
+            }
+            CK(hipStreamSynchronize(stream));
+            int32_t hdr[16]; CK(hipMemcpy(hdr, d_ws, 64, hipMemcpyDeviceToHost));
+            if (hdr[1] != 0 || hdr[4] != 0) { printf("mode 3: workspace header after the chain: error %d, ticket %d\n", hdr[1], hdr[4]); return 4; }
+            int64_t cur; CK(hipMemcpy(&cur, d_cur, 8, hipMemcpyDeviceToHost));
+            if (cur != n_ref) { printf("mode 3: cursor %lld != %lld\n", (long long)cur, (long long)n_ref); return 4; }
         } else {
             DD(dd_unproject_compact(&b, &out, (int64_t *)d_off, (int64_t *)d_cur, d_ws, wsb, stream));
         }
