@@ -17,6 +17,9 @@ for tag in $TAGS; do
     mip360conf_smooth) ARGS="--workload mip360conf --conf-kind smooth" ;;
     *) ARGS="--workload $tag" ;;
   esac
+  case $tag in      # (the streaming chains of garden185 are hundreds of small launches of the same kernel: they would be averaged into its counters)
+    garden185|bernoulli) ARGS="$ARGS --streaming=" ;;
+  esac
   D="$OUT/$tag"; mkdir -p "$D"
   python3 "$R/bench.py" $ARGS --cpu-seconds 0 --strong-views 0 > "$D/bench.json" 2> "$D/bench.err" || { echo "$tag: bench failed"; exit 1; }
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/stats" -- \
