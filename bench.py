@@ -429,6 +429,7 @@ def streaming_record(args, dd, cfg, scene, params, E, batch, builder, device, vi
             builder.reset()
             for sb in subs:
                 builder.append(sb)
+            builder.join()                  # (small appends run on the builder's side streams: the event behind the chain must see them)
 
         chain(); builder.check()
         ts, hs = [], []

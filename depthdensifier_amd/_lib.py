@@ -21,7 +21,7 @@ import torch  # noqa: F401  (load order, see above)
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("DDCORE_LIB", _HERE / "libddcore.so"))
 
-DD_ABI_VERSION = 11
+DD_ABI_VERSION = 12
 DD_OK = 0
 DD_F32, DD_F16 = 0, 1
 DD_VALID_DEPTH_POSITIVE = 0x1
@@ -39,6 +39,7 @@ EXPORTS = (
     "dd_plan",
     "dd_scatter",
     "dd_unproject_compact",
+    "dd_stream_fork",
     "dd_floater_votes",
     "dd_filter_last_error",
     "dd_votes_workspace_bytes",
@@ -83,6 +84,8 @@ class DDViewBatch(C.Structure):
         ("view_index_base", C.c_int32),
         ("tuning", C.c_uint32),
         ("refined_out", C.c_void_p),
+        ("chain", C.c_void_p),
+        ("chain_seq", C.c_int64),
     ]
 
 
@@ -171,6 +174,8 @@ def _load() -> C.CDLL:
     lib.dd_unproject_compact.argtypes = [
         C.POINTER(DDViewBatch), C.POINTER(DDCloudOut), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
     ]
+    lib.dd_stream_fork.restype = C.c_int
+    lib.dd_stream_fork.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.dd_floater_votes.restype = C.c_int
     lib.dd_floater_votes.argtypes = [C.POINTER(DDFilterViews), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]
     lib.dd_votes_workspace_bytes.restype = C.c_int64

@@ -45,6 +45,8 @@ constexpr unsigned long long ST_INCL = 2ull << 62;  // value = slot after the ti
 constexpr unsigned long long POISON = 1ull << (EPOCH_SHIFT - 1);      // inclusive granule of a tile that does not know its first row (a look-back
                                                                       // gave up somewhere before it): whoever reads it does not know its own either
 constexpr unsigned long long VAL_MASK = POISON - 1;                   // rows below 2^43
+constexpr int CHAIN_SHIFT = 44;                   // chain word: [63:44] sequence (mod 2^20), [43:0] the row the next call starts from
+constexpr unsigned CHAIN_SEQ_MASK = (1u << 20) - 1u;
 constexpr long long POISON_ROW = 1ll << 42;   // the cursor a call leaves behind when its last tile does not know the row after the batch: beyond any
                                               // capacity, so that calls chained behind it count their points and write nothing (the error word is set)
 constexpr unsigned TAG_AGG = 1u << EPOCH_BITS, TAG_INCL = 2u << EPOCH_BITS;   // granule >> EPOCH_SHIFT == TAG_x | epoch
@@ -102,6 +104,8 @@ struct KArgs {
     unsigned long long *gran;     // look-back granules, one per tile of the single-pass tiling
     unsigned long long *pref;     // scan service: the first row of every tile, written by the service workgroup (same tags as the granules)
     int scan_service;             // single-pass lean kernel: one workgroup of the launch scans the tiles' counts, the tiles poll their own row
+    unsigned long long *chain;    // ABI 12: the word that chains this call behind the previous one of the same cloud on another stream (or NULL)
+    unsigned chain_seq;           // ... and the sequence number the word must show before this call's scan may start
     TileCO *tiles;                // two-pass: count and first row of every tile (NULL in dd_count_valid)
     unsigned long long ws_words;  // 8-byte words of the caller's workspace behind the header (what a wrap of the epoch zeroes)
     unsigned long long *counts;   // per-view counts (dd_count_valid)
@@ -664,6 +668,25 @@ __device__ __forceinline__ void scan_service(const KArgs &a, const unsigned epoc
     long long running = base;                         // first row of tile f
     unsigned spins = 0;
     bool poison = false;                              // from here on the rows are unknown (a tile never published; fault injection)
+    if (a.chain) {
+        // chained behind the previous call of this cloud, which runs on another stream and may not have finished its scan yet: the
+        // batch starts where that call says it ends.  (This call's tiles load and count meanwhile; nothing of the previous call waits
+        // for anything of this one, so waiting here cannot dead-lock as long as this launch cannot occupy every slot: ddcore.h)
+        unsigned long long w;
+        for (;;) {
+            w = ld_state(a.chain);
+            if ((unsigned)(w >> CHAIN_SHIFT) == (a.chain_seq & CHAIN_SEQ_MASK)) break;
+            if (++spins > limit) { poison = true; break; }
+            __builtin_amdgcn_s_sleep(DD_LB_SLEEP);
+        }
+        spins = 0;
+        running = (long long)(w & ((1ull << CHAIN_SHIFT) - 1ull));
+        if (running >= POISON_ROW) poison = true;     // the previous call did not know where it ended: neither does this one
+        if (poison) {
+            for (unsigned i = (unsigned)lane; i < T; i += 64u) st_state(&a.pref[i], itag | POISON);
+            f = T;
+        }
+    }
     while (f < T) {
         unsigned long long s[K];
 #pragma unroll
@@ -718,8 +741,19 @@ __device__ __forceinline__ void scan_service(const KArgs &a, const unsigned epoc
         if (lane == 0) a.hdr->done = 0u;
     }
     if (lane == 0) {
+        const long long end = poison ? POISON_ROW : running;
         a.view_offsets[a.V] = poison ? -1ll : running;
-        close_call(a.hdr, a.cursor_out, poison ? POISON_ROW : running, epoch);
+        if (a.chain) {
+            // the cursor for whoever reads it after the streams are joined -- written through, and acknowledged BEFORE the chain word
+            // releases the next call (whose own cursor store must not be overtaken by this one) ...
+            __hip_atomic_store(a.cursor_out, end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            a.hdr->ticket = 0u;
+            a.hdr->epoch = epoch == EPOCH_MAX ? 0u : epoch + 1u;
+            st_state(a.chain, ((unsigned long long)((a.chain_seq + 1u) & CHAIN_SEQ_MASK) << CHAIN_SHIFT) | (unsigned long long)end);
+        } else {
+            close_call(a.hdr, a.cursor_out, end, epoch);
+        }
     }
 }
 // a tile's side of it: wave 0 polls the tile's own word (all lanes the same address: one request)
@@ -1545,6 +1579,19 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
     STAMP_END();
 }
 
+// ---- the gate of a chained call that is too large to wait inside its own workgroups (DDViewBatch.chain): ONE wave, in front of the
+// call on the call's stream, returns when the previous call of the cloud -- on the other stream -- has finished its SCAN.  The call's
+// kernel then starts beside the previous call's last tiles (which are still writing rows) instead of behind them, and none of its
+// workgroups ever holds a slot while it waits for another launch.  (Gives up after ~2 s like every wait here; the call's own scan
+// then waits once more, and poisons the call if the word still does not come.) ----
+__global__ __launch_bounds__(64) void chain_gate(const unsigned long long *chain, const unsigned seq) {
+    unsigned spins = 0;
+    while ((unsigned)(__hip_atomic_load(chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> CHAIN_SHIFT) != (seq & CHAIN_SEQ_MASK)) {
+        if (++spins > SPIN_LIMIT) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
 // ---- the count-free plan (tuning bit 17): every visited pixel taken as valid -- tile t of a view starts tv * tile rows
 // into the view, view v starts v * P rows behind the cursor.  The scatter pass verifies it (assume_dense above). ----
 __global__ __launch_bounds__(256) void plan_dense(const KArgs a, const unsigned tile) {
@@ -1741,6 +1788,7 @@ struct Plan {
     bool single;    // dd_unproject_compact runs the single-pass kernel
     int tile;
     int sp_pxt;     // lean single-pass kernel: pixels per lane (the tile is SP_WAVES * 64 * sp_pxt pixels)
+    bool chain_gate;  // a chained call too large to wait inside its own workgroups: chain_gate runs in front of it
 };
 
 int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
@@ -1829,6 +1877,18 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
         a.scan_service = p.lean && ((b->tuning >> 26) & 1u) == 0u;
         a.static_tiles = (int)((b->tuning >> 22) & 1u);
         a.lb_lanes = wsel == 2u ? 32u : wsel == 3u ? 64u : (unsigned)LB_LANES;
+        if (b->chain) {
+            // a chained call's workgroups occupy slots while its scan waits for the previous call: it must never be able to occupy
+            // all of them (512 slots of 12 waves), whatever else of this cloud is in flight -- at most 384 workgroups, the scan included
+            const unsigned long long wgs = (unsigned long long)((a.P + SP_WAVES * 64 * p.sp_pxt - 1) / (SP_WAVES * 64 * p.sp_pxt)) * (unsigned)a.V + 1ull;
+            if (!p.lean || !a.scan_service || p.refine || !p.single)
+                return fail(DD_ERR_UNSUPPORTED, "DDViewBatch.chain needs the single-pass kernel with the scan service (stride-1 maps, no DD_REFINE, tuning without 1 / 4 / bit 17 / bit 26)");
+            // a call of more than 384 workgroups gets a GATE in front of it (chain_gate): one wave that returns when the previous
+            // call's scan is over, so that this call's workgroups exist only once they have nothing to wait for
+            p.chain_gate = wgs > 384ull;
+            a.chain = reinterpret_cast<unsigned long long *>(b->chain);
+            a.chain_seq = (unsigned)(b->chain_seq & (int64_t)CHAIN_SEQ_MASK);
+        }
     }
     p.tile = p.lean ? L_TILE : G_TILE;      // tiling of the two-pass kernels (count / plan / scatter); the finest single-pass tiling is the same
     a.tiles_per_view = (a.P + p.tile - 1) / p.tile;
@@ -2021,6 +2081,13 @@ int dd_scatter(const DDViewBatch *batch, const DDCloudOut *out, const int64_t *v
     return check_launch("dd_scatter");
 }
 
+int dd_stream_fork(void *event, void *from_stream, void *to_stream) {
+    if (!event) return fail(DD_ERR_INVALID_ARG, "event is NULL");
+    if (hipEventRecord((hipEvent_t)event, (hipStream_t)from_stream) != hipSuccess) return fail(DD_ERR_LAUNCH, "hipEventRecord failed");
+    if (hipStreamWaitEvent((hipStream_t)to_stream, (hipEvent_t)event, 0) != hipSuccess) return fail(DD_ERR_LAUNCH, "hipStreamWaitEvent failed");
+    return DD_OK;
+}
+
 int dd_unproject_compact(const DDViewBatch *batch, const DDCloudOut *out, int64_t *view_offsets_dev,
                          int64_t *cursor_dev, void *workspace, int64_t workspace_bytes, void *stream) {
     KArgs a; Plan p;
@@ -2041,6 +2108,7 @@ int dd_unproject_compact(const DDViewBatch *batch, const DDCloudOut *out, int64_
         }
         // ONE stream operation: the granules are tagged with the workspace's call epoch (nothing is zeroed), and the last tile
         // to finish its look-back writes the cursor and closes the call (close_call)
+        if (p.chain_gate) hipLaunchKernelGGL(chain_gate, dim3(1), dim3(64), 0, s, a.chain, a.chain_seq);
         launch_scatter<true>(p, a, s);
         return check_launch("dd_unproject_compact");
     }

@@ -597,6 +597,10 @@ class CloudBuilder:
     # workgroups then write three classes at once -- 0.72 instead of 0.66 of the roofline on BASELINE configs[4] with the count
     # pass included, 0.815 for the scatter kernel alone (0.81 for the whole step where the count pass is guessed away: fuse_tuning).
     # Below this many rows (3 GiB of points) the count pass costs more than the interleaving wins back.
+    CHAIN_MAX_TILES = 700            # small appends up to this many 12288-pixel tiles (4 views of 1080p) are chained across the two side streams:
+                                     # 1 view per call 0.40 -> 0.60 of the roofline, 2 views 0.52 -> 0.57, 4 views 0.61 -> 0.65; from 8 views on a call's
+                                     # scan is over only ~9 us before its last rows are written and the gate in front of the next call wins nothing
+                                     # (profiles/r05_streaming_chained_two_streams.txt)
     INTERLEAVE_MIN_ROWS = 256 << 20
     GUESS_MIN_PIXELS = 4 << 20       # unmasked batches from this size on run count-free (1.41x the single pass at 24 M pixels, 1.22x at 61 M, 1.11x at
                                      # 244 M, 1.23x at 6.1 G: profiles/r04_ab_count_free_small_batches.txt); below, a launch is a few microseconds either way
@@ -685,6 +689,15 @@ class CloudBuilder:
         self.guess_policy = guess_policy if guess_policy is not None else GuessPolicy()
         import os
         self.exclusive_gpu = (os.environ.get("DD_EXCLUSIVE_GPU", "0") == "1") if exclusive_gpu is None else bool(exclusive_gpu)
+        # consecutive SMALL appends (a streamed view per call, scripts/test.py:131) chained across two side streams so that call n + 1
+        # runs beside the tail of call n (DDViewBatch.chain, include/ddcore.h): only where this stream has the GPU to itself
+        self.overlap_small = os.environ.get("DD_OVERLAP_SMALL", "1") == "1"
+        self._side: list = []                        # two side streams + their workspaces, made at the first chained append
+        self._side_ws: list = []
+        self._chain = None                           # (1,) int64 device: the chain word
+        self._chain_seq = 0
+        self._side_busy = False                      # chained calls are in flight on the side streams: join before anything else
+        self._fork_ev = None
         self.speculate_dense = True                  # fuse_tuning may run unmasked batches of a blocked cloud without the counting pass
         self.dense_misses = 0                        # ... until one of them was not dense (then never again on this cloud)
 
@@ -696,7 +709,34 @@ class CloudBuilder:
         else:
             self.cursor.fill_(int(self._start))
 
+    def join(self) -> None:
+        """Order the caller's stream behind everything appended so far (small appends may run on the builder's side streams:
+        ``exclusive_gpu``).  ``check()`` / ``finish()`` / ``reset()`` do it by themselves; a caller that reads the cloud's arrays or
+        records a timing event without them calls this first."""
+        self._join_side()
+
+    def _join_side(self) -> None:
+        """The side streams' chained calls into the caller's stream: everything enqueued from here on runs behind them."""
+        if self._side_busy:
+            cur = torch.cuda.current_stream(self.device)
+            for s in self._side:
+                cur.wait_stream(s)
+            self._side_busy = False
+
+    def _chained_ok(self, batch: "ViewBatch", tuning: int) -> bool:
+        """May this append run chained on a side stream?  A small single-pass call on a GPU this stream has to itself (the later of
+        two calls in flight occupies workgroup slots while it waits for the earlier one's scan: never more than 384 of the 512)."""
+        if not (self.exclusive_gpu and self.overlap_small) or batch.stride != 1 or batch._knots is not None:
+            return False
+        if tuning & (1 | 4 | 8 | 0x3F00 | _lib.DD_TUNE_ASSUME_DENSE | (1 << 26) | (3 << 18)):
+            return False
+        _, H, W = batch.depth.shape
+        # small calls only (a large batch fills the chip by itself and its launch latency is nothing): up to CHAIN_MAX_TILES tiles of
+        # 12288 pixels.  (Up to 383 tiles of 6144 the call waits inside its scan workgroup; above, behind a one-wave gate kernel.)
+        return batch.num_views * (-(-(H * W) // 12288)) <= self.CHAIN_MAX_TILES and H * W >= 8
+
     def reset(self) -> None:
+        self._join_side()
         self._epoch += 1
         self._appends = 0
         self._guesses_pending = 0                    # (guesses nobody looked at are neither hits nor misses)
@@ -712,7 +752,10 @@ class CloudBuilder:
         """Bytes of maps that holding ``batch`` for a redo keeps alive beyond what is held already."""
         if self._retained and self._retained[-1][0] is batch:          # the same batch again (a timing loop): nothing new is held
             return 0
-        return sum(t.numel() * t.element_size() for t in (batch.depth, batch.mask, batch.conf, batch.normal, batch.rgb) if t is not None)
+        n = getattr(batch, "_map_bytes", None)
+        if n is None:
+            n = batch._map_bytes = sum(t.numel() * t.element_size() for t in (batch.depth, batch.mask, batch.conf, batch.normal, batch.rgb) if t is not None)
+        return n
 
     def _will_retain(self, batch: "ViewBatch") -> bool:
         return self._retain_complete and self._retained_bytes + self._retain_cost(batch) <= self._retain_limit
@@ -774,11 +817,15 @@ class CloudBuilder:
             self._guesses_pending += 1                # (the policy's guess, not the caller's bit: scored when the status is read)
         try:
             cb = batch.c_struct()
-            ws = self._workspace(batch.workspace_bytes())
             out = self._out_struct()
             offsets = _offsets if redo else self._offsets_slice(batch.num_views + 1)
-            check(lib.dd_unproject_compact(C.byref(cb), C.byref(out), offsets.data_ptr(), self.cursor.data_ptr(),
-                                           ws.data_ptr(), ws.numel(), _stream(self.device)))
+            if not redo and self._chained_ok(batch, batch.tuning):
+                ws = self._append_chained(batch, cb, out, offsets)
+            else:
+                self._join_side()
+                ws = self._workspace(batch.workspace_bytes())
+                check(lib.dd_unproject_compact(C.byref(cb), C.byref(out), offsets.data_ptr(), self.cursor.data_ptr(),
+                                               ws.data_ptr(), ws.numel(), _stream(self.device)))
         finally:
             batch.tuning = saved
         if not redo:
@@ -786,6 +833,57 @@ class CloudBuilder:
             self._workspaces.append(ws)
             self._retain(batch, offsets)
         return offsets
+
+    def _append_chained(self, batch: "ViewBatch", cb, out, offsets: torch.Tensor) -> torch.Tensor:
+        """One small call on the next of two side streams, chained to the previous one through the chain word (``DDViewBatch.chain``):
+        the call's scan starts from the row the previous call ends at as soon as THAT call's scan is over -- its tiles load and count
+        meanwhile, and the previous call's last rows are still being written.  A one-view call is bound by the launch-to-launch latency
+        of a stream (4-5 us of the 25 it takes), not by its kernel: two streams take 1.5x as many calls per second
+        (``tools/experiments/two_stream_chains.py``)."""
+        need = batch.workspace_bytes()
+        if not self._side:
+            self._side = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
+            self._side_raw = [s.cuda_stream for s in self._side]
+            self._chain = torch.zeros(1, dtype=torch.int64, device=self.device)
+            self._chain_ptr = self._chain.data_ptr()
+            self._fork_ev = torch.cuda.Event()
+            self._fork_ev.record(torch.cuda.current_stream(self.device))      # (creates the underlying event)
+            self._fork_raw = self._fork_ev.cuda_event
+        if len(self._side_ws) < 2 or self._side_ws[0].numel() < need:
+            self._join_side()
+            old = self._side_ws
+            self._side_ws = [torch.zeros(max(need, 1024), dtype=torch.uint8, device=self.device) for _ in range(2)]
+            for o, n in zip(old, self._side_ws):
+                n[:16].copy_(o[:16])                         # (a pending error word travels with the workspace)
+        if not self._side_busy:
+            self._chain.copy_(self.cursor, non_blocking=True)      # sequence 0, the row this chain starts from
+            self._chain_seq = 0
+        k = self._chain_seq & 1
+        side, ws = self._side_raw[k], self._side_ws[k]
+        # the maps of the batch (and, the first time, the chain word) are ready on the caller's stream: the side stream waits for them
+        check(lib.dd_stream_fork(self._fork_raw, _stream(self.device), side))
+        if not self._will_retain(batch):                     # nobody keeps the maps alive for the side stream: tell the allocator
+            for t in (batch.depth, batch.mask, batch.conf, batch.normal, batch.rgb, batch.params):
+                if t is not None:
+                    t.record_stream(self._side[k])
+        cb.chain, cb.chain_seq = self._chain_ptr, self._chain_seq
+        try:
+            check(lib.dd_unproject_compact(C.byref(cb), C.byref(out), offsets.data_ptr(), self.cursor.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), side))
+        finally:
+            cb.chain, cb.chain_seq = None, 0
+        self._chain_seq += 1
+        self._side_busy = True
+        return ws
+
+    def __del__(self):
+        import sys
+        if sys is None or sys.is_finalizing():       # (no stream work while the interpreter -- and with it the HIP runtime -- goes down)
+            return
+        try:
+            self._join_side()
+        except Exception:      # noqa: BLE001
+            pass
 
     def fuse_tuning(self, batch: "ViewBatch") -> int:
         """``DDViewBatch.tuning`` with which ``append`` runs ``batch``: the batch's own, plus -- for a large stride-1 batch without
@@ -829,6 +927,7 @@ class CloudBuilder:
         """Pass 2 only (``dd_scatter``) for a batch planned with :func:`plan_batch` against this
         cloud's cursor; advances the cursor.  Used by ``unproject_views`` (exact allocation) and
         by ``bench.py`` to time the dominant kernel on its own."""
+        self._join_side()
         cb = batch.c_struct()
         out = self._out_struct()
         check(lib.dd_scatter(C.byref(cb), C.byref(out), plan.view_offsets.data_ptr(), plan.workspace.data_ptr(),
@@ -851,6 +950,7 @@ class CloudBuilder:
         kernels enqueued so far; ``.result()`` waits for that copy alone.  A caller that runs scene after scene
         (``scripts/run_batch.py:57-91``) asks here, enqueues the next scene and reads the answer later -- the GPU never
         idles while the host looks at a number."""
+        self._join_side()
         ws = list({id(w): w for w in self._workspaces}.values())
         ws, late = ws[:7], ws[7:]                     # (more than 7 distinct workspaces: the rest are read when the result is)
         k, slot = _results.take()
@@ -903,6 +1003,7 @@ class CloudBuilder:
         """A look-back of the single-pass kernel timed out (a workgroup was parked for ~2 s: another tenant, ranks sharing
         the GPU): every batch appended since the last reset is run again through dd_plan + dd_scatter (``tuning`` bit 4),
         whose workgroups do not depend on each other, writing the same rows and the same offset tensors."""
+        self._join_side()
         what = ("a batch run without a counting pass ('assume dense', tuning bit 17) was not dense" if dense_miss
                 else "an in-kernel scan timed out in one of the appended batches")
         if not self._retain_complete or not self._retained:
@@ -1018,6 +1119,7 @@ class CapturedChain:
             builder.reset()
             for b in self.batches:
                 builder.append(b)
+            builder._join_side()                      # (chained small calls fork onto the builder's side streams: joined inside the capture)
             self.graph.capture_end()
         torch.cuda.synchronize(dev)
 

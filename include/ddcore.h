@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 11
+#define DD_ABI_VERSION 12
 
 enum {
     DD_OK = 0,
@@ -119,6 +119,20 @@ typedef struct DDViewBatch {
                                  instead of by ticket.  Same rows whatever these say */
     float *refined_out;       /* DD_REFINE: NULL, or (V,H,W) float32 receiving the refined, mask-zeroed depth -- the map the
                                  reference caches for the multi-view filter (scripts/test.py:194, 197-201) */
+    int64_t *chain;           /* ABI 12: NULL, or (1) int64 device word that chains consecutive calls of ONE cloud across TWO streams, so
+                                 that call n + 1 runs beside the tail of call n instead of behind it (a streaming caller's small calls --
+                                 scripts/test.py:131: one view per iteration -- are bound by the launch-to-launch latency of a stream, not by
+                                 their kernels).  The word holds [63:44] a sequence number, [43:0] the row the next call starts from; the
+                                 caller initialises it to (0, first row).  A call with chain != NULL takes its first row from the word --
+                                 its scan workgroup polls until the sequence equals chain_seq (mod 2^20) -- not from *cursor_dev, and when
+                                 its scan is over stores (chain_seq + 1, row after the batch) there, and the row in *cursor_dev as usual.
+                                 Calls that may be in flight together need a workspace and a view_offsets array each; two in flight at
+                                 most, on a GPU the process has to itself.  A call of at most 383 tiles of 6144 pixels (a 1080p view)
+                                 starts at once and waits inside its scan workgroup -- its tiles load and count meanwhile, and could
+                                 never occupy every slot; a larger one is preceded by a one-wave gate kernel on its stream that returns
+                                 when the earlier call's scan is over, so that its workgroups never hold a slot while they wait for
+                                 another launch.  Stride-1 maps and the scan service only (DD_ERR_UNSUPPORTED otherwise) */
+    int64_t chain_seq;
 } DDViewBatch;
 
 /*
@@ -200,6 +214,12 @@ int dd_scatter(const DDViewBatch *batch, const DDCloudOut *out, const int64_t *v
 int dd_unproject_compact(const DDViewBatch *batch, const DDCloudOut *out,
                          int64_t *view_offsets_dev, int64_t *cursor_dev,
                          void *workspace, int64_t workspace_bytes, void *stream);
+
+/* ABI 12, for calls chained across two streams (DDViewBatch.chain): everything enqueued on `to_stream` from here on runs behind
+ * everything enqueued on `from_stream` so far -- hipEventRecord(event, from_stream) + hipStreamWaitEvent(to_stream, event) in one
+ * call (`event`: a hipEvent_t of the caller, as void*).  The maps of a chained call are produced on the caller's stream and read
+ * on a side stream; when the cloud is read, the caller's stream is ordered behind the side streams the same way. */
+int dd_stream_fork(void *event, void *from_stream, void *to_stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-GPU fuse: what scripts/test.py:262-266 (np.concatenate of the per-view arrays)

@@ -32,7 +32,7 @@ def test_header_symbols_are_exported(libmod):
 
 def test_struct_layout_matches_header(libmod):
     # DDViewParams is 32 floats; DDViewBatch / DDCloudOut sizes for the LP64 layout in the header
-    assert C.sizeof(libmod.DDViewBatch) == 4 * 4 + 6 * 8 + 6 * 4 + 8
+    assert C.sizeof(libmod.DDViewBatch) == 4 * 4 + 6 * 8 + 6 * 4 + 8 + 2 * 8      # (+ chain, chain_seq: ABI 12)
     assert C.sizeof(libmod.DDCloudOut) == 5 * 8 + 8 + 8
 
 

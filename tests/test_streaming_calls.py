@@ -287,3 +287,50 @@ def test_no_guess_without_a_way_back_and_policies_are_the_callers(dd):
     assert results["holed"][:4] == (len(want), 0, 1, 1)                     # one miss, one redo, then counted
     assert torch.equal(results["holed"][4], want.points)
     assert not hasattr(dd.CloudBuilder, "guess_hits") and not hasattr(dd.CloudBuilder, "guess_misses")
+
+
+@pytest.mark.parametrize("shape", [(96, 160), (1080, 1920)])
+def test_small_appends_chained_across_two_streams_write_the_same_cloud(dd, shape):
+    """``CloudBuilder(exclusive_gpu=True)``: consecutive one-view appends run on two side streams, each call's scan taking its first
+    row from the chain word the previous call leaves (``DDViewBatch.chain``): the cloud of one batch, bit for bit -- also when a
+    large append, a check and a reset come in between, and when the chain is replayed from a captured graph."""
+    import torch
+    H, W = shape
+    V = 21 if H > 500 else 40
+    depth, mask, normal, rgb, params, E = _case(51, V, H, W)
+    whole = dd.ViewBatch(depth, params, E, mask=mask, normal=normal, rgb=rgb)
+    ref = dd.CloudBuilder(whole.max_points, normals=True, colors=True, pixel_index=True)
+    ref.append(whole)
+    want = ref.finish()
+    b = dd.CloudBuilder(whole.max_points, normals=True, colors=True, pixel_index=True, exclusive_gpu=True)
+    ones = [whole.slice(v, v + 1) for v in range(V)]
+    for rep in range(3):
+        b.reset()
+        for i, s in enumerate(ones):
+            b.append(s)
+            if rep == 1 and i == V // 3:
+                assert b.check() == int(want.view_offsets[i + 1])          # a check in the middle joins the streams
+        assert b._chain_seq >= V // 2 and len(b._side) == 2                 # (the calls did go through the side streams)
+        _equal(b.finish(), want)
+    # a large batch between small ones: joins, runs on the caller's stream, and the chain starts again behind it
+    b.reset()
+    b.append(ones[0]); b.append(ones[1])
+    b.append(whole.slice(2, V - 2))
+    b.append(ones[V - 2]); b.append(ones[V - 1])
+    _equal(b.finish(), want)
+    # the same chain from a captured graph, twice
+    g = dd.capture_chain(b, ones)
+    for _ in range(2):
+        b.xyz.zero_()
+        g.replay()
+        _equal(b.finish(), want)
+    # a give-up in the middle of a chain: the calls behind it learn from the chain word that their rows are unknown and write nothing
+    b.reset()
+    for i, s in enumerate(ones[:6]):
+        s.tuning = 64 if i == 2 else 0
+        b.append(s)
+    s_bad = ones[2]
+    got = b.finish()
+    s_bad.tuning = 0
+    assert b.healed == 1 and not b.exclusive_gpu                           # healed two-pass; tickets from here on
+    assert torch.equal(got.points, want.points[:len(got)]) and len(got) == int(want.view_offsets[6])

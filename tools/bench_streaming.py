@@ -102,6 +102,7 @@ def main():
                 builder.reset()
                 for s in subs:
                     builder.append(s)
+                builder.join()
             # (ii) the bare C-ABI call
             structs = [(s.c_struct(), torch.empty(s.num_views + 1, dtype=torch.int64, device=dev)) for s in subs]
             out = builder._out_struct()
