@@ -106,6 +106,7 @@ struct KArgs {
     int scan_service;             // single-pass lean kernel: one workgroup of the launch scans the tiles' counts, the tiles poll their own row
     unsigned long long *chain;    // ABI 12: the word that chains this call behind the previous one of the same cloud on another stream (or NULL)
     unsigned chain_seq;           // ... and the sequence number the word must show before this call's scan may start
+    int chain_gated;              // ... the call is preceded by chain_gate (too large to wait inside its own workgroups)
     TileCO *tiles;                // two-pass: count and first row of every tile (NULL in dd_count_valid)
     unsigned long long ws_words;  // 8-byte words of the caller's workspace behind the header (what a wrap of the epoch zeroes)
     unsigned long long *counts;   // per-view counts (dd_count_valid)
@@ -478,15 +479,22 @@ constexpr int SP_WAVES = DD_SP_WAVES;         // single-pass variant: 12 waves, 
 #define DD_SP_SMALL_BATCH_TILES 3072
 #endif
 // A small batch (a streamed view or two: scripts/test.py:131 densifies one view per loop iteration)
-// does not fill the chip even once, so a tile's lifetime IS the kernel's: 8 pixels per lane instead of 16 -- 6144-pixel tiles -- halve
+// does not fill the chip even once, so a tile's lifetime IS the kernel's: 8 pixels per lane instead of 16 -- 8192-pixel tiles of 16 waves -- halve
 // the chain of gather / store sweeps every lane walks through and double the workgroups (profiles/r05_stamps_small_batches.txt:
 // of the 17 us a 12288-pixel tile of a one-view launch lives, 8.5 are those sweeps, 16 times one memory latency that nothing hides).
 // In a CHAIN of calls (what a streaming caller makes) the small tile wins up to 16 views of 1080p per call and draws at 32
 // (profiles/r05_streaming_sweep_9_service_ticket_vs_index.txt: 8 views 0.677 against 0.644, 16 views 0.717 against 0.704); a single
 // launch between two synchronisations prefers the large tile from four views on (r05_ab_scan_service_2.txt) -- the chain decides.
 constexpr int SP_PXT_SMALL = DD_SP_PXT_SMALL;
+#ifndef DD_SP_WAVES_SMALL
+#define DD_SP_WAVES_SMALL 16
+#endif
+// ... in workgroups of 16 waves (8192-pixel tiles): with 52 registers and 49 KiB of LDS two of them -- 32 waves -- fit a CU, where the
+// 12-wave workgroup leaves it at 24; 8 waves (four per CU) do the same.  A chain of one-view calls 0.43 -> 0.51 of the roofline,
+// two views 0.52 -> 0.60, four 0.62 -> 0.66, eight 0.68 -> 0.69 (profiles/r05_streaming_small_tile_waves.txt)
+constexpr int SP_WAVES_SMALL = DD_SP_WAVES_SMALL;
 constexpr unsigned long long SP_SMALL_BATCH_TILES = DD_SP_SMALL_BATCH_TILES;   // batches of up to this many 12288-pixel tiles take the small tile
-static_assert(DD_SP_WAVES * 64 * DD_SP_PXT_SMALL >= 4096, "the workspace holds one record per 4096 pixels: the small single-pass tile must not be finer");
+static_assert(DD_SP_WAVES_SMALL * 64 * DD_SP_PXT_SMALL >= 4096 && DD_SP_WAVES * 64 * DD_SP_PXT_SMALL >= 4096, "the workspace holds one record per 4096 pixels: the small single-pass tile must not be finer");
 
 typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
 typedef float f32x3 __attribute__((ext_vector_type(3)));
@@ -1866,7 +1874,7 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
     // tuning bit 26 = the decoupled look-back of rounds 1-4 instead of the service (bits 20-21: 2 / 3 = 32 / 64 polling lanes instead
     // of 16).  The tile goes by the size of the batch: 16 pixels per lane, 12288-pixel tiles -- or, for a streamed view or a few
     // (scripts/test.py:131 densifies one view per loop iteration: the launch does not fill the chip and a tile's lifetime IS the
-    // kernel's), 8 pixels per lane, 6144-pixel tiles, rows written past the L2.  tuning bits 18-19: 1 / 3 force the small / the large
+    // kernel's), 8 pixels per lane, 8192-pixel tiles of 16 waves, rows written past the L2.  tuning bits 18-19: 1 / 3 force the small / the large
     // tile.  profiles/r05_ab_scan_service*.txt (service + workgroup index against the look-back of round 4): 1.02-1.03x on 185 x 1080p,
     // 1.06x on a per-pixel confidence cull, 1.09x on 100 x 12 MP, 1.05-1.2x on 8 views, 1.14x on one.
     {
@@ -1880,12 +1888,15 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
         if (b->chain) {
             // a chained call's workgroups occupy slots while its scan waits for the previous call: it must never be able to occupy
             // all of them (512 slots of 12 waves), whatever else of this cloud is in flight -- at most 384 workgroups, the scan included
-            const unsigned long long wgs = (unsigned long long)((a.P + SP_WAVES * 64 * p.sp_pxt - 1) / (SP_WAVES * 64 * p.sp_pxt)) * (unsigned)a.V + 1ull;
+            // (counted in the 12-wave small tile a call that waits in its scan runs with: 6144 pixels)
+            const unsigned tile_px = p.sp_pxt == SP_PXT_SMALL ? SP_WAVES * 64 * SP_PXT_SMALL : SP_WAVES * 64 * L_PXT;
+            const unsigned long long wgs = (unsigned long long)((a.P + tile_px - 1) / tile_px) * (unsigned)a.V + 1ull;
             if (!p.lean || !a.scan_service || p.refine || !p.single)
                 return fail(DD_ERR_UNSUPPORTED, "DDViewBatch.chain needs the single-pass kernel with the scan service (stride-1 maps, no DD_REFINE, tuning without 1 / 4 / bit 17 / bit 26)");
             // a call of more than 384 workgroups gets a GATE in front of it (chain_gate): one wave that returns when the previous
             // call's scan is over, so that this call's workgroups exist only once they have nothing to wait for
             p.chain_gate = wgs > 384ull;
+            a.chain_gated = p.chain_gate ? 1 : 0;
             a.chain = reinterpret_cast<unsigned long long *>(b->chain);
             a.chain_seq = (unsigned)(b->chain_seq & (int64_t)CHAIN_SEQ_MASK);
         }
@@ -1945,7 +1956,10 @@ void launch_lean4(const KArgs &a, hipStream_t s) {
 template <typename DepthT, bool SP, bool HM, bool HN>
 void launch_lean3(const KArgs &a, hipStream_t s, int sp_pxt) {
     if constexpr (SP) {
-        if (sp_pxt == SP_PXT_SMALL) launch_lean4<DepthT, SP, HM, HN, SP_WAVES, SP_PXT_SMALL>(a, s);
+        // (a chained call that waits inside its scan workgroup -- a single view -- keeps the 12-wave workgroup: beside the previous
+        // call's tail it is the faster of the two, 3.2 against 3.6-4.0 ms per 185 calls; everywhere else 16 waves win)
+        if (sp_pxt == SP_PXT_SMALL && a.chain && !a.chain_gated) launch_lean4<DepthT, SP, HM, HN, SP_WAVES, SP_PXT_SMALL>(a, s);
+        else if (sp_pxt == SP_PXT_SMALL) launch_lean4<DepthT, SP, HM, HN, SP_WAVES_SMALL, SP_PXT_SMALL>(a, s);
         else launch_lean4<DepthT, SP, HM, HN, SP_WAVES, L_PXT>(a, s);
     } else {
         launch_lean4<DepthT, SP, HM, HN, WAVES, L_PXT>(a, s);
@@ -2102,8 +2116,10 @@ int dd_unproject_compact(const DDViewBatch *batch, const DDCloudOut *out, int64_
 
     a.cursor_out = reinterpret_cast<long long *>(cursor_dev);   // the kernels advance the cursor themselves
     if (p.single) {
-        if (p.lean) {   // the single-pass lean kernel works on SP_WAVES * 64 * sp_pxt-pixel tiles (12288, or 6144 for a small batch)
-            a.tiles_per_view = (a.P + SP_WAVES * 64 * p.sp_pxt - 1) / (SP_WAVES * 64 * p.sp_pxt);
+        if (p.lean) {   // the single-pass lean kernel works on tiles of 12 waves x 16 pixels per lane (12288), or 16 x 8 (8192) for a small batch
+            const unsigned tile_px = p.sp_pxt != SP_PXT_SMALL ? SP_WAVES * 64 * L_PXT
+                                   : (a.chain && !a.chain_gated) ? SP_WAVES * 64 * SP_PXT_SMALL : SP_WAVES_SMALL * 64 * SP_PXT_SMALL;
+            a.tiles_per_view = (a.P + tile_px - 1) / tile_px;
             a.num_tiles = a.tiles_per_view * (unsigned)a.V;
         }
         // ONE stream operation: the granules are tagged with the workspace's call epoch (nothing is zeroed), and the last tile

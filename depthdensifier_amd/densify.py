@@ -692,6 +692,8 @@ class CloudBuilder:
         # consecutive SMALL appends (a streamed view per call, scripts/test.py:131) chained across two side streams so that call n + 1
         # runs beside the tail of call n (DDViewBatch.chain, include/ddcore.h): only where this stream has the GPU to itself
         self.overlap_small = os.environ.get("DD_OVERLAP_SMALL", "1") == "1"
+        if os.environ.get("DD_CHAIN_MAX_TILES"):
+            self.CHAIN_MAX_TILES = int(os.environ["DD_CHAIN_MAX_TILES"])
         self._side: list = []                        # two side streams + their workspaces, made at the first chained append
         self._side_ws: list = []
         self._chain = None                           # (1,) int64 device: the chain word
@@ -774,7 +776,11 @@ class CloudBuilder:
     @staticmethod
     def _versions(batch: "ViewBatch") -> tuple:
         """(data_ptr, version counter) of every map of a batch: what a redo must find unchanged."""
-        return tuple((t.data_ptr(), t._version) for t in (batch.depth, batch.mask, batch.conf, batch.normal, batch.rgb) if t is not None)
+        maps = getattr(batch, "_maps", None)
+        if maps is None:          # (the maps of a batch and where they live never change; what is written INTO them may: the version counters)
+            maps = batch._maps = tuple(t for t in (batch.depth, batch.mask, batch.conf, batch.normal, batch.rgb) if t is not None)
+            batch._map_ptrs = tuple(t.data_ptr() for t in maps)
+        return batch._map_ptrs + tuple(t._version for t in maps)
 
     def _offsets_slice(self, n: int) -> torch.Tensor:
         """(n,) int64 device slice from a pooled tensor (one allocation per ~4096 offsets, not per append)."""
@@ -877,12 +883,12 @@ class CloudBuilder:
         return ws
 
     def __del__(self):
-        import sys
-        if sys is None or sys.is_finalizing():       # (no stream work while the interpreter -- and with it the HIP runtime -- goes down)
-            return
         try:
+            import sys
+            if sys.is_finalizing():                  # (no stream work while the interpreter -- and with it the HIP runtime -- goes down)
+                return
             self._join_side()
-        except Exception:      # noqa: BLE001
+        except BaseException:      # noqa: BLE001
             pass
 
     def fuse_tuning(self, batch: "ViewBatch") -> int:
@@ -899,14 +905,17 @@ class CloudBuilder:
             t |= _lib.DD_TUNE_BY_INDEX       # (the fused refine stage and an explicit single pass included)
         if (t & (1 | 4 | 8 | 0x3F00 | _lib.DD_TUNE_ASSUME_DENSE)) or batch.stride != 1 or batch._knots is not None:
             return t
+        dense_tiles = 128 if (self.normal is None and self.packed is None and not batch.rotate_normals) else 0
+        npx = batch.max_points
+        if npx < self.GUESS_MIN_PIXELS:               # a streamed view or two: neither the interleaved scatter nor the guess is for it
+            return t | dense_tiles
         blocked = (self.placement is not None and self.placement.layout == "blocked"
-                   and self.placement.mode.startswith(("probed", "degraded")) and batch.max_points >= self.INTERLEAVE_MIN_ROWS // 2)
+                   and self.placement.mode.startswith(("probed", "degraded")) and npx >= self.INTERLEAVE_MIN_ROWS // 2)
         guess = (self.normal is None and batch.mask is None and batch.conf is None and self.speculate_dense and not self.dense_misses
-                 and self.guess_policy.allows() and batch.max_points >= self.GUESS_MIN_PIXELS
+                 and self.guess_policy.allows()
                  and self.capacity >= batch.max_points        # (a cloud sized below the pixel count says the maps have holes)
                  and self._will_retain(batch))                # (a guess that misses is redone from the batch: only if it will be held)
-        if self.normal is None and self.packed is None and not batch.rotate_normals:
-            t |= 128        # a cloud of points (and colours): tiles whose pixels all survive take the list-free path -- 1.5 % on 100 x 12 MP now
+        t |= dense_tiles    # a cloud of points (and colours): tiles whose pixels all survive take the list-free path -- 1.5 % on 100 x 12 MP now
                             # that the single pass no longer waits for a look-back (profiles/r05_ab_scan_service_3.txt); nothing with normals
         if blocked or guess:
             # (+ bit 128: dense tiles take the list-free path -- in the scatter pass, which waits for no look-back, its smaller

@@ -112,7 +112,7 @@ typedef struct DDViewBatch {
                                  does by itself).  Ignored with tuning 8, DD_REFINE and on strided maps;
                                  bits 18-19 (ABI 11) = tile of the single-pass kernel on stride-1 maps: 0 = by the size of the batch
                                  (up to 3072 tiles of 12288 pixels -- a streamed view or a dozen, scripts/test.py:131 -- 8 pixels per lane,
-                                 6144-pixel tiles, rows written past the L2; above, 16 pixels per lane, 12288-pixel tiles), 1 / 3 =
+                                 8192-pixel tiles of 16 waves, rows written past the L2; above, 16 pixels per lane, 12288-pixel tiles), 1 / 3 =
                                  force the small / the large tile; bit 26 = the decoupled look-back of ABI <= 10 instead of the scan
                                  service (one workgroup of the launch scans the tiles' counts, a tile polls its own first row), with
                                  bits 20-21 = its polling lanes (0 / 1 = 16, 2 = 32, 3 = 64) and bit 22 = tiles by workgroup index

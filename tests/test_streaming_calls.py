@@ -70,7 +70,7 @@ def _equal(a, b):
 @pytest.mark.parametrize("dtype", (np.float32, np.float16))
 @pytest.mark.parametrize("shape", [(3, 67, 129), (2, 128, 256), (1, 255, 257), (2, 200, 331), (9, 96, 172), (70, 216, 384)])
 def test_every_single_pass_geometry_writes_the_oracles_cloud(dd, orc, shape, dtype):
-    """Small tile (8 pixels per lane, 6144) / large tile (16, 12288), tiles by ticket / by workgroup index, 16 / 32 / 64
+    """Small tile (8 pixels per lane, 16 waves: 8192) / large tile (16, 12288), tiles by ticket / by workgroup index, 16 / 32 / 64
     polling lanes: indices, colours and normals bit-exact against the oracle, and the rows of all variants identical."""
     V, H, W = shape
     depth, mask, normal, rgb, params, E = _case(11 + H, V, H, W, dtype)
