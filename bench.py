@@ -306,6 +306,7 @@ def strong_scaling_record(args, dd, D, dist, use_dist, rank, world, device, fenc
         def sharded():
             builder.reset()
             offs = builder.append(batch)
+            builder.join()                  # (a tiny batch may have run on the builder's side streams: its offsets are read right here)
             counts = offs[1:] - offs[:-1]
             return D.offsets_from_counts(D.exchange_counts(counts, V_total) if use_dist else counts)
 
@@ -832,6 +833,7 @@ def main() -> None:
                 e[0].record()
             if single_pass:
                 offs = builder.append(batch)
+                builder.join()              # (no-op unless the batch was small enough to run on the builder's side streams)
                 if record:
                     e[1].record(); e[2].record()
             else:
@@ -886,7 +888,7 @@ def main() -> None:
             for _ in range(7):
                 builder.reset()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(); builder.append(batch); e1.record()
+                e0.record(); builder.append(batch); builder.join(); e1.record()
                 torch.cuda.synchronize(device)
                 ts.append(e0.elapsed_time(e1))
             builder.check()
@@ -931,7 +933,7 @@ def main() -> None:
                 for _ in range(5):
                     b2.reset()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(); b2.append(batch); e1.record()
+                    e0.record(); b2.append(batch); b2.join(); e1.record()
                     torch.cuda.synchronize(device)
                     ts.append(e0.elapsed_time(e1))
                 alloc_ms.append(float(np.median(ts)))

@@ -802,7 +802,9 @@ class CloudBuilder:
 
     def append(self, batch: ViewBatch, _offsets: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Enqueue one batch; returns its (V+1,) absolute view offsets (device, valid once the
-        stream has run)."""
+        stream has run).  With ``exclusive_gpu`` a small batch (up to 4 views of 1080p) is enqueued on one of the builder's two side
+        streams (``_append_chained``): its offsets and rows are ordered with the caller's stream by ``join()`` / ``check()`` /
+        ``finish()`` / ``reset()``, not by the append itself."""
         if self.normal is not None and batch.normal is None:
             raise ValueError("this cloud carries normals but the batch has no normal map")
         if self.rgb is not None and batch.rgb is None:

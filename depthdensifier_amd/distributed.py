@@ -330,6 +330,7 @@ def fuse_replicated(batch, num_views_total: int, *, normals: bool = True, colors
     # the counts are KNOWN here (plan_fuse): nothing to guess -- and a guess that missed would scatter rows beyond this rank's
     # [own_lo, own_hi) into regions of the shared buffers that RCCL is receiving the peers' rows into
     builder.speculate_dense = False
+    builder.overlap_small = False           # every chunk's rows are handed to RCCL right behind its kernel: the caller's stream, no side streams
     moved = [t for t in (builder.xyz, builder.normal, builder.rgb, builder.pix, builder.view, builder.packed) if t is not None]
     work = []
     for (lo, hi), ranges in zip(plan.chunk_views, plan.chunk_rows):
