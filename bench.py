@@ -492,6 +492,7 @@ def streaming_record(args, dd, cfg, scene, params, E, batch, builder, device, vi
             item["hip_graph_chain_ms"] = None
             item["hip_graph_error"] = f"{type(e).__name__}: {e}"[:200]
         rec["per_call"][str(k)] = item
+    rec["side_stream_probes"] = int(getattr(builder, "side_stream_probes", 0))      # pairs of streams tried until two ran side by side
     rec["all_ok"] = ok_all
     return rec
 

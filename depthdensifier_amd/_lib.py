@@ -21,7 +21,7 @@ import torch  # noqa: F401  (load order, see above)
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("DDCORE_LIB", _HERE / "libddcore.so"))
 
-DD_ABI_VERSION = 12
+DD_ABI_VERSION = 13
 DD_OK = 0
 DD_F32, DD_F16 = 0, 1
 DD_VALID_DEPTH_POSITIVE = 0x1
@@ -40,6 +40,7 @@ EXPORTS = (
     "dd_scatter",
     "dd_unproject_compact",
     "dd_stream_fork",
+    "dd_streams_overlap",
     "dd_floater_votes",
     "dd_filter_last_error",
     "dd_votes_workspace_bytes",
@@ -176,6 +177,8 @@ def _load() -> C.CDLL:
     ]
     lib.dd_stream_fork.restype = C.c_int
     lib.dd_stream_fork.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.dd_streams_overlap.restype = C.c_int
+    lib.dd_streams_overlap.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
     lib.dd_floater_votes.restype = C.c_int
     lib.dd_floater_votes.argtypes = [C.POINTER(DDFilterViews), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]
     lib.dd_votes_workspace_bytes.restype = C.c_int64

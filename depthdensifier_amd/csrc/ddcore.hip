@@ -1600,6 +1600,25 @@ __global__ __launch_bounds__(64) void chain_gate(const unsigned long long *chain
     }
 }
 
+// ---- do two streams run side by side?  (dd_streams_overlap)  HIP deals its streams to a few hardware queues, and two streams on ONE
+// queue run strictly one after the other: calls chained across them would gain nothing (measured: 26 instead of 17 us per one-view
+// call, profiles/r05_streaming_queue_collision.txt).  `overlap_wait` on stream A waits up to 1 ms of wall clock for the flag that
+// `overlap_set`, launched behind it on stream B, raises: it sees the flag only if B's kernel ran while A's was running. ----
+__global__ __launch_bounds__(64) void overlap_wait(int *w) {
+    if (threadIdx.x) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
+    int seen = 0;
+    for (;;) {
+        if (__hip_atomic_load(&w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { seen = 1; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 100000ull) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    w[1] = seen;
+}
+__global__ __launch_bounds__(64) void overlap_set(int *w) {
+    if (threadIdx.x == 0) __hip_atomic_store(&w[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- the count-free plan (tuning bit 17): every visited pixel taken as valid -- tile t of a view starts tv * tile rows
 // into the view, view v starts v * P rows behind the cursor.  The scatter pass verifies it (assume_dense above). ----
 __global__ __launch_bounds__(256) void plan_dense(const KArgs a, const unsigned tile) {
@@ -2097,8 +2116,39 @@ int dd_scatter(const DDViewBatch *batch, const DDCloudOut *out, const int64_t *v
 
 int dd_stream_fork(void *event, void *from_stream, void *to_stream) {
     if (!event) return fail(DD_ERR_INVALID_ARG, "event is NULL");
+    // A stream with nothing pending has nothing to wait for: the fork then costs one query on the host and no barrier packet in
+    // either queue (a stream that is being captured cannot be queried; there the fork is recorded as it is).
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusActive;
+    if (hipStreamIsCapturing((hipStream_t)from_stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusActive; }
+    if (cap == hipStreamCaptureStatusNone) {
+        if (hipStreamQuery((hipStream_t)from_stream) == hipSuccess) return DD_OK;
+        (void)hipGetLastError();                       // (hipErrorNotReady must not stay behind as the thread's last error)
+    }
     if (hipEventRecord((hipEvent_t)event, (hipStream_t)from_stream) != hipSuccess) return fail(DD_ERR_LAUNCH, "hipEventRecord failed");
     if (hipStreamWaitEvent((hipStream_t)to_stream, (hipEvent_t)event, 0) != hipSuccess) return fail(DD_ERR_LAUNCH, "hipStreamWaitEvent failed");
+    return DD_OK;
+}
+
+int dd_streams_overlap(void *stream_a, void *stream_b, int32_t *scratch_dev, int32_t *overlap_out) {
+    if (!scratch_dev || !overlap_out) return fail(DD_ERR_INVALID_ARG, "scratch_dev / overlap_out is NULL");
+    if (stream_a == stream_b) { *overlap_out = 0; return DD_OK; }
+    hipStream_t sa = (hipStream_t)stream_a, sb = (hipStream_t)stream_b;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    for (hipStream_t s : {sa, sb})
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            return fail(DD_ERR_INVALID_ARG, "dd_streams_overlap synchronises both streams: not inside a stream capture");
+        }
+    int *w = reinterpret_cast<int *>(scratch_dev);
+    if (hipMemsetAsync(w, 0, 8, sa) != hipSuccess || hipStreamSynchronize(sa) != hipSuccess || hipStreamSynchronize(sb) != hipSuccess)
+        return fail(DD_ERR_LAUNCH, "dd_streams_overlap: clearing the scratch words failed");
+    overlap_wait<<<1, 64, 0, sa>>>(w);
+    overlap_set<<<1, 64, 0, sb>>>(w);
+    int32_t seen = 0;
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(sb) != hipSuccess
+        || hipMemcpyAsync(&seen, w + 1, 4, hipMemcpyDeviceToHost, sa) != hipSuccess || hipStreamSynchronize(sa) != hipSuccess)
+        return fail(DD_ERR_LAUNCH, "dd_streams_overlap: the probe kernels failed");
+    *overlap_out = seen;
     return DD_OK;
 }
 

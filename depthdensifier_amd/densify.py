@@ -695,6 +695,7 @@ class CloudBuilder:
         if os.environ.get("DD_CHAIN_MAX_TILES"):
             self.CHAIN_MAX_TILES = int(os.environ["DD_CHAIN_MAX_TILES"])
         self._side: list = []                        # two side streams + their workspaces, made at the first chained append
+        self.side_stream_probes = 0                  # candidates tried until two streams ran side by side (_ensure_side)
         self._side_ws: list = []
         self._chain = None                           # (1,) int64 device: the chain word
         self._chain_seq = 0
@@ -735,7 +736,41 @@ class CloudBuilder:
         _, H, W = batch.depth.shape
         # small calls only (a large batch fills the chip by itself and its launch latency is nothing): up to CHAIN_MAX_TILES tiles of
         # 12288 pixels.  (Up to 383 tiles of 6144 the call waits inside its scan workgroup; above, behind a one-wave gate kernel.)
-        return batch.num_views * (-(-(H * W) // 12288)) <= self.CHAIN_MAX_TILES and H * W >= 8
+        if not (batch.num_views * (-(-(H * W) // 12288)) <= self.CHAIN_MAX_TILES and H * W >= 8):
+            return False
+        return self._ensure_side()
+
+    def _ensure_side(self) -> bool:
+        """The two side streams of the chained appends, made once: two streams whose kernels really run side by side.  The HIP
+        runtime deals its streams to a few hardware queues and two streams on one queue run strictly in order -- chained across such
+        a pair a one-view call takes 26 us instead of 17 (and 23 on the caller's stream alone: profiles/r05_streaming_queue_collision.txt;
+        which streams collide depends on what else the process has created).  So the pair is probed (``dd_streams_overlap``, ~50 us per
+        candidate); when no candidate runs beside the first stream this cloud does not chain its appends."""
+        if self._side:
+            return True
+        if not self.overlap_small or torch.cuda.is_current_stream_capturing():      # (the probe synchronises: never inside a capture)
+            return False
+        scratch = torch.zeros(2, dtype=torch.int32, device=self.device)
+        seen = C.c_int32(0)
+        with torch.cuda.device(self.device):
+            first = torch.cuda.Stream(self.device)
+            for _ in range(8):
+                second = torch.cuda.Stream(self.device)
+                self.side_stream_probes += 1
+                check(lib.dd_streams_overlap(first.cuda_stream, second.cuda_stream, scratch.data_ptr(), C.byref(seen)))
+                if seen.value:
+                    break
+            else:
+                self.overlap_small = False
+                return False
+        self._side = [first, second]
+        self._side_raw = [s.cuda_stream for s in self._side]
+        self._chain = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._chain_ptr = self._chain.data_ptr()
+        self._fork_ev = torch.cuda.Event()
+        self._fork_ev.record(torch.cuda.current_stream(self.device))      # (creates the underlying event)
+        self._fork_raw = self._fork_ev.cuda_event
+        return True
 
     def reset(self) -> None:
         self._join_side()
@@ -848,21 +883,7 @@ class CloudBuilder:
         meanwhile, and the previous call's last rows are still being written.  A one-view call is bound by the launch-to-launch latency
         of a stream (4-5 us of the 25 it takes), not by its kernel: two streams take 1.5x as many calls per second
         (``tools/experiments/two_stream_chains.py``)."""
-        need = batch.workspace_bytes()
-        if not self._side:
-            self._side = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
-            self._side_raw = [s.cuda_stream for s in self._side]
-            self._chain = torch.zeros(1, dtype=torch.int64, device=self.device)
-            self._chain_ptr = self._chain.data_ptr()
-            self._fork_ev = torch.cuda.Event()
-            self._fork_ev.record(torch.cuda.current_stream(self.device))      # (creates the underlying event)
-            self._fork_raw = self._fork_ev.cuda_event
-        if len(self._side_ws) < 2 or self._side_ws[0].numel() < need:
-            self._join_side()
-            old = self._side_ws
-            self._side_ws = [torch.zeros(max(need, 1024), dtype=torch.uint8, device=self.device) for _ in range(2)]
-            for o, n in zip(old, self._side_ws):
-                n[:16].copy_(o[:16])                         # (a pending error word travels with the workspace)
+        self._side_workspaces(batch.workspace_bytes())
         if not self._side_busy:
             self._chain.copy_(self.cursor, non_blocking=True)      # sequence 0, the row this chain starts from
             self._chain_seq = 0
@@ -883,6 +904,15 @@ class CloudBuilder:
         self._chain_seq += 1
         self._side_busy = True
         return ws
+
+    def _side_workspaces(self, need: int) -> None:
+        """One workspace per side stream, of at least ``need`` bytes."""
+        if len(self._side_ws) < 2 or self._side_ws[0].numel() < need:
+            self._join_side()
+            old = self._side_ws
+            self._side_ws = [torch.zeros(max(need, 1024), dtype=torch.uint8, device=self.device) for _ in range(2)]
+            for o, n in zip(old, self._side_ws):
+                n[:16].copy_(o[:16])                         # (a pending error word travels with the workspace)
 
     def __del__(self):
         try:
@@ -1120,7 +1150,10 @@ class CapturedChain:
 
     def __init__(self, builder: "CloudBuilder", batches: Sequence["ViewBatch"]):
         dev = builder.device
-        builder._workspace(max([b.workspace_bytes() for b in batches if b.num_views] + [1024]))      # (allocated outside the capture)
+        need = max([b.workspace_bytes() for b in batches if b.num_views] + [1024])
+        builder._workspace(need)                                                                     # (allocated outside the capture)
+        if builder.exclusive_gpu and builder._ensure_side():      # ... and so are the side streams of chained appends (probed: synchronises)
+            builder._side_workspaces(need)
         self.builder, self.batches = builder, list(batches)
         self.graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream(dev)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 12
+#define DD_ABI_VERSION 13
 
 enum {
     DD_OK = 0,
@@ -218,8 +218,17 @@ int dd_unproject_compact(const DDViewBatch *batch, const DDCloudOut *out,
 /* ABI 12, for calls chained across two streams (DDViewBatch.chain): everything enqueued on `to_stream` from here on runs behind
  * everything enqueued on `from_stream` so far -- hipEventRecord(event, from_stream) + hipStreamWaitEvent(to_stream, event) in one
  * call (`event`: a hipEvent_t of the caller, as void*).  The maps of a chained call are produced on the caller's stream and read
- * on a side stream; when the cloud is read, the caller's stream is ordered behind the side streams the same way. */
+ * on a side stream; when the cloud is read, the caller's stream is ordered behind the side streams the same way.  When
+ * `from_stream` has nothing pending (hipStreamQuery == hipSuccess, outside a stream capture) there is nothing to order and
+ * nothing is enqueued: a chain of small calls on resident maps then carries no barrier packet at all. */
 int dd_stream_fork(void *event, void *from_stream, void *to_stream);
+
+/* ABI 13: do kernels of `stream_a` and `stream_b` run side by side?  The HIP runtime deals streams to a few hardware queues, and two
+ * streams that share one run strictly in order -- calls chained across them (DDViewBatch.chain) would then be SLOWER than on one
+ * stream.  A one-thread kernel on `stream_a` waits (at most 1 ms) for a flag that a kernel launched behind it on `stream_b` raises;
+ * *overlap_out = 1 if it saw the flag.  `scratch_dev`: 8 bytes of device memory.  Synchronises both streams (about 50 us; call it
+ * once per pair of side streams, outside any stream capture) and no other. */
+int dd_streams_overlap(void *stream_a, void *stream_b, int32_t *scratch_dev, int32_t *overlap_out);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-GPU fuse: what scripts/test.py:262-266 (np.concatenate of the per-view arrays)

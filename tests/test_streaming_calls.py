@@ -334,3 +334,46 @@ def test_small_appends_chained_across_two_streams_write_the_same_cloud(dd, shape
     s_bad.tuning = 0
     assert b.healed == 1 and not b.exclusive_gpu                           # healed two-pass; tickets from here on
     assert torch.equal(got.points, want.points[:len(got)]) and len(got) == int(want.view_offsets[6])
+
+
+def test_side_streams_are_probed_before_calls_are_chained_across_them(dd, monkeypatch):
+    """ABI 13: two HIP streams may share a hardware queue and then run strictly in order (``dd_streams_overlap``): a stream beside
+    itself never overlaps; the pair a builder settles on does; and a builder that finds no pair does not chain -- same cloud."""
+    import ctypes as C
+    import torch
+    from depthdensifier_amd import _lib, densify
+    lib = _lib.lib
+    scratch = torch.zeros(2, dtype=torch.int32, device="cuda")
+    seen = C.c_int32(7)
+    s = torch.cuda.Stream()
+    assert lib.dd_streams_overlap(s.cuda_stream, s.cuda_stream, scratch.data_ptr(), C.byref(seen)) == 0 and seen.value == 0
+    assert lib.dd_streams_overlap(s.cuda_stream, s.cuda_stream, None, C.byref(seen)) != 0
+    V, H, W = 6, 120, 200
+    depth, mask, normal, rgb, params, E = _case(77, V, H, W)
+    whole = dd.ViewBatch(depth, params, E, mask=mask, normal=normal, rgb=rgb)
+    ref = dd.CloudBuilder(whole.max_points, normals=True, colors=True, pixel_index=True)
+    ref.append(whole)
+    want = ref.finish()
+    ones = [whole.slice(v, v + 1) for v in range(V)]
+    b = dd.CloudBuilder(whole.max_points, normals=True, colors=True, pixel_index=True, exclusive_gpu=True)
+    for o in ones:
+        b.append(o)
+    _equal(b.finish(), want)
+    assert len(b._side) == 2 and 1 <= b.side_stream_probes <= 8
+    seen.value = 0
+    assert lib.dd_streams_overlap(b._side_raw[0], b._side_raw[1], scratch.data_ptr(), C.byref(seen)) == 0 and seen.value == 1
+    # a process in which no second stream runs beside the first: every probe says no -> the appends stay on the caller's stream
+
+    class NoOverlap:
+        def __getattr__(self, name):
+            return getattr(lib, name)
+
+        def dd_streams_overlap(self, a, b_, w, out):
+            out._obj.value = 0
+            return 0
+    monkeypatch.setattr(densify, "lib", NoOverlap())
+    c = dd.CloudBuilder(whole.max_points, normals=True, colors=True, pixel_index=True, exclusive_gpu=True)
+    for o in ones:
+        c.append(o)
+    _equal(c.finish(), want)
+    assert c._side == [] and c.side_stream_probes == 8 and c.overlap_small is False and c._chain_seq == 0
