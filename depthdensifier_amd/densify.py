@@ -839,7 +839,9 @@ class CloudBuilder:
         """Enqueue one batch; returns its (V+1,) absolute view offsets (device, valid once the
         stream has run).  With ``exclusive_gpu`` a small batch (up to 4 views of 1080p) is enqueued on one of the builder's two side
         streams (``_append_chained``): its offsets and rows are ordered with the caller's stream by ``join()`` / ``check()`` /
-        ``finish()`` / ``reset()``, not by the append itself."""
+        ``finish()`` / ``reset()``, not by the append itself -- and so are its READS: a caller that writes into the batch's maps again
+        (a staging buffer it refills in place) calls ``join()`` first.  (Maps that are merely dropped are safe: the builder holds them
+        until the next check, or tells the allocator which stream still reads them.)"""
         if self.normal is not None and batch.normal is None:
             raise ValueError("this cloud carries normals but the batch has no normal map")
         if self.rgb is not None and batch.rgb is None:

@@ -26,7 +26,10 @@ def _torchrun(nproc, env_extra, timeout=150):
     for attempt in range(3):            # the port found free a moment ago can be taken by the time the rendezvous binds it: another one then
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
                             "--master-port", str(_port()), str(ROOT / "tests" / "fuse_worker.py")], capture_output=True, text=True, timeout=timeout, env=env)
-        if r.returncode == 0 or "EADDRINUSE" not in r.stderr:
+        # (retried: a rendezvous that did not come up -- the port, a refused or reset connection between the local ranks; a worker that
+        #  ran and found a wrong cloud is not)
+        if r.returncode == 0 or not any(k in r.stderr for k in ("EADDRINUSE", "Connection refused", "Connection reset", "RendezvousConnectionError",
+                                                                 "RendezvousTimeoutError", "connectFullMesh")):
             break
     return r
 
