@@ -1,0 +1,4 @@
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/rehearse
+REHEARSE=1 timeout -k 10 1000 bash tools/run_multi_gpu.sh gpurun_out/rehearse > gpurun_out/rehearse/log.txt 2>&1; rc=$?
+tail -30 gpurun_out/rehearse/r05_scale_summary.txt | cut -c1-300
+exit $rc
