@@ -115,6 +115,29 @@ def main():
                     rc = lib.dd_unproject_compact(C.byref(cs), C.byref(out), offs.data_ptr(), builder.cursor.data_ptr(), ws.data_ptr(), ws.numel(), sp)
                     assert rc == 0
             modes = [("builder.append", chain_builder), ("C ABI", chain_abi)]
+            # (iii) the bare C-ABI calls chained across the builder's two side streams (DDViewBatch.chain; what builder.append does for
+            #       small calls with exclusive_gpu, without its Python): structs with the chain word and the sequence numbers set beforehand
+            if builder.exclusive_gpu and tun == 0 and builder._chained_ok(subs[0], 1 << 22):
+                structs2 = []
+                for i, (cs, offs) in enumerate(structs):
+                    c2 = type(cs)()
+                    C.memmove(C.byref(c2), C.byref(cs), C.sizeof(cs))
+                    c2.chain, c2.chain_seq, c2.tuning = builder._chain_ptr, i, cs.tuning | (1 << 22)
+                    structs2.append((c2, offs))
+                builder._side_workspaces(max(s.workspace_bytes() for s in subs))
+
+                def chain_abi2():
+                    builder.cursor.zero_()
+                    builder._chain.copy_(builder.cursor, non_blocking=True)
+                    for sd in builder._side_raw:
+                        assert lib.dd_stream_fork(builder._fork_raw, sp, sd) == 0
+                    for i, (cs, offs) in enumerate(structs2):
+                        w = builder._side_ws[i & 1]
+                        rc = lib.dd_unproject_compact(C.byref(cs), C.byref(out), offs.data_ptr(), builder.cursor.data_ptr(), w.data_ptr(), w.numel(), builder._side_raw[i & 1])
+                        assert rc == 0
+                    for sd in builder._side:
+                        stream.wait_stream(sd)
+                modes.append(("C ABI chained", chain_abi2))
             for xtag, xlib in xlibs:
                 def chain_x(xlib=xlib):
                     builder.cursor.zero_()
@@ -158,7 +181,7 @@ def main():
                 if name != "builder.append":
                     last = structs[-1][1]
                     ok = ok and int(last[-1].item()) == n
-                err = int(ws[:8].view(torch.int32)[1].item())
+                err = int(ws[:8].view(torch.int32)[1].item()) | (sum(int(w[:8].view(torch.int32)[1].item()) for w in builder._side_ws) if name == "C ABI chained" else 0)
                 med = float(np.median(ts))
                 res[name] = med
                 print(f"k={k:3d} {tag:10s} {name:15s} chain {med:8.3f} ms (min {min(ts):7.3f})  per call {1e3 * med / len(subs):7.2f} us  frac {alg / med / 1e6 / 8000:5.3f}  "

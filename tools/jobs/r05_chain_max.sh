@@ -1,3 +1,4 @@
+# with the forks gone: does a gate in front of 8-view (and larger) calls win now?  (DD_CHAIN_MAX_TILES 700 against 4000, twice)
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
 export DD_EXCLUSIVE_GPU=1
 for m in 700 4000 700 4000; do

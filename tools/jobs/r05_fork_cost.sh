@@ -1,3 +1,4 @@
+# what the fork in front of every chained call costs, and whether dd_stream_fork's idle shortcut triggers (tools/experiments/fork_cost.py)
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
 export DD_EXCLUSIVE_GPU=1
 rocm-smi --showbus 2>/dev/null | grep -i "pci bus" | head -1

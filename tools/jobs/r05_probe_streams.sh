@@ -1,3 +1,4 @@
+# dd_streams_overlap: the tests, then the scenario in which the two side streams used to share a hardware queue (bench_streaming --graph)
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
 timeout -k 10 300 python -m pytest tests/test_streaming_calls.py tests/test_host_cpu.py -x -q 2>&1 | tail -4
 export TMPDIR=/tmp DD_EXCLUSIVE_GPU=1

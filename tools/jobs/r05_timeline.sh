@@ -1,3 +1,4 @@
+# the sharing tests once more, then 8-view calls with and without a gate under rocprofv3 --kernel-trace (tools/kernel_timeline.py)
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
 timeout -k 10 400 python -m pytest tests/test_fuse_gpu.py -x -q -m gpu -k "sharing_the_gpu" > gpurun_out/r05_fuse_share.log 2>&1; rc=$?
 tail -5 gpurun_out/r05_fuse_share.log
