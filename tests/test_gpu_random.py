@@ -51,6 +51,11 @@ def _case(seed):
         opts["tuning"] |= 1 << 17
         if r4.uniform() < 0.5:
             opts["tuning"] |= int(r4.integers(1, 64)) << 8     # with the tiles of the scatter pass in an interleaved order
+    r5 = np.random.default_rng(50_000 + seed)
+    if r5.uniform() < 0.6 and not (opts["tuning"] & (1 | 4 | (1 << 17))):
+        # round 5: the single-pass kernel's geometries -- tiles by workgroup index (bit 22), the decoupled look-back instead of the scan
+        # service (bit 26), the small / the large tile forced (bits 18-19 = 1 / 3), 32 / 64 polling lanes (bits 20-21 = 2 / 3)
+        opts["tuning"] |= (int(r5.integers(0, 2)) << 22) | (int(r5.integers(0, 2)) << 26) | (int(r5.choice([0, 1, 3])) << 18) | (int(r5.choice([0, 2, 3])) << 20)
     return d, opts
 
 

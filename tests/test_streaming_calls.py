@@ -377,3 +377,46 @@ def test_side_streams_are_probed_before_calls_are_chained_across_them(dd, monkey
         c.append(o)
     _equal(c.finish(), want)
     assert c._side == [] and c.side_stream_probes == 8 and c.overlap_small is False and c._chain_seq == 0
+
+
+N_STREAM_SEEDS = int(__import__("os").environ.get("DD_STREAM_SEEDS", "16"))          # soak: DD_STREAM_SEEDS=400
+
+
+@pytest.mark.parametrize("seed", range(N_STREAM_SEEDS))
+def test_random_chains_of_appends_write_the_one_batch_cloud(dd, seed):
+    """Random view sizes / dtypes / fields, the views cut at random into calls of 1-5 views, appended with checks, joins and resets
+    thrown in, on a shared GPU (tickets, one stream) or an exclusive one (by index; small calls chained across two streams, waiting
+    inside their scan or behind a gate): always the cloud of ONE batch, bit for bit."""
+    import torch
+    rng = np.random.default_rng(70_000 + seed)
+    if rng.uniform() < 0.12:
+        V, H, W = int(rng.integers(2, 6)), 1080, 1920                        # one call of 1-5 such views: with and without a gate
+    elif rng.uniform() < 0.5:
+        V, H, W = int(rng.integers(3, 25)), int(rng.integers(1, 60)) * 4, int(rng.integers(1, 60)) * 8
+    else:
+        V, H, W = int(rng.integers(3, 25)), int(rng.integers(3, 300)), int(rng.integers(3, 400))
+    dtype = np.float16 if rng.uniform() < 0.4 else np.float32
+    depth, mask, normal, rgb, params, E = _case(int(rng.integers(1 << 30)), V, H, W, dtype=dtype, rho=float(rng.uniform(0.1, 1.0)))
+    fields = dict(normals=bool(rng.uniform() < 0.6), colors=bool(rng.uniform() < 0.6))
+    whole = dd.ViewBatch(depth, params, E, mask=mask if rng.uniform() < 0.7 else None, normal=normal if fields["normals"] else None,
+                         rgb=rgb if fields["colors"] else None)
+    ref = dd.CloudBuilder(whole.max_points, pixel_index=True, **fields)
+    ref.speculate_dense = False
+    ref.append(whole)
+    want = ref.finish()
+    b = dd.CloudBuilder(whole.max_points, pixel_index=True, exclusive_gpu=bool(rng.uniform() < 0.7), **fields)
+    b.speculate_dense = False
+    for _ in range(2):
+        b.reset()
+        lo = 0
+        while lo < V:
+            hi = min(V, lo + int(rng.integers(1, 6)))
+            b.append(whole.slice(lo, hi))
+            lo = hi
+            u = rng.uniform()
+            if u < 0.12:
+                assert b.check() == int(want.view_offsets[lo])
+            elif u < 0.2:
+                b.join()
+        _equal(b.finish(), want)
+    assert b.healed == 0 and b.dense_misses == 0
