@@ -103,6 +103,7 @@ struct KArgs {
     WsHeader *hdr;
     unsigned long long *gran;     // look-back granules, one per tile of the single-pass tiling
     unsigned long long *pref;     // scan service: the first row of every tile, written by the service workgroup (same tags as the granules)
+    int refine_plain;             // DD_REFINE, tuning bits 27 / 28 (A/B switches): 1 = bisect all knots, 2 = one median per window
     int scan_service;             // single-pass lean kernel: one workgroup of the launch scans the tiles' counts, the tiles poll their own row
     unsigned long long *chain;    // ABI 12: the word that chains this call behind the previous one of the same cloud on another stream (or NULL)
     unsigned chain_seq;           // ... and the sequence number the word must show before this call's scan may start
@@ -1157,6 +1158,7 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
     float *const s_d = reinterpret_cast<float *>(s_raw);                              // 4 B per pixel
     unsigned short *const s_q = reinterpret_cast<unsigned short *>(s_raw + LT * 4);  // 2 B per pixel
     __shared__ float s_knots[REFINE ? 2 * REFINE_MAX_KNOTS : 1];
+    __shared__ unsigned short s_grid[REFINE ? ddmath::LUT_BUCKETS : 1];      // where in the knots to start looking (ddrefine_math.h)
     __shared__ unsigned s_tot[NW];
     __shared__ long long s_excl;
     __shared__ unsigned s_ticket;
@@ -1242,24 +1244,91 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
         const unsigned lo = q0 > Wd + 1u ? q0 - (Wd + 1u) : 0u;
         const unsigned hi = (q0 + (unsigned)LT + Wd + 1u) < a.P ? (q0 + (unsigned)LT + Wd + 1u) : a.P;
         __syncthreads();
+        // Round 5: this stage is bound by the vector ALU, not by memory (24 us per 1080p view where the plain kernel takes 14): the curve
+        // is found through a grid of buckets instead of a bisection of all knots (~10 dependent LDS reads -> ~2), and four consecutive
+        // windows share their sorted columns (median9x4).  Same bits as ddmath::lut / median9 (dd_refine_apply), which the tests compare.
+        const ddmath::LutGrid grid = ddmath::lut_grid(s_kx, nk);
+        for (int j = tid; j < ddmath::LUT_BUCKETS; j += BT) s_grid[j] = ddmath::lut_grid_entry(s_kx, nk, grid, j);
+        __syncthreads();
         // (tried in round 2: batches of 7 pixels per lane with their loads issued together and a fixed-trip lockstep search --
         // 6 % SLOWER on the same box; the other waves of the CU already hide these latencies and the early-exit search does less work)
-        for (unsigned e = lo + (unsigned)tid; e < hi; e += (unsigned)BT) {
-            const long long p = vbase + e;
-            const float raw = a.raw_f16 ? (float)reinterpret_cast<const _Float16 *>(a.depth)[p] : reinterpret_cast<const float *>(a.depth)[p];
-            const bool mk = a.mask ? (a.mask[p] != 0) : (raw > 0.0f);         // depth_refiner.py:238-241
-            s_val[e - lo] = mk ? ddmath::lut(s_kx, s_ky, nk, raw) : 0.0f;     // :185-191
+        bool any_nan = false;
+        if (a.refine_plain & 1) {
+            for (unsigned e = lo + (unsigned)tid; e < hi; e += (unsigned)BT) {
+                const long long p = vbase + e;
+                const float raw = a.raw_f16 ? (float)reinterpret_cast<const _Float16 *>(a.depth)[p] : reinterpret_cast<const float *>(a.depth)[p];
+                const bool mk = a.mask ? (a.mask[p] != 0) : (raw > 0.0f);         // depth_refiner.py:238-241
+                const float val = mk ? ddmath::lut(s_kx, s_ky, nk, raw) : 0.0f;   // :185-191
+                any_nan |= val != val;
+                s_val[e - lo] = val;
+            }
+        } else {
+            // four consecutive values per lane and step: one wide load of the depth, one of the mask, four look-ups in lock step
+            const unsigned cnt = hi - lo;
+            const long long pb = vbase + lo;
+            for (unsigned e4 = (unsigned)tid * 4u; e4 < cnt; e4 += (unsigned)BT * 4u) {
+                float raw[4], val[4];
+                bool mk[4];
+                const bool whole = e4 + 4u <= cnt;
+                if (whole) {
+                    if (a.raw_f16) {
+                        const u32x2 w = *reinterpret_cast<const u32x2_unaligned *>(reinterpret_cast<const _Float16 *>(a.depth) + pb + e4);
+                        raw[0] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w.x & 0xffffu)); raw[1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w.x >> 16));
+                        raw[2] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w.y & 0xffffu)); raw[3] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w.y >> 16));
+                    } else {
+                        const u32x4 w = *reinterpret_cast<const u32x4_unaligned *>(reinterpret_cast<const float *>(a.depth) + pb + e4);
+                        raw[0] = __uint_as_float(w.x); raw[1] = __uint_as_float(w.y); raw[2] = __uint_as_float(w.z); raw[3] = __uint_as_float(w.w);
+                    }
+                    const unsigned m4 = a.mask ? *reinterpret_cast<const u32_unaligned *>(a.mask + pb + e4) : 0u;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) mk[k] = a.mask ? ((m4 >> (8 * k)) & 0xffu) != 0u : (raw[k] > 0.0f);      // depth_refiner.py:238-241
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const bool in = e4 + (unsigned)k < cnt;
+                        const long long p = pb + e4 + (in ? k : 0);
+                        raw[k] = a.raw_f16 ? (float)reinterpret_cast<const _Float16 *>(a.depth)[p] : reinterpret_cast<const float *>(a.depth)[p];
+                        mk[k] = in && (a.mask ? (a.mask[p] != 0) : (raw[k] > 0.0f));
+                    }
+                }
+                ddmath::lut_grid_eval4(s_kx, s_ky, nk, grid, s_grid, raw, mk, val);          // :185-191
+                any_nan |= (val[0] != val[0]) | (val[1] != val[1]) | (val[2] != val[2]) | (val[3] != val[3]);
+                if (whole) *reinterpret_cast<float4 *>(s_val + e4) = make_float4(val[0], val[1], val[2], val[3]);
+                else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (e4 + (unsigned)k < cnt) s_val[e4 + k] = val[k];
+                }
+            }
         }
-        __syncthreads();
+        const bool tile_nan = __syncthreads_or((int)any_nan) != 0;            // (a NaN anywhere in the tile or its halo: the windows take the careful path)
         const bool smooth = vp->skip_smoothing == 0;
         float ref[CH][VEC];
+        unsigned y0g = 0u, x0g = 0u;
 #pragma unroll
         for (int ch = 0; ch < CH; ++ch) {
             const unsigned qb = qw + (unsigned)(ch * 64 + lane) * VEC;
-            unsigned y = qb / Wd, x = qb - y * Wd;
+            unsigned y, x;
+            if (ch == 0) { y0g = qb / Wd; x0g = qb - y0g * Wd; }             // (one division per lane: the lane's next group lies CSPAN pixels on)
+            else { x0g += (unsigned)CSPAN; while (x0g >= Wd) { x0g -= Wd; ++y0g; } }
+            y = y0g; x = x0g;
             unsigned b = 0;
+            // four windows of one image row, none at the left or right border, no NaN in the tile: their columns are sorted once
+            const bool fast = smooth && !tile_nan && !(a.refine_plain & 2) && VEC == 4 && qb + 4u <= a.P && x >= 1u && x + 5u <= Wd;
+            if (fast) {
+                const unsigned ym = y ? y - 1u : 0u, yp = y + 1u < Hd ? y + 1u : Hd - 1u;
+                const float *const r1 = s_val + (y * Wd + x - 1u - lo);
+                float m4[4];
+                ddmath::median9x4(s_val + (ym * Wd + x - 1u - lo), r1, s_val + (yp * Wd + x - 1u - lo), m4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float r = (r1[k + 1] != 0.0f) ? m4[k] : 0.0f;       // :203
+                    if (r > 0.0f) b |= 1u << k;
+                    ref[ch][k] = r;
+                }
+            }
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
+                if (fast) break;
                 const unsigned q = qb + (unsigned)k;
                 float r = 0.0f;
                 if (q < a.P) {
@@ -1902,6 +1971,7 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
         const bool small = (tsel == 1u || (tsel == 0u && big_tiles <= SP_SMALL_BATCH_TILES)) && !p.refine;
         p.sp_pxt = small ? SP_PXT_SMALL : L_PXT;
         a.scan_service = p.lean && ((b->tuning >> 26) & 1u) == 0u;
+        a.refine_plain = (int)((b->tuning >> 27) & 3u);
         a.static_tiles = (int)((b->tuning >> 22) & 1u);
         a.lb_lanes = wsel == 2u ? 32u : wsel == 3u ? 64u : (unsigned)LB_LANES;
         if (b->chain) {

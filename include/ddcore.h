@@ -116,7 +116,9 @@ typedef struct DDViewBatch {
                                  force the small / the large tile; bit 26 = the decoupled look-back of ABI <= 10 instead of the scan
                                  service (one workgroup of the launch scans the tiles' counts, a tile polls its own first row), with
                                  bits 20-21 = its polling lanes (0 / 1 = 16, 2 = 32, 3 = 64) and bit 22 = tiles by workgroup index
-                                 instead of by ticket.  Same rows whatever these say */
+                                 instead of by ticket; bits 27 / 28 (DD_REFINE, A/B switches) = the curve found by bisecting all
+                                 knots / one median per window, as before round 5's grid of buckets and shared sorted columns.
+                                 Same rows whatever these say */
     float *refined_out;       /* DD_REFINE: NULL, or (V,H,W) float32 receiving the refined, mask-zeroed depth -- the map the
                                  reference caches for the multi-view filter (scripts/test.py:194, 197-201) */
     int64_t *chain;           /* ABI 12: NULL, or (1) int64 device word that chains consecutive calls of ONE cloud across TWO streams, so

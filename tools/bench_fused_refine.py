@@ -10,7 +10,9 @@ sys.path.insert(0, str(ROOT))
 import bench, depthdensifier_amd as dd
 from depthdensifier_amd.depth_refiner import DepthRefiner
 
-ap = argparse.ArgumentParser(); ap.add_argument("--views", type=int, default=64); a = ap.parse_args()
+ap = argparse.ArgumentParser(); ap.add_argument("--views", type=int, default=64)
+ap.add_argument("--tuning", type=lambda x: int(x, 0), default=0, help="DDViewBatch.tuning of the fused batch (bit 27: bisect all knots, bit 28: one median per window)")
+a = ap.parse_args()
 dev = torch.device("cuda", 0)
 cfg = dict(bench.WORKLOADS["garden185"]); cfg["V"] = a.views
 ids = np.arange(a.views)
@@ -33,6 +35,7 @@ def unfused():
 
 fused_batch = dd.ViewBatch(scene["depth"], params, E, mask=scene["mask"], normal=scene["normal"], rgb=scene["rgb"], device=dev,
                            refine=[(kx, ky, False)] * V, refined_out=True)
+fused_batch.tuning = a.tuning
 def fused():
     b.reset(); b.append(fused_batch)
 
