@@ -497,6 +497,51 @@ def streaming_record(args, dd, cfg, scene, params, E, batch, builder, device, vi
     return rec
 
 
+def fused_refine_record(dd, cfg, scene, params, E, builder, device) -> dict:
+    """The call scripts/test.py's loop amounts to (:179-240: refine the raw depth with the fitted curve, then densify) as pipeline.py
+    issues it: ONE kernel (DD_REFINE: LUT + 3x3 median + validity + unprojection; the refined map written once for the filter cache).
+    The whole workload in one batch with a synthetic 500-knot curve per view; the first views are compared, bit for bit, with
+    dd_refine_apply followed by the plain call.  This stage is bound by the vector ALU (profiles/r05_fused_refine.txt), so `frac` is
+    reported as what it is -- the share of the HBM peak its own bytes amount to -- next to the plain kernel's."""
+    from depthdensifier_amd.depth_refiner import DepthRefiner
+    V, H, W = scene["depth"].shape
+    r = DepthRefiner(use_fp16=False)
+    g = torch.Generator(device=device).manual_seed(0)
+    x = torch.rand(500, device=device, generator=g) * 7 + 1
+    kx, ky = r._sorted_knots(x, 1.1 * x + 0.05 * torch.rand(500, device=device, generator=g))
+    ids = np.arange(V)
+    kw = dict(mask=scene["mask"], normal=scene["normal"], rgb=scene["rgb"], device=device)
+    fused = dd.ViewBatch(scene["depth"], params, E, refine=[(kx, ky, False)] * V, refined_out=True, **kw)
+    builder.reset(); builder.append(fused); n = builder.check()
+    ts = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(device)
+        builder.reset(); e0.record(); builder.append(fused); e1.record()
+        torch.cuda.synchronize(device)
+        ts.append(e0.elapsed_time(e1))
+    n = builder.check()
+    med = float(np.median(ts))
+    # bytes by the model of section 8d with the refined map's write added: P (depth + mask + 4) + N (rows + gathers)
+    per_point = 12 + (12 if cfg["normal"] else 0) * 2 + (3 if cfg["rgb"] else 0) * 2
+    alg = V * H * W * (scene["depth"].element_size() + 1 + 4) + n * per_point
+    k = min(V, 3)
+    small = dd.ViewBatch(scene["depth"][:k], params[:k], E[:k], refine=[(kx, ky, False)] * k, refined_out=True,
+                         **{a: (b[:k] if torch.is_tensor(b) else b) for a, b in kw.items()})
+    b2 = dd.CloudBuilder(small.max_points, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=False, device=device, placement="first")
+    b2.append(small); got = b2.finish()
+    refined = torch.stack([r._apply_curve_hip(scene["depth"][v], scene["mask"][v], kx, ky) for v in range(k)])
+    plain = dd.ViewBatch(refined, params[:k], E[:k], **{a: (b[:k] if torch.is_tensor(b) else b) for a, b in kw.items()})
+    b3 = dd.CloudBuilder(plain.max_points, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=False, device=device, placement="first")
+    b3.append(plain); want = b3.finish()
+    same = (len(got) == len(want) and torch.equal(got.points, want.points) and torch.equal(small.refined.view(torch.int32), refined.view(torch.int32))
+            and (got.normals is None or torch.equal(got.normals, want.normals)) and (got.colors is None or torch.equal(got.colors, want.colors)))
+    return {"what": "raw depth -> points in ONE kernel (DD_REFINE: transfer curve + 3x3 median fused into the densify kernel; refined map written for the filter "
+                    "cache), the whole workload in one batch, 500 knots", "ms": round(med, 4), "us_per_view": round(1e3 * med / V, 2), "points": int(n),
+            "algorithmic_bytes": int(alg), "frac": round(alg / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "bound": "valu (235 vector instructions per pixel; plain kernel: 86)",
+            "equals_refine_apply_then_plain": bool(same), "views_compared": k}
+
+
 def _cpu_worker(job):
     """One process of the all-cores courtesy baseline: the oracle over this worker's views (arrays staged as .npy in
     shared memory by the parent; only the oracle calls are timed)."""
@@ -1071,6 +1116,10 @@ def main() -> None:
         failed = failed or not sr["all_ok"]
         if rank == 0:
             line["streaming"] = sr
+        fr = fused_refine_record(dd, st["cfg"], st["scene"], st["params"], st["E"], st["builder"], device)
+        failed = failed or not fr["equals_refine_apply_then_plain"]
+        if rank == 0:
+            line["fused_refine"] = fr
 
     # BASELINE configs[2] (2000-view strong scaling: sharded / gathered / gathered-compact / Bernoulli), timed AFTER the main
     # result exists.  Doubly guarded: an exception is reported in the line; a collective that does not finish within
@@ -1155,6 +1204,10 @@ def main() -> None:
                 failed = failed or not sr["all_ok"]
                 if rank == 0:
                     rec["streaming"] = sr
+                fr = fused_refine_record(dd, sst["cfg"], sst["scene"], sst["params"], sst["E"], sst["builder"], device)
+                failed = failed or not fr["equals_refine_apply_then_plain"]
+                if rank == 0:
+                    rec["fused_refine"] = fr
             sst.clear()
             del sst
             gc.collect()
