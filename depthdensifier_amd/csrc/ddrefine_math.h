@@ -60,22 +60,10 @@ __device__ __forceinline__ unsigned short lut_grid_entry(const float *kx, int n,
     }
     return (unsigned short)lo;
 }
-__device__ __forceinline__ float lut_grid_eval(const float *kx, const float *ky, int n, const LutGrid g, const unsigned short *grid, float d) {
-    if (d != d) return d;
-    const int b = (int)fminf(fmaxf((d - g.x0) * g.inv, 0.0f), (float)(LUT_BUCKETS - 1));
-    // the answer lies between the entry of this bucket (every knot before it is < d) and the entry three buckets on (the first knot >=
-    // an edge a whole bucket above d: lower_bound is monotone) -- three buckets' worth of knots to bisect instead of all of them
-    int lo = grid[b];
-    int hi = (g.inv != 0.0f && b + 3 < LUT_BUCKETS) ? (int)grid[b + 3] : n;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (kx[mid] < d) lo = mid + 1; else hi = mid;
-    }
-    return lut_blend(kx, ky, n, d, lo);
-}
-
 // Four values at once, their bisections in lock step (the four chains of dependent LDS reads overlap; the trip count is what the
-// slowest lane of the wave needs -- two or three steps with a grid, not ten).  out[k] = 0 where !mk[k].
+// slowest lane of the wave needs -- two or three steps with a grid, not ten).  For each value the answer lies between the entry of
+// its bucket (every knot before it is < d) and the entry three buckets on (the first knot >= an edge a whole bucket above d).
+// out[k] = 0 where !mk[k].
 __device__ __forceinline__ void lut_grid_eval4(const float *kx, const float *ky, int n, const LutGrid g, const unsigned short *grid,
                                                const float (&d)[4], const bool (&mk)[4], float (&out)[4]) {
     int base[4], len[4];
