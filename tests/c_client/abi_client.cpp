@@ -98,9 +98,11 @@ int main() {
     // mode 2 writes into arrays handed out by the HBM zone arena (dd_arena_*): ordinary device pointers for every entry point
     DDArena *arena = NULL;
     void *aptr[3] = {NULL, NULL, NULL};
-    for (int mode = 0; mode < 4; ++mode) {       // 0: dd_plan + dd_scatter, 1: fused dd_unproject_compact, 2: fused, into arena arrays,
+    for (int mode = 0; mode < 5; ++mode) {       // 0: dd_plan + dd_scatter, 1: fused dd_unproject_compact, 2: fused, into arena arrays,
                                                  // 3: the reference's loop (scripts/test.py:131): ONE VIEW PER CALL, chained through one
                                                  //    cursor and one workspace that is never zeroed again (ABI 11: a call is one kernel launch)
+                                                 // 4: the same loop with consecutive calls on TWO streams (ABI 12 / 13): DDViewBatch.chain,
+                                                 //    a workspace per stream, the pair of streams probed with dd_streams_overlap first
         if (mode == 2) {
             if (dd_arena_create(0, 0, &arena) != DD_OK) { printf("dd_arena_create: %s\n", dd_arena_last_error()); return 6; }
             const int64_t sizes[3] = {(int64_t)N * 12, (int64_t)N * 12, (int64_t)N * 3};
@@ -136,6 +138,50 @@ int main() {
             if (hdr[1] != 0 || hdr[4] != 0) { printf("mode 3: workspace header after the chain: error %d, ticket %d\n", hdr[1], hdr[4]); return 4; }
             int64_t cur; CK(hipMemcpy(&cur, d_cur, 8, hipMemcpyDeviceToHost));
             if (cur != n_ref) { printf("mode 3: cursor %lld != %lld\n", (long long)cur, (long long)n_ref); return 4; }
+        } else if (mode == 4) {
+            hipStream_t side[2]; CK(hipStreamCreateWithFlags(&side[0], hipStreamNonBlocking));
+            void *d_scratch; CK(hipMalloc(&d_scratch, 8));
+            int32_t seen = 0, tried = 0;
+            std::vector<hipStream_t> spare;
+            for (; tried < 8 && !seen; ++tried) {        // the runtime may have put both streams on one hardware queue: take another second stream
+                CK(hipStreamCreateWithFlags(&side[1], hipStreamNonBlocking));
+                DD(dd_streams_overlap(side[0], side[1], (int32_t *)d_scratch, &seen));
+                if (!seen) spare.push_back(side[1]);
+            }
+            if (!seen) { printf("mode 4: no pair of streams that run side by side in 8 tries: chaining skipped\n"); }
+            else {
+                void *d_chain, *d_ws2[2]; hipEvent_t ev;
+                CK(hipMalloc(&d_chain, 8)); CK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                for (int k = 0; k < 2; ++k) { CK(hipMalloc(&d_ws2[k], (size_t)wsb)); CK(hipMemset(d_ws2[k], 0, (size_t)wsb)); }
+                for (int rep = 0; rep < 3; ++rep) {
+                    CK(hipMemsetAsync(d_cur, 0, 8, stream)); CK(hipMemsetAsync(d_chain, 0, 8, stream));      // sequence 0 starts at row 0
+                    for (int k = 0; k < 2; ++k) DD(dd_stream_fork(ev, stream, side[k]));                      // both side streams behind that
+                    for (int v = 0; v < V; ++v) {
+                        DDViewBatch one = b;
+                        one.num_views = 1; one.view_index_base = v;
+                        one.depth = (const char *)d_depth + (size_t)v * P * 4; one.mask = (const uint8_t *)d_mask + (size_t)v * P;
+                        one.normal = (const float *)d_normal + (size_t)v * P * 3; one.rgb = (const uint8_t *)d_rgb + (size_t)v * P * 3;
+                        one.params = (const DDViewParams *)d_params + v;
+                        one.chain = (int64_t *)d_chain; one.chain_seq = v;
+                        DD(dd_unproject_compact(&one, &out, (int64_t *)d_off + v, (int64_t *)d_cur, d_ws2[v & 1], wsb, side[v & 1]));
+                    }
+                    for (int k = 0; k < 2; ++k) DD(dd_stream_fork(ev, side[k], stream));                      // join: the caller's stream behind both
+                    CK(hipStreamSynchronize(stream));      // (the next repetition rewrites the chain word: dd_stream_fork may skip an idle stream, so be sure)
+                }
+                int64_t cur; CK(hipMemcpy(&cur, d_cur, 8, hipMemcpyDeviceToHost));
+                if (cur != n_ref) { printf("mode 4: cursor %lld != %lld\n", (long long)cur, (long long)n_ref); return 4; }
+                for (int k = 0; k < 2; ++k) {
+                    int32_t hdr[16]; CK(hipMemcpy(hdr, d_ws2[k], 64, hipMemcpyDeviceToHost));
+                    if (hdr[1] != 0) { printf("mode 4: error word %d in workspace %d\n", hdr[1], k); return 4; }
+                    CK(hipFree(d_ws2[k]));
+                }
+                CK(hipFree(d_chain)); CK(hipEventDestroy(ev));
+                printf("mode 4: %d views chained across two streams (%d pair(s) of streams probed)\n", V, tried);
+            }
+            for (hipStream_t sp : spare) CK(hipStreamDestroy(sp));
+            if (seen) CK(hipStreamDestroy(side[1]));
+            CK(hipStreamDestroy(side[0])); CK(hipFree(d_scratch));
+            if (!seen) DD(dd_unproject_compact(&b, &out, (int64_t *)d_off, (int64_t *)d_cur, d_ws, wsb, stream));
         } else {
             DD(dd_unproject_compact(&b, &out, (int64_t *)d_off, (int64_t *)d_cur, d_ws, wsb, stream));
         }

@@ -775,3 +775,6 @@ def test_c_abi_client_without_python(tmp_path):
     assert build.returncode == 0, build.stderr[-2000:]
     run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0 and "C ABI OK" in run.stdout, run.stdout + run.stderr
+    # round 5: the per-view loop on one stream (mode 3) and chained across two probed streams (mode 4: DDViewBatch.chain, dd_stream_fork,
+    # dd_streams_overlap) -- or, said so, not chained where no two streams of the process run side by side
+    assert "mode 3:" in run.stdout and ("chained across two streams" in run.stdout or "chaining skipped" in run.stdout), run.stdout
