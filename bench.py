@@ -466,7 +466,8 @@ def streaming_record(args, dd, cfg, scene, params, E, batch, builder, device, vi
         if not args.no_verify:
             try:
                 offs = torch.cat([builder._offsets[0]] + [o[1:] for o in builder._offsets[1:]])
-                views = sorted(set(list(range(min(V, 2))) + [V // 2, V - 1]))
+                # (1 and 8 views per call against the oracle on four views; the chains in between on two: each costs seconds of host time)
+                views = sorted(set(list(range(min(V, 2))) + [V // 2, V - 1])) if k in (1, 8) else sorted({0, V - 1})
                 v = verify_views(dd, cfg, scene, params, E, views, offs, {"points": builder.xyz, "normals": builder.normal, "colors": builder.rgb},
                                  device, view_base)
                 v["rows_total"] = total
