@@ -1107,7 +1107,10 @@ def main() -> None:
         return line, state
 
 
+    t_main = time.perf_counter()
+    phases = {}                          # wall seconds of this process's phases (what the driver's clock around the run is made of)
     line, st = run_workload(args.workload, args.steps, args.warmup, args.alloc_rounds, args.views, args.cpu_seconds)
+    phases[args.workload] = round(time.perf_counter() - t_main, 1)
     verified, strong = st["verified"], None
     failed = verified is not None and not verified.get("all_ranks_ok", True)
 
@@ -1171,6 +1174,7 @@ def main() -> None:
         from depthdensifier_amd import placement as _pl0
         _pl0.trim(device)                # spare chunks of the arena go back too: the sub-records start from an empty device
 
+    phases["strong2000"] = round(time.perf_counter() - t_main - sum(phases.values()), 1)
     # the other single-GPU configurations of BASELINE.json as sub-records of the default line (N = 1 only: every one of them is a
     # one-GPU workload; the driver's N > 1 runs measure the scaling curve of the main workload)
     subs = []
@@ -1218,8 +1222,11 @@ def main() -> None:
         if rank == 0:
             line[name] = rec
         torch.cuda.empty_cache()
+        phases[name] = round(time.perf_counter() - t_main - sum(phases.values()), 1)
 
     if rank == 0:
+        phases["total_since_main"] = round(time.perf_counter() - t_main, 1)
+        line["wall_s"] = phases
         print(json.dumps(line), file=real_out, flush=True)
         _release_line_guard(guard)
 
