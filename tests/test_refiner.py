@@ -146,6 +146,54 @@ def test_hip_apply_kernel_equals_tensor_path(shape, skip, with_mask):
     assert torch.equal(got, want)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DD_APPLY_SEEDS", "24"))))      # soak: DD_APPLY_SEEDS=1000
+def test_hip_apply_kernel_random_against_the_tensor_path(seed):
+    """dd_refine_apply against the tensor formulation on the CPU -- the independent side of the round-5 rewrite (both GPU kernels
+    share the grid look-up and the shared-column medians): random sizes (several 64x16 tiles, ragged edges), 2..2048 knots in
+    uniform / tight / clustered / narrow sets, with and without NaN (a NaN anywhere in a tile selects the careful medians),
+    +-inf, negative and zero depths, float16 / float32."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from depthdensifier_amd.depth_refiner import DepthRefiner
+    rng = np.random.default_rng(80_000 + seed)
+    g = torch.Generator().manual_seed(80_000 + seed)
+    H, W = (int(rng.integers(1, 70)), int(rng.integers(1, 300))) if rng.uniform() < 0.5 else (int(rng.integers(20, 200)), int(rng.integers(60, 200)))
+    depth = torch.rand((H, W), generator=g) * 4 + 0.2
+    depth[torch.rand((H, W), generator=g) < 0.1] = 0.0
+    flat = depth.view(-1)
+    if rng.uniform() < 0.5:
+        flat[::89] = float("nan")
+    flat[3::97] = float("inf"); flat[5::101] = -1.0; flat[7::211] = float("-inf")
+    half = bool(rng.uniform() < 0.3)
+    if half:
+        depth = depth.half().float()                      # (the kernel reads float16, the tensor path the same values as float32)
+    mask = (torch.rand((H, W), generator=g) < float(rng.uniform(0.3, 1.0))) if rng.uniform() < 0.7 else None
+    n = int(rng.choice([2, 3, 40, 500, 512, 513, 2048]))
+    x = torch.rand(n, generator=g) * 3 + 0.5
+    kind = str(rng.choice(["uniform", "uniform", "tight", "two_clusters", "narrow"]))
+    if kind == "tight":
+        x = 2.0 + 1e-4 * (x - 0.5)
+    elif kind == "two_clusters":
+        x = torch.where(torch.arange(n) % 2 == 0, 0.7 + 1e-3 * x, 3.9 + 1e-3 * x)
+    elif kind == "narrow":
+        x = 1.9 + 0.1 * x
+    y = 2.0 * x + 0.3 * torch.frac(x * 7919.0)            # a function of x: equal knots (frequent in the tight sets) carry equal values,
+    skip = bool(rng.uniform() < 0.3)                      # whichever way a sort orders them
+    r = DepthRefiner(use_fp16=False, skip_smoothing=skip)
+    d_gpu = depth.half().cuda() if half else depth.cuda()
+    got = r._apply_curve_hip(d_gpu, None if mask is None else mask.cuda(), x.cuda(), y.cuda()).cpu()
+    cpu = DepthRefiner.__new__(DepthRefiner)
+    cpu.__dict__.update(r.__dict__); cpu.device = torch.device("cpu"); cpu.dtype = torch.float32
+    m_cpu = mask if mask is not None else depth > 0
+    if int(m_cpu.sum()) < 4:
+        pytest.skip("fewer than 4 masked pixels: the tensor path takes its own branch")
+    want = cpu._apply_curve(depth.clone(), m_cpu, x, y)
+    nan = torch.isnan(want)
+    assert torch.equal(torch.isnan(got), nan)             # (a NaN is a NaN: the CPU's carries another payload)
+    assert torch.equal(got[~nan].view(torch.int32), want[~nan].view(torch.int32))
+
+
 def _tensor_fit_cpu(r, depth, pts, E, K):
     """The correspondence half as the tensor formulation evaluates it on the CPU (= the reference's op sequence, which
     the CPU golden test pins): returns z_mono, z_metric (kept, in order), counts and the scale."""
