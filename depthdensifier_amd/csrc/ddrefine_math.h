@@ -41,6 +41,7 @@ __device__ __forceinline__ float lut(const float *kx, const float *ky, int n, fl
 #define DD_LUT_BUCKETS 512          // (1024: the same speed, 1 KiB more LDS per workgroup)
 #endif
 constexpr int LUT_BUCKETS = DD_LUT_BUCKETS;
+
 struct LutGrid {
     float x0, inv;                          // bucket of d: (d - x0) * inv, clamped to [0, LUT_BUCKETS - 1]
 };
@@ -74,6 +75,7 @@ __device__ __forceinline__ void lut_grid_eval4(const float *kx, const float *ky,
         len[k] = ((g.inv != 0.0f && b + 3 < LUT_BUCKETS) ? (int)grid[b + 3] : n) - base[k];
         if (!mk[k] || d[k] != d[k]) len[k] = 0;
     }
+    // (tried: the range scanned four knots per step with independent reads instead of halved -- 20.7 against 19.6 us per view)
     while (__any((len[0] | len[1] | len[2] | len[3]) > 0)) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                  // lower_bound of d[k] in [base, base + len]
