@@ -75,7 +75,8 @@ __device__ __forceinline__ void lut_grid_eval4(const float *kx, const float *ky,
         len[k] = ((g.inv != 0.0f && b + 3 < LUT_BUCKETS) ? (int)grid[b + 3] : n) - base[k];
         if (!mk[k] || d[k] != d[k]) len[k] = 0;
     }
-    // (tried: the range scanned four knots per step with independent reads instead of halved -- 20.7 against 19.6 us per view)
+    // (tried: the range scanned four knots per step with independent reads instead of halved -- 20.7 against 19.6 us per view; the
+    //  count of knots below d built from its top bit down with wave-uniform steps, 8 instead of 13 instructions per step -- 19.8)
     while (__any((len[0] | len[1] | len[2] | len[3]) > 0)) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                  // lower_bound of d[k] in [base, base + len]
