@@ -668,7 +668,7 @@ def main() -> None:
     ap.add_argument("--n1-strong-mpix", type=float, default=0.0, help="N = 1 strong2000 sharded Mpixels/s of an earlier run: speedup_vs_n1 is computed against it")
     ap.add_argument("--views", type=int, default=0, help="override views per GPU (garden185) / total views (scene2000)")
     ap.add_argument("--pixel-index", action="store_true", help="also emit the int32 pixel index per point")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--cpu-procs", type=int, default=-1,
                     help="also time the oracle over this many processes (courtesy all-cores figure); -1 = the cores this job may use, 0/1 = skip")
     ap.add_argument("--strong-views", type=int, default=2000, help="views of the strong-scaling sub-record (BASELINE configs[2]); 0 = skip")
