@@ -360,8 +360,12 @@ def test_side_streams_are_probed_before_calls_are_chained_across_them(dd, monkey
         b.append(o)
     _equal(b.finish(), want)
     assert len(b._side) == 2 and 1 <= b.side_stream_probes <= 8
-    seen.value = 0
-    assert lib.dd_streams_overlap(b._side_raw[0], b._side_raw[1], scratch.data_ptr(), C.byref(seen)) == 0 and seen.value == 1
+    ok = False
+    for _ in range(4):                 # (the probe gives its second kernel 1 ms to start: a host thread that lost the CPU in between says 0)
+        seen.value = 0
+        assert lib.dd_streams_overlap(b._side_raw[0], b._side_raw[1], scratch.data_ptr(), C.byref(seen)) == 0
+        ok = ok or seen.value == 1
+    assert ok
     # a process in which no second stream runs beside the first: every probe says no -> the appends stay on the caller's stream
 
     class NoOverlap:
