@@ -310,7 +310,8 @@ def test_small_appends_chained_across_two_streams_write_the_same_cloud(dd, shape
             b.append(s)
             if rep == 1 and i == V // 3:
                 assert b.check() == int(want.view_offsets[i + 1])          # a check in the middle joins the streams
-        assert b._chain_seq >= V // 2 and len(b._side) == 2                 # (the calls did go through the side streams)
+        assert (b._chain_seq >= V // 2 and len(b._side) == 2) or not b.overlap_small      # (the calls did go through the side streams -- unless
+                                                                                           #  the probe found no two streams that run side by side)
         _equal(b.finish(), want)
     # a large batch between small ones: joins, runs on the caller's stream, and the chain starts again behind it
     b.reset()
@@ -359,6 +360,9 @@ def test_side_streams_are_probed_before_calls_are_chained_across_them(dd, monkey
     for o in ones:
         b.append(o)
     _equal(b.finish(), want)
+    if not b._side:
+        assert b.side_stream_probes == 8 and b.overlap_small is False
+        pytest.skip("no two streams of this process run side by side: nothing was chained")
     assert len(b._side) == 2 and 1 <= b.side_stream_probes <= 8
     ok = False
     for _ in range(4):                 # (the probe gives its second kernel 1 ms to start: a host thread that lost the CPU in between says 0)
