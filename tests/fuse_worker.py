@@ -47,14 +47,20 @@ def main():
         assert a.shape == b.shape, (what, a.shape, b.shape)
         assert torch.equal(a.view(torch.uint8) if a.dtype.is_floating_point else a, b.view(torch.uint8) if b.dtype.is_floating_point else b), what
 
+    def stage(what):                       # (how far this rank got, should it die: tests/test_fuse_gpu.py)
+        torch.cuda.synchronize()
+        print(f"rank {rank}: stage {what} done", file=sys.stderr, flush=True)
+
+    stage("whole scene on this rank")
     for chunks in (1, 3, 20):
         cloud, plan = D.fuse_replicated(batch, V, pixel_index=True, view_index=True, chunks=chunks)
         torch.cuda.synchronize()
+        stage(f"rows, chunks={chunks}")
         assert plan.total_points == len(full) and torch.equal(cloud.view_offsets, full.view_offsets)
         for name in ("points", "colors", "normals", "pixel_index", "view_index"):
             same(getattr(cloud, name), getattr(full, name), f"rows, chunks={chunks}, {name}")
     cloud, plan = D.fuse_replicated(batch, V, record="xyz_rgba", chunks=2)
-    torch.cuda.synchronize()
+    stage("xyz_rgba")
     same(cloud.packed, full_packed.packed, "xyz_rgba record")
     same(cloud.points.contiguous(), full.points, "xyz_rgba points view")
     same(cloud.colors.contiguous(), full.colors, "xyz_rgba colours view")
@@ -72,7 +78,7 @@ def main():
     if p2p and world > 1:                                                     # gather-to-owner needs send/recv (gloo: host-staged)
         owner = world - 1
         cloud, plan = D.fuse_replicated(batch, V, record="xyz_rgba", chunks=2, dst=owner)
-        torch.cuda.synchronize()
+        stage("gather-to-owner")
         if rank == owner:
             same(cloud.packed, full_packed.packed, "gather-to-owner")
         else:
