@@ -149,11 +149,17 @@ class _PinnedRing:
         self._bufs: list = []
         self._events: list = []
         self._next = 0
+        import threading
+        self._lock = threading.Lock()        # (clouds are built from several threads: tests/test_streaming_calls.py, the batch driver)
 
     def upload(self, arr: np.ndarray, device: torch.device) -> torch.Tensor:
         arr = np.ascontiguousarray(arr)
         if arr.nbytes == 0 or arr.nbytes > self.nbytes:
             return torch.from_numpy(arr).to(device)
+        with self._lock:
+            return self._upload(arr, device)
+
+    def _upload(self, arr: np.ndarray, device: torch.device) -> torch.Tensor:
         if not self._bufs:
             # one page-locked block for all slots (a pinned allocation costs ~0.3 ms whatever its size)
             block = torch.empty(self.slots * self.nbytes, dtype=torch.uint8, pin_memory=True)
