@@ -92,7 +92,8 @@ constexpr int PSTRIDE = PHW + 1;             // LDS row stride (67 words: rows s
 
 __global__ __launch_bounds__(256) void refine_apply_tiles(const RArgs a, const int tiles_x, const int tiles) {
     __shared__ float s_val[PHH * PSTRIDE];
-    __shared__ float s_kx[MAX_LDS_KNOTS], s_ky[MAX_LDS_KNOTS];
+    extern __shared__ float s_knots[];                 // 2 n floats: the workgroup's LDS follows the number of knots (more workgroups per CU)
+    float *const s_kx = s_knots, *const s_ky = s_knots + a.n;
     __shared__ unsigned short s_grid[ddmath::LUT_BUCKETS];
     const int tid = threadIdx.x;
     for (int i = tid; i < a.n; i += 256) { s_kx[i] = a.kx[i]; s_ky[i] = a.ky[i]; }
@@ -395,9 +396,9 @@ int dd_refine_apply(const void *depth, int32_t depth_dtype, const uint8_t *mask,
     static const bool plain = [] { const char *e = getenv("DD_REFINE_APPLY_PLAIN"); return e && e[0] == '1'; }();
     if (n_knots <= MAX_LDS_KNOTS && !plain) {
         const int tiles_x = (width + PW - 1) / PW, tiles = tiles_x * ((height + PH - 1) / PH);
-        static const int max_wgs = [] { const char *e = getenv("DD_REFINE_APPLY_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1536; }();
+        static const int max_wgs = [] { const char *e = getenv("DD_REFINE_APPLY_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4096; }();
         const int wgs = tiles < max_wgs ? tiles : max_wgs;     // (the knots and their grid are built once per workgroup)
-        hipLaunchKernelGGL(refine_apply_tiles, dim3(wgs), dim3(256), 0, (hipStream_t)stream, a, tiles_x, tiles);
+        hipLaunchKernelGGL(refine_apply_tiles, dim3(wgs), dim3(256), (size_t)n_knots * 2 * sizeof(float), (hipStream_t)stream, a, tiles_x, tiles);
     } else {
         const dim3 grid((width + TW - 1) / TW, (height + TH - 1) / TH);
         hipLaunchKernelGGL(refine_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
