@@ -646,6 +646,65 @@ def _release_line_guard(guard) -> None:
         pass
 
 
+def launch_ranks(n: int, argv, grace_s: float = 15.0) -> int:
+    """Start ``n`` ranks of ``python argv...`` on this node, one fresh process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+    their environment, exactly what ``python -m torch.distributed.run --nnodes=1 --nproc-per-node n`` hands its workers), wait for
+    them and return 0 only if every one of them did.  The caller must not have initialised the GPU: the children are started with
+    ``subprocess`` (fork + exec of a process that holds no GPU state), never by replacing a running program.  When a rank fails the
+    others get ``grace_s`` seconds to notice (a collective that errors out), then SIGTERM, then SIGKILL -- by PID, nothing else.
+    stdout is shared with the children: rank 0 prints the ONE result line, every other rank sends its stdout to stderr itself."""
+    import signal
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    if "MASTER_PORT" not in env:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            env["MASTER_PORT"] = str(s.getsockname()[1])
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs between processes on these hosts
+    env.setdefault("OMP_NUM_THREADS", "1")                 # (as torchrun does: N ranks must not each take every core)
+    env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    sys.stdout.flush()
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=dict(env, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")))
+
+    def forward(signum, _frame):                            # the driver's time-out reaches the ranks too
+        for p in procs:
+            if p.poll() is None:
+                p.send_signal(signum)
+    old = {s: signal.signal(s, forward) for s in (signal.SIGTERM, signal.SIGINT)}
+    try:
+        failed_at = None
+        while any(p.poll() is None for p in procs):
+            time.sleep(0.05)
+            bad = [p for p in procs if p.poll() not in (None, 0)]
+            if bad and failed_at is None:
+                failed_at = time.monotonic()
+                print(f"[bench] rank {procs.index(bad[0])} exited with {bad[0].returncode}; the other ranks get {grace_s:.0f} s", file=sys.stderr, flush=True)
+            if failed_at is not None and time.monotonic() - failed_at > grace_s:
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                t_kill = time.monotonic() + 10.0
+                while any(p.poll() is None for p in procs) and time.monotonic() < t_kill:
+                    time.sleep(0.05)
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+                for p in procs:
+                    p.wait()
+    finally:
+        for s, h in old.items():
+            signal.signal(s, h)
+    codes = [p.returncode for p in procs]
+    if any(codes):
+        print(f"[bench] rank exit codes {codes}", file=sys.stderr, flush=True)
+        return next((c for c in codes if 0 < c < 256), 1)      # (a rank's own exit code; ranks ended by a signal have negative ones)
+    return 0
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -691,10 +750,11 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # launched plainly (`python bench.py --gpus N`): this process -- which has not touched the GPU and never will -- starts the N
+        # ranks as fresh children, one per GPU, and leaves with their verdict; rank 0's single line goes straight to the shared stdout
+        sys.exit(launch_ranks(args.gpus, [str(Path(__file__).resolve())] + sys.argv[1:]))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with: python -m torch.distributed.run --nnodes=1 "
-                     "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         args.gpus = world
     explicit = args.workload is not None
     if args.workload is None:

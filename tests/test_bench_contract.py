@@ -99,6 +99,25 @@ def test_two_ranks_sharing_the_gpu():
     assert s["gathered"]["bytes_received_per_rank"] > 0 and s["verified"]["all_ranks_ok"]
 
 
+def test_plain_launch_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with no launcher in front of it (the shape of the driver's 1-GPU command) starts
+    its two ranks itself and prints ONE line with n_gpus 2.  CPU twin of the launcher: tests/test_bench_launcher.py."""
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--views", "8", "--strong-views", "9",
+           "--strong-steps", "1", "--chunks", "2", "--alloc-rounds", "0"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    out = subprocess.run(cmd, cwd=ROOT, env=dict(env, DD_BENCH_SHARE_GPU="1"), capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout[:500]
+    line = json.loads(lines[0])
+    _check(line, 2, 2, 1)
+    assert line["config"]["workload"] == "scene2000" and line["scaling"] == "strong" and line["rccl_world_size"] == 2
+    assert line["verified"]["all_ranks_ok"] and line["strong2000"]["verified"]["all_ranks_ok"]
+
+
 def test_weak_scaling_variant_still_runs_on_two_ranks():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29657", "bench.py", "--gpus", "2", "--workload", "garden185", "--steps", "2", "--warmup", "1", "--views", "4",

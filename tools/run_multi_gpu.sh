@@ -5,7 +5,7 @@
 #      scene, strong scaling, chunks 5, grouped send/recv, every rank receives) and the sweep chunks {1,5,10} x DD_ALLGATHERV
 #      {p2p,broadcast} x gather-dst {all,0};
 #   3. one rocprofv3 --kernel-trace --memory-copy-trace of rank 0 at the largest N (the program directly after `--`).
-# Results: profiles/r05_scale_*.json (one bench line each), profiles/r05_scale_summary.txt, profiles/r05_scale_rank0_trace_*.csv.
+# Results: profiles/$TAG_scale_*.json (one bench line each), profiles/$TAG_scale_summary.txt, profiles/$TAG_scale_rank0_trace_*.csv (TAG defaults to r06).
 #   usage: tools/run_multi_gpu.sh [outdir]          (run from the repo root)
 set -uo pipefail
 R=$(cd "$(dirname "$0")/.." && pwd)
@@ -24,7 +24,8 @@ if [ "$REHEARSE" = 1 ]; then
   SMALL="--views 8 --strong-views 8 --strong-steps 1 --steps 2 --warmup 1"
 fi
 if [ "$NGPU" -lt 2 ]; then echo "needs at least 2 GPUs"; exit 2; fi
-SUM="$OUT/r05_scale_summary.txt"
+TAG=${TAG:-r06}
+SUM="$OUT/${TAG}_scale_summary.txt"
 : > "$SUM"
 
 echo "== 1. RCCL tests" | tee -a "$SUM"
@@ -36,14 +37,10 @@ line() {   # line <tag> <N> <env assignments...> -- <bench args...>
   local tag=$1 n=$2; shift 2
   local envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
   local port=$((29800 + RANDOM % 150))
-  if [ "$n" -eq 1 ]; then
-    env "${envs[@]}" timeout -k 10 900 python3 bench.py --gpus 1 "$@" > "$OUT/r05_scale_$tag.json" 2> "$OUT/r05_scale_$tag.err"
-  else
-    env "${envs[@]}" timeout -k 10 900 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node "$n" --master-addr 127.0.0.1 --master-port "$port" \
-        bench.py --gpus "$n" "$@" > "$OUT/r05_scale_$tag.json" 2> "$OUT/r05_scale_$tag.err"
-  fi
+  # one entry at every N: bench.py starts its own ranks when it is launched plainly (bench.launch_ranks) -- the driver's command shape
+  env "${envs[@]}" MASTER_PORT="$port" timeout -k 10 900 python3 bench.py --gpus "$n" "$@" > "$OUT/${TAG}_scale_$tag.json" 2> "$OUT/${TAG}_scale_$tag.err"
   local rc=$?
-  python3 - "$OUT/r05_scale_$tag.json" "$tag" "$rc" <<'PY' | tee -a "$SUM"
+  python3 - "$OUT/${TAG}_scale_$tag.json" "$tag" "$rc" <<'PY' | tee -a "$SUM"
 import json, sys
 try:
     d = json.load(open(sys.argv[1]))
@@ -59,7 +56,7 @@ PY
 
 echo "== 2. bench lines" | tee -a "$SUM"
 line n1 1 -- --workload scene2000 --cpu-seconds 0 --alloc-rounds 0 $SMALL
-N1=$(python3 -c "import json; print(json.load(open('$OUT/r05_scale_n1.json'))['value'])" 2>/dev/null || echo 0)
+N1=$(python3 -c "import json; print(json.load(open('$OUT/${TAG}_scale_n1.json'))['value'])" 2>/dev/null || echo 0)
 NS=""; for n in 2 4 8; do [ "$n" -le "$NGPU" ] && NS="$NS $n"; done
 for n in $NS; do
   line "n${n}_default" "$n" -- --n1-strong-mpix "$N1" $SMALL
@@ -76,11 +73,11 @@ export TMPDIR=/tmp
 # rank 0 runs under the profiler (the program directly after `--`), the other ranks plainly: one launcher per rank, no re-exec
 PORT=$((29950 + RANDOM % 40))
 for r in $(seq 1 $((NMAX - 1))); do
-  RANK=$r LOCAL_RANK=$r WORLD_SIZE=$NMAX MASTER_ADDR=127.0.0.1 MASTER_PORT=$PORT timeout -k 10 600 python3 bench.py --gpus "$NMAX" --steps 5 --warmup 2 --alloc-rounds 0 > /dev/null 2> "$OUT/r05_scale_trace_rank$r.err" &
+  RANK=$r LOCAL_RANK=$r WORLD_SIZE=$NMAX MASTER_ADDR=127.0.0.1 MASTER_PORT=$PORT timeout -k 10 600 python3 bench.py --gpus "$NMAX" --steps 5 --warmup 2 --alloc-rounds 0 > /dev/null 2> "$OUT/${TAG}_scale_trace_rank$r.err" &
 done
 ( cd /tmp && RANK=0 LOCAL_RANK=0 WORLD_SIZE=$NMAX MASTER_ADDR=127.0.0.1 MASTER_PORT=$PORT timeout -k 10 600 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv \
-    -d /tmp/r05_scale_trace -- python3 "$R/bench.py" --gpus "$NMAX" --steps 5 --warmup 2 --alloc-rounds 0 > "$OUT/r05_scale_trace_rank0.json" 2> "$OUT/r05_scale_trace_rank0.err" )
+    -d /tmp/${TAG}_scale_trace -- python3 "$R/bench.py" --gpus "$NMAX" --steps 5 --warmup 2 --alloc-rounds 0 > "$OUT/${TAG}_scale_trace_rank0.json" 2> "$OUT/${TAG}_scale_trace_rank0.err" )
 wait
-for f in $(find /tmp/r05_scale_trace -name "*_kernel_stats.csv" -o -name "*_memory_copy_stats.csv" 2>/dev/null); do cp "$f" "$OUT/r05_scale_rank0_trace_$(basename "$f" | sed 's/^[0-9]*_//')"; done
-python3 tools/kernel_trace_groups.py /tmp/r05_scale_trace "$OUT/r05_scale_rank0_kernel_groups.csv" "rank 0 of $NMAX, bench.py --gpus $NMAX --steps 5 --warmup 2" > /dev/null 2>&1 || true
+for f in $(find /tmp/${TAG}_scale_trace -name "*_kernel_stats.csv" -o -name "*_memory_copy_stats.csv" 2>/dev/null); do cp "$f" "$OUT/${TAG}_scale_rank0_trace_$(basename "$f" | sed 's/^[0-9]*_//')"; done
+python3 tools/kernel_trace_groups.py /tmp/${TAG}_scale_trace "$OUT/${TAG}_scale_rank0_kernel_groups.csv" "rank 0 of $NMAX, bench.py --gpus $NMAX --steps 5 --warmup 2" > /dev/null 2>&1 || true
 echo "done; summary in $SUM"
