@@ -257,7 +257,7 @@ class PendingCheck:
     def __init__(self, builder: "CloudBuilder", key: int, slot: torch.Tensor, nws: int, workspaces: list, event, late=()):
         self._b, self._key, self._slot, self._nws, self._ws, self._event, self._late = builder, key, slot, nws, workspaces, event, list(late)
         self._epoch = builder._epoch                 # reset() since then: the cloud asked about is no longer the builder's
-        self._retained_then = len(builder._retained)        # the batches this check covers ...
+        self._retained_then = builder._released + len(builder._retained)      # the batches this check covers, counted since the last reset() (released ones included) ...
         self._appends_then = builder._appends                # ... (all of them, if nothing was appended since)
         self._guesses_then = builder._guesses_pending
         self._done = False
@@ -282,6 +282,7 @@ class PendingCheck:
         stale = b._epoch != self._epoch
         if bad:
             dense_miss = any(code == 2 for _, code in words)          # (2: a batch run as 'assume dense' was not)
+            b._join_side()                                # chained calls may still run on the side streams: nothing of a workspace is wiped under them
             for w in bad:
                 w.zero_()                                 # sticky word: cleared only here, once seen -- and with it the whole workspace:
                                                           # after a give-up the single-pass state (epoch, granules) is not to be trusted
@@ -293,7 +294,7 @@ class PendingCheck:
             if not heal:
                 raise RuntimeError(f"libddcore: {what} (workspace error word set); rows are invalid -- append the batches again with tuning=4")
             total = b._heal(dense_miss=dense_miss)
-            self._retained_then, self._appends_then, self._guesses_then = len(b._retained), b._appends, 0      # the redo covered everything held
+            self._retained_then, self._appends_then, self._guesses_then = b._released + len(b._retained), b._appends, 0      # the redo covered everything held
         if total > b.capacity:
             raise OverflowError(f"cloud capacity {b.capacity} < {total} valid points; "
                                 "allocate with capacity=batch.max_points or count_valid() first")
@@ -688,6 +689,7 @@ class CloudBuilder:
         self._retain_limit = torch.cuda.mem_get_info(dev)[0] // 4
         self._retain_complete = True
         self._retain_base: Optional[int] = None      # row the retained batches start from (None: the cloud's start)
+        self._released = 0                           # retained batches released since the last reset(): checks count in absolute numbers
         self._epoch = 0                              # counts reset(): a PendingCheck knows which cloud it was asked about
         self.healed = 0
         self._guesses_pending = 0
@@ -790,6 +792,7 @@ class CloudBuilder:
         self._retained_bytes = 0
         self._retain_complete = True
         self._retain_base = None
+        self._released = 0
 
     def _retain_cost(self, batch: "ViewBatch") -> int:
         """Bytes of maps that holding ``batch`` for a redo keeps alive beyond what is held already."""
@@ -857,6 +860,7 @@ class CloudBuilder:
             self._appends += 1
         if batch.num_views == 0:                       # an empty chunk of views: nothing to enqueue, the cursor stays
             offsets = _offsets if redo else self._offsets_slice(1)
+            self._join_side()                          # (chained calls on the side streams advance the cursor: read it behind them)
             offsets.copy_(self.cursor, non_blocking=True)
             if not redo:
                 self._offsets.append(offsets)
@@ -1012,9 +1016,12 @@ class CloudBuilder:
 
     def _release_retained(self, total: int, covered: Optional[int] = None, appends_then: Optional[int] = None) -> None:
         """Everything a check covered is final: those batches (and their maps) need not be held any longer, a later redo starts
-        behind them.  ``covered`` / ``appends_then``: how many retained batches / append() calls the check saw; batches appended
-        after it stay held (or stay not held, if retention had given up by then) -- the check says nothing about them."""
+        behind them.  ``covered``: how many batches had been retained since the last reset() when the check was asked for -- an
+        ABSOLUTE count (released ones included: several checks may be in flight, and the one read first shifts the list under the
+        others); ``appends_then``: the append() calls the check saw.  Batches appended after the check stay held (or stay not held,
+        if retention had given up by then) -- the check says nothing about them."""
         if appends_then is None or appends_then == self._appends:
+            self._released += len(self._retained)
             self._retained.clear()                    # nothing was appended since: the whole cloud so far is final
             self._retained_bytes = 0
             self._retain_complete = True
@@ -1022,7 +1029,11 @@ class CloudBuilder:
             return
         if not self._retain_complete:
             return                                    # batches behind the check are not held: a redo of them stays impossible
-        del self._retained[:covered]
+        k = covered - self._released                  # of the batches this check covers, those still held
+        if k <= 0:
+            return                                    # a later check was read first: it released them all and moved the base beyond
+        del self._retained[:k]
+        self._released += k
         self._retained_bytes = sum(e[3] for e in self._retained)
         self._retain_base = total                     # the row the first batch behind the check starts from
 
@@ -1042,6 +1053,7 @@ class CloudBuilder:
 
     def _scan_gave_up(self) -> bool:
         bad = False
+        self._join_side()                                    # (never wipe a workspace under a chained call that still runs)
         for ws in {id(w): w for w in self._workspaces}.values():
             if int(ws[:8].view(torch.int32)[1].item()) != 0:
                 ws.zero_()                                   # sticky word: cleared only here, once seen (the whole workspace, as above)

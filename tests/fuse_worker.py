@@ -35,8 +35,15 @@ def main():
     d["mask"][min(3, V - 1)] = False                                          # an empty view
     params = np.tile([150.0, 152.0, 100.0, 60.0], (V, 1))
     kw = dict(mask=d["mask"], normal=d["normal"], rgb=d["rgb"])
+    def stage(what):                       # (how far this rank got, should it die: tests/test_fuse_gpu.py)
+        torch.cuda.synchronize()
+        print(f"rank {rank}: stage {what} done", file=sys.stderr, flush=True)
+
+    stage("start")
     full = dd.unproject_views(d["depth"], params, d["cam_from_world"], view_index=True, **kw)
+    stage("whole scene, rows")
     full_packed = dd.unproject_views(d["depth"], params, d["cam_from_world"], record="xyz_rgba", pixel_index=False, **kw)
+    stage("whole scene, records")
 
     lo, hi = D.shard_views(V, world, rank)
     cut = lambda a: a[lo:hi]
@@ -47,11 +54,7 @@ def main():
         assert a.shape == b.shape, (what, a.shape, b.shape)
         assert torch.equal(a.view(torch.uint8) if a.dtype.is_floating_point else a, b.view(torch.uint8) if b.dtype.is_floating_point else b), what
 
-    def stage(what):                       # (how far this rank got, should it die: tests/test_fuse_gpu.py)
-        torch.cuda.synchronize()
-        print(f"rank {rank}: stage {what} done", file=sys.stderr, flush=True)
-
-    stage("whole scene on this rank")
+    stage("own batch on the device")
     for chunks in (1, 3, 20):
         cloud, plan = D.fuse_replicated(batch, V, pixel_index=True, view_index=True, chunks=chunks)
         torch.cuda.synchronize()

@@ -245,6 +245,41 @@ def test_more_checks_in_flight_than_the_ring_had_slots(dd):
     assert [p.result() for p in pending] == [n1 * (i + 1) for i in range(300)]
 
 
+@pytest.mark.parametrize("order", ("A then B", "B then A"))
+def test_two_checks_in_flight_release_only_what_each_covers(dd, orc, order):
+    """check A covers 2 batches, check B covers 4, two more are appended; A and B are read (in either order); then a later
+    batch faults (injection, tuning bit 64) and is healed: the redo must start at the row behind batch 4, from batches 5.. only --
+    the cloud equals the one-batch cloud.  (Round 5 counted a check's batches relative to a list the other check had shifted.)"""
+    import torch
+    V, H, W = 9, 48, 112
+    depth, mask, normal, rgb, params, E = _case(47, V, H, W)
+    want = dd.unproject_views(depth, params, E, mask=mask, normal=normal, rgb=rgb)
+    one = lambda v, tuning=0, n=1: dd.ViewBatch(depth[v:v + n], params[v:v + n], E[v:v + n], mask=mask[v:v + n], normal=normal[v:v + n],
+                                                rgb=rgb[v:v + n], view_index_base=v, tuning=tuning)
+    b = dd.CloudBuilder(V * H * W, normals=True, colors=True, placement="first")
+    offs = want.view_offsets.tolist()
+    for v in (0, 1):
+        b.append(one(v))
+    A = b.check_async()
+    for v in (2, 3):
+        b.append(one(v))
+    B = b.check_async()
+    for v in (4, 5):
+        b.append(one(v))
+    if order == "A then B":
+        assert A.result() == offs[2] and len(b._retained) == 4 and b._retain_base == offs[2]
+        assert B.result() == offs[4]
+    else:
+        assert B.result() == offs[4] and len(b._retained) == 2 and b._retain_base == offs[4]
+        assert A.result() == offs[2]                     # the older answer, read late: releases nothing more, moves nothing back
+    assert len(b._retained) == 2 and b._retain_base == offs[4] and b._released == 4
+    b.append(one(6, tuning=64, n=2))                      # an in-kernel scan gives up here (two tiles: the second one's row is "unknown") ...
+    b.append(one(8))
+    cloud = b.finish()                                    # ... and the redo replays the batches of views 4..8 from the row behind view 3
+    assert b.healed == 1
+    _equal(cloud, want)
+
+
 def test_no_guess_without_a_way_back_and_policies_are_the_callers(dd):
     """A batch is run count-free ("no holes") only if the builder will hold it for the redo a miss needs; the score of the guesses
     lives in an object the caller owns -- two builders in two threads, each with its own, do not see each other's misses."""
