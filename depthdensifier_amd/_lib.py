@@ -21,7 +21,7 @@ import torch  # noqa: F401  (load order, see above)
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("DDCORE_LIB", _HERE / "libddcore.so"))
 
-DD_ABI_VERSION = 13
+DD_ABI_VERSION = 14
 DD_OK = 0
 DD_F32, DD_F16 = 0, 1
 DD_VALID_DEPTH_POSITIVE = 0x1
@@ -30,7 +30,7 @@ DD_VALID_CONF = 0x4
 DD_ROTATE_NORMALS = 0x8
 DD_REFINE = 0x10
 
-#: every symbol include/ddcore.h declares
+#: every symbol include/ddcore.h declares (and, last, the two of include/ddcore_lab.h: the experiment switches of tests and A/B tools)
 EXPORTS = (
     "dd_abi_version",
     "dd_last_error",
@@ -41,6 +41,7 @@ EXPORTS = (
     "dd_unproject_compact",
     "dd_stream_fork",
     "dd_streams_overlap",
+    "dd_chain_workgroup_limit",
     "dd_floater_votes",
     "dd_filter_last_error",
     "dd_votes_workspace_bytes",
@@ -63,7 +64,10 @@ EXPORTS = (
     "dd_arena_stats",
     "dd_arena_destroy",
     "dd_arena_last_error",
+    "dd_debug_tuning",
+    "dd_debug_plan",
 )
+LAB_EXPORTS = ("dd_debug_tuning", "dd_debug_plan")
 
 
 class DDViewBatch(C.Structure):
@@ -123,8 +127,27 @@ class DDFilterViews(C.Structure):
 
 DD_ARENA_ROTATED = 8
 DD_ARENA_BLOCKED = 16
-DD_TUNE_ASSUME_DENSE = 1 << 17      # DDViewBatch.tuning: count-free plan, verified by the scatter pass (include/ddcore.h)
-DD_TUNE_BY_INDEX = 1 << 22          # DDViewBatch.tuning: single-pass tiles taken by workgroup index, not by ticket (the caller has the GPU to itself)
+# DDViewBatch.tuning (include/ddcore.h): what a caller may choose
+DD_TUNE_GENERIC, DD_TUNE_TWO_PASS, DD_TUNE_SINGLE_PASS, DD_TUNE_DENSE_TILES = 1, 4, 8, 128
+DD_TUNE_INTERLEAVE_MASK = 63 << 8
+DD_TUNE_ASSUME_DENSE = 1 << 17      # count-free plan, verified by the scatter pass
+DD_TUNE_TILE_SMALL, DD_TUNE_TILE_LARGE = 1 << 18, 3 << 18
+DD_TUNE_BY_INDEX = 1 << 22          # single-pass tiles taken by workgroup index, not by ticket (the caller has the GPU to itself)
+DD_TUNE_ALL = (DD_TUNE_GENERIC | DD_TUNE_TWO_PASS | DD_TUNE_SINGLE_PASS | DD_TUNE_DENSE_TILES | DD_TUNE_INTERLEAVE_MASK | DD_TUNE_ASSUME_DENSE
+               | DD_TUNE_TILE_LARGE | DD_TUNE_BY_INDEX)
+
+
+def DD_TUNE_INTERLEAVE(k: int) -> int:
+    return ((int(k) - 1) & 63) << 8
+
+
+# include/ddcore_lab.h: the thread-local experiment switches (tests, A/B tools) -- never set by the product path
+DD_LAB_LIST_ORDER, DD_LAB_FAULT_INJECT, DD_LAB_POLL_LANES_32, DD_LAB_POLL_LANES_64 = 1, 2, 4, 8
+DD_LAB_LOOKBACK, DD_LAB_REFINE_BISECT, DD_LAB_REFINE_MEDIAN9, DD_LAB_APPLY_PLAIN = 16, 32, 64, 128
+
+
+def DD_LAB_APPLY_WGS(n: int) -> int:
+    return (int(n) & 0x1FFF) << 8
 
 
 class DDArenaStats(C.Structure):
@@ -179,6 +202,12 @@ def _load() -> C.CDLL:
     lib.dd_stream_fork.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.dd_streams_overlap.restype = C.c_int
     lib.dd_streams_overlap.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+    lib.dd_chain_workgroup_limit.restype = C.c_int32
+    lib.dd_chain_workgroup_limit.argtypes = []
+    lib.dd_debug_tuning.restype = C.c_uint32
+    lib.dd_debug_tuning.argtypes = [C.c_uint32]
+    lib.dd_debug_plan.restype = C.c_int
+    lib.dd_debug_plan.argtypes = [C.POINTER(DDViewBatch), C.POINTER(C.c_int32)]
     lib.dd_floater_votes.restype = C.c_int
     lib.dd_floater_votes.argtypes = [C.POINTER(DDFilterViews), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]
     lib.dd_votes_workspace_bytes.restype = C.c_int64
@@ -239,3 +268,21 @@ def check(rc: int) -> int:
     if rc < 0:
         raise DDCoreError(int(rc), lib.dd_last_error().decode("utf-8", "replace"))
     return rc
+
+
+class lab_switches:
+    """``with lab_switches(bits):`` -- the library calls this thread makes inside run with the experiment switches of
+    ``include/ddcore_lab.h`` (``DD_LAB_*``); zero bits cost nothing.  Tests and A/B tools only."""
+
+    def __init__(self, bits: int):
+        self.bits = int(bits)
+
+    def __enter__(self):
+        if self.bits:
+            self._before = lib.dd_debug_tuning(self.bits)
+        return self
+
+    def __exit__(self, *exc):
+        if self.bits:
+            lib.dd_debug_tuning(self._before)
+        return False

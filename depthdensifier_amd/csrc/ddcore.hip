@@ -27,7 +27,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "ddcore.h"
+#include "ddcore_lab.h"
 #include "ddrefine_math.h"
 
 namespace {
@@ -1871,23 +1874,55 @@ int fail(int code, const char *msg) {
     return code;
 }
 
-// DDViewBatch.tuning bits (0 = defaults)
-constexpr unsigned TUNE_FORCE_GENERIC = 1u;   // scalar kernels even on aligned stride-1 maps (testing)
-constexpr unsigned TUNE_TWO_PASS = 4u;        // dd_unproject_compact: plan + scatter even on the lean path
-constexpr unsigned TUNE_SINGLE_PASS = 8u;     // dd_unproject_compact: ticket + decoupled look-back (default on the lean path)
-constexpr unsigned TUNE_ASSUME_DENSE = 1u << 17;   // dd_unproject_compact, lean path: scatter against a count-free plan, verified by the scatter
+// DDViewBatch.tuning bits (0 = defaults): the caller's choices, DD_TUNE_* of ddcore.h
+constexpr unsigned TUNE_FORCE_GENERIC = DD_TUNE_GENERIC;     // scalar kernels even on aligned stride-1 maps
+constexpr unsigned TUNE_TWO_PASS = DD_TUNE_TWO_PASS;          // dd_unproject_compact: plan + scatter even on the lean path
+constexpr unsigned TUNE_SINGLE_PASS = DD_TUNE_SINGLE_PASS;    // dd_unproject_compact: the single-pass kernel (default on the lean path)
+constexpr unsigned TUNE_ASSUME_DENSE = DD_TUNE_ASSUME_DENSE;  // dd_unproject_compact, lean path: scatter against a count-free plan, verified by the scatter
 
+// The experiment switches (ddcore_lab.h): a thread-local word, zero unless a test or an A/B tool has set it on this thread.
+thread_local uint32_t g_lab = 0u;
+
+// (every member has an initialiser, and make_plan starts from Plan{}: up to round 5 `chain_gate` was written for chained calls only, an
+// unchained call read whatever its caller's stack held there, and a non-zero byte launched the gate kernel with a NULL chain word --
+// the rare "Memory access fault ... address (nil)" of the three-rank rehearsal; tests/c_client/plan_stack_test.cpp)
 struct Plan {
-    bool refine;    // DD_REFINE: the fused refine stage (single-pass lean kernel, float32)
-    bool f16;
-    bool lean;      // stride-1 maps (any size >= one vector) -> lean kernels; otherwise the generic scalar kernels
-    bool single;    // dd_unproject_compact runs the single-pass kernel
-    int tile;
-    int sp_pxt;     // lean single-pass kernel: pixels per lane (the tile is SP_WAVES * 64 * sp_pxt pixels)
-    bool chain_gate;  // a chained call too large to wait inside its own workgroups: chain_gate runs in front of it
+    bool refine = false;    // DD_REFINE: the fused refine stage (single-pass lean kernel, float32)
+    bool f16 = false;
+    bool lean = false;      // stride-1 maps (any size >= one vector) -> lean kernels; otherwise the generic scalar kernels
+    bool single = false;    // dd_unproject_compact runs the single-pass kernel
+    int tile = 0;
+    int sp_pxt = 0;         // lean single-pass kernel: pixels per lane (the tile is SP_WAVES * 64 * sp_pxt pixels)
+    bool chain_gate = false;  // a chained call too large to wait inside its own workgroups: chain_gate runs in front of it
 };
 
+// Workgroups an UNGATED chained call may have: three quarters of the slots the current device offers the instantiation such a call
+// runs with (12 waves, 8 pixels per lane; the variant with the most registers), from the runtime's occupancy calculator and the
+// device's CU count -- a partitioned GPU (CPX: 32 CUs) or another build setting (DD_LEAN_WGS, DD_SP_WAVES) moves the limit with
+// it.  A device property, looked up once per device; 0 = unknown: every chained call is gated.
+unsigned chain_wg_limit() {
+    static std::atomic<int> cache[64];               // per device ordinal: 0 = not looked up yet, -1 = unknown, else the limit
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 0u; }
+    int v = cache[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        int cus = 0, per_cu = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess
+            || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, compact_lean<float, true, true, true, true, SP_WAVES, false, SP_PXT_SMALL>, 64 * SP_WAVES, 0) != hipSuccess
+            || cus < 1 || per_cu < 1) {
+            (void)hipGetLastError();
+            v = -1;
+        } else {
+            v = (int)(((long long)cus * per_cu * 3) / 4);
+            if (v < 1) v = -1;
+        }
+        cache[dev].store(v, std::memory_order_relaxed);
+    }
+    return v > 0 ? (unsigned)v : 0u;
+}
+
 int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
+    p = Plan{};
     if (!b) return fail(DD_ERR_INVALID_ARG, "batch is NULL");
     if (b->num_views <= 0 || b->height <= 0 || b->width <= 0) return fail(DD_ERR_INVALID_ARG, "num_views/height/width must be positive");
     if (b->stride < 1) return fail(DD_ERR_INVALID_ARG, "stride must be >= 1");
@@ -1901,6 +1936,8 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
     }
     if (!(b->flags & (DD_VALID_MASK | DD_VALID_CONF | DD_VALID_DEPTH_POSITIVE)))
         return fail(DD_ERR_INVALID_ARG, "flags select no validity rule");
+    if (b->tuning & ~(uint32_t)DD_TUNE_ALL) return fail(DD_ERR_INVALID_ARG, "tuning: reserved bits set (the experiment switches moved to ddcore_lab.h with ABI 14)");
+    const uint32_t lab = g_lab;
     const long long hw = (long long)b->height * b->width;
     if (hw >= (1ll << 31)) return fail(DD_ERR_UNSUPPORTED, "views of 2^31 pixels or more are not supported");
 
@@ -1944,13 +1981,13 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
     // (the scalar kernels run single-pass only on request, and only on views below 2^30 pixels: what a two-pass call leaves in a
     // workspace must read as "not published" to a later single-pass call -- see TileCO)
     p.single = ((b->tuning & TUNE_SINGLE_PASS) != 0 && (p.lean || hw < (1ll << 30))) || (p.lean && (p.refine || !(b->tuning & (TUNE_TWO_PASS | TUNE_ASSUME_DENSE))));
-    a.align_runs = (b->tuning & 32u) == 0;  // tuning bit 32: rows in list order (A/B of the line-aligned sweeps)
-    // tuning bit 128: tiles whose pixels all survive take the list-free path (dense_wave).  Off by default: measured in the
+    a.align_runs = (lab & DD_LAB_LIST_ORDER) == 0;  // lab: rows in list order (A/B of the line-aligned sweeps)
+    // DD_TUNE_DENSE_TILES: tiles whose pixels all survive take the list-free path (dense_wave).  Off by default: measured in the
     // real kernel it is the same rows with a third of the instructions, and 0-5 % SLOWER.
     // The dense path steps x by 64 per lane (width >= 64) and derives rows in float32 (width < 2^23).
-    a.dense_ok = (b->tuning & 128u) != 0 && b->width >= 64 && b->width < (1 << 23);
-    a.order_regions = 1u + ((b->tuning >> 8) & 63u);       // tuning bits 8-13: the scatter pass interleaves 2 .. 64 stretches of tiles
-    a.spin_limit = (b->tuning & 64u) ? 0u : SPIN_LIMIT;   // tuning bit 64: fault injection -- a tile that would have to wait for a
+    a.dense_ok = (b->tuning & DD_TUNE_DENSE_TILES) != 0 && b->width >= 64 && b->width < (1 << 23);
+    a.order_regions = 1u + ((b->tuning >> 8) & 63u);       // DD_TUNE_INTERLEAVE: the scatter pass interleaves 2 .. 64 stretches of tiles
+    a.spin_limit = (lab & DD_LAB_FAULT_INJECT) ? 0u : SPIN_LIMIT;   // lab, fault injection: a tile that would have to wait for a
                                                           // predecessor gives up at once, and every eighth tile behaves as if it had:
                                                           // wrong rows, the workspace's error word set (tests of the caller's recovery)
     // The lean single-pass kernel (round 5).  The tiles' first rows come from the scan service: one workgroup of the launch -- the one
@@ -1967,24 +2004,25 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
     // 1.06x on a per-pixel confidence cull, 1.09x on 100 x 12 MP, 1.05-1.2x on 8 views, 1.14x on one.
     {
         const unsigned long long big_tiles = (unsigned long long)((a.P + SP_WAVES * L_WSPAN - 1) / (SP_WAVES * L_WSPAN)) * (unsigned)a.V;
-        const unsigned tsel = (b->tuning >> 18) & 3u, wsel = (b->tuning >> 20) & 3u;
+        const unsigned tsel = (b->tuning >> 18) & 3u, wsel = (lab & DD_LAB_POLL_LANES_64) ? 3u : (lab & DD_LAB_POLL_LANES_32) ? 2u : 0u;
         const bool small = (tsel == 1u || (tsel == 0u && big_tiles <= SP_SMALL_BATCH_TILES)) && !p.refine;
         p.sp_pxt = small ? SP_PXT_SMALL : L_PXT;
-        a.scan_service = p.lean && ((b->tuning >> 26) & 1u) == 0u;
-        a.refine_plain = (int)((b->tuning >> 27) & 3u);
+        a.scan_service = p.lean && (lab & DD_LAB_LOOKBACK) == 0u;
+        a.refine_plain = ((lab & DD_LAB_REFINE_BISECT) ? 1 : 0) | ((lab & DD_LAB_REFINE_MEDIAN9) ? 2 : 0);
         a.static_tiles = (int)((b->tuning >> 22) & 1u);
         a.lb_lanes = wsel == 2u ? 32u : wsel == 3u ? 64u : (unsigned)LB_LANES;
         if (b->chain) {
             // a chained call's workgroups occupy slots while its scan waits for the previous call: it must never be able to occupy
-            // all of them (512 slots of 12 waves), whatever else of this cloud is in flight -- at most 384 workgroups, the scan included
+            // all of them, whatever else of this cloud is in flight -- at most three quarters of the device's slots for this
+            // instantiation (chain_wg_limit: 384 of the 512 of a whole MI355X, 48 of the 64 of a CPX partition), the scan included
             // (counted in the 12-wave small tile a call that waits in its scan runs with: 6144 pixels)
             const unsigned tile_px = p.sp_pxt == SP_PXT_SMALL ? SP_WAVES * 64 * SP_PXT_SMALL : SP_WAVES * 64 * L_PXT;
             const unsigned long long wgs = (unsigned long long)((a.P + tile_px - 1) / tile_px) * (unsigned)a.V + 1ull;
             if (!p.lean || !a.scan_service || p.refine || !p.single)
                 return fail(DD_ERR_UNSUPPORTED, "DDViewBatch.chain needs the single-pass kernel with the scan service (stride-1 maps, no DD_REFINE, tuning without 1 / 4 / bit 17 / bit 26)");
-            // a call of more than 384 workgroups gets a GATE in front of it (chain_gate): one wave that returns when the previous
-            // call's scan is over, so that this call's workgroups exist only once they have nothing to wait for
-            p.chain_gate = wgs > 384ull;
+            // a larger call gets a GATE in front of it (chain_gate): one wave that returns when the previous call's scan is over, so
+            // that this call's workgroups exist only once they have nothing to wait for
+            p.chain_gate = wgs > (unsigned long long)chain_wg_limit();
             a.chain_gated = p.chain_gate ? 1 : 0;
             a.chain = reinterpret_cast<unsigned long long *>(b->chain);
             a.chain_seq = (unsigned)(b->chain_seq & (int64_t)CHAIN_SEQ_MASK);
@@ -2130,9 +2168,30 @@ int enqueue_plan(const Plan &p, const KArgs &a, hipStream_t s) {
 
 }  // namespace
 
+// (for the library's other translation units: dd_refine_apply reads its two switches here)
+uint32_t dd_lab_word() { return g_lab; }
+
 extern "C" {
 
 int dd_abi_version(void) { return DD_ABI_VERSION; }
+
+uint32_t dd_debug_tuning(uint32_t bits) {
+    const uint32_t before = g_lab;
+    g_lab = bits;
+    return before;
+}
+
+int32_t dd_chain_workgroup_limit(void) { return (int32_t)chain_wg_limit(); }
+
+int dd_debug_plan(const DDViewBatch *batch, int32_t out[8]) {
+    KArgs a; Plan p;
+    int rc = make_plan(batch, a, p);
+    if (rc != DD_OK) return rc;
+    if (!out) return fail(DD_ERR_INVALID_ARG, "out is NULL");
+    out[0] = p.lean; out[1] = p.single; out[2] = p.refine; out[3] = p.f16; out[4] = p.tile; out[5] = p.sp_pxt; out[6] = p.chain_gate;
+    out[7] = (int32_t)a.num_tiles;
+    return DD_OK;
+}
 
 const char *dd_last_error(void) { return g_err; }
 
@@ -2244,7 +2303,7 @@ int dd_unproject_compact(const DDViewBatch *batch, const DDCloudOut *out, int64_
         }
         // ONE stream operation: the granules are tagged with the workspace's call epoch (nothing is zeroed), and the last tile
         // to finish its look-back writes the cursor and closes the call (close_call)
-        if (p.chain_gate) hipLaunchKernelGGL(chain_gate, dim3(1), dim3(64), 0, s, a.chain, a.chain_seq);
+        if (p.chain_gate && a.chain) hipLaunchKernelGGL(chain_gate, dim3(1), dim3(64), 0, s, a.chain, a.chain_seq);
         launch_scatter<true>(p, a, s);
         return check_launch("dd_unproject_compact");
     }

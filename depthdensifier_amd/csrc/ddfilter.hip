@@ -725,7 +725,7 @@ int dd_floater_votes(const DDFilterViews *views, const float *xyz, const float *
     if (views->mode == 2) return fail("mode 2 (the float32 first pass and its verify build) was removed in ABI 9");
     if (n > 0 && (!xyz || !normal || !votes_dev)) return fail("xyz / normal / votes_dev is NULL");
     if (n == 0) return DD_OK;
-    FArgs a;
+    FArgs a{};
     a.xyz = xyz; a.normal = normal; a.depth = views->depth; a.mask = views->mask; a.cams = views->cams;
     a.votes = votes_dev; a.n = n; a.hw = (long long)views->height * views->width;
     a.V = views->num_views; a.H = views->height; a.W = views->width; a.accumulate = accumulate;
@@ -800,7 +800,7 @@ int dd_compact_cloud(const DDCloudOut *in, int64_t n, const int32_t *votes_dev, 
     hipStream_t s = (hipStream_t)stream;
     const int64_t tiles = (n + C_TILE - 1) / C_TILE, groups = (tiles + C_GROUP - 1) / C_GROUP;
     if (tiles > 0x7fffffffll) return fail("too many rows for one call");
-    CArgs a;
+    CArgs a{};
     a.votes = votes_dev; a.xyz = in->xyz; a.normal = in->normal; a.rgb = in->rgb; a.pix = in->pixel_index; a.view = in->view_index;
     a.o_xyz = out->xyz; a.o_normal = out->normal; a.o_rgb = out->rgb; a.o_pix = out->pixel_index; a.o_view = out->view_index;
     a.o_packed = out->xyz_rgba; a.capacity = out->capacity;

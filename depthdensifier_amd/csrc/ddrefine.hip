@@ -14,7 +14,10 @@
 #include <stdlib.h>
 
 #include "ddcore.h"
+#include "ddcore_lab.h"
 #include "ddrefine_math.h"
+
+uint32_t dd_lab_word();      // ddcore.hip: this thread's experiment switches
 
 namespace {
 
@@ -390,13 +393,14 @@ int dd_refine_apply(const void *depth, int32_t depth_dtype, const uint8_t *mask,
     if (depth_dtype != DD_F32 && depth_dtype != DD_F16) return fail("depth_dtype must be DD_F32 or DD_F16");
     if (!knots_x || !knots_y || n_knots < 2) return fail("need at least two sorted knots");
     if ((long long)height * width >= (1ll << 31)) return fail("view too large");
-    RArgs a;
+    RArgs a{};
     a.depth = depth; a.mask = mask; a.kx = knots_x; a.ky = knots_y; a.out = refined_out;
     a.H = height; a.W = width; a.n = n_knots; a.f16 = depth_dtype == DD_F16; a.skip_smoothing = skip_smoothing;
-    static const bool plain = [] { const char *e = getenv("DD_REFINE_APPLY_PLAIN"); return e && e[0] == '1'; }();
+    const uint32_t lab = dd_lab_word();          // the experiment switches of ddcore_lab.h (zero in production)
+    const bool plain = (lab & DD_LAB_APPLY_PLAIN) != 0u;
     if (n_knots <= MAX_LDS_KNOTS && !plain) {
         const int tiles_x = (width + PW - 1) / PW, tiles = tiles_x * ((height + PH - 1) / PH);
-        static const int max_wgs = [] { const char *e = getenv("DD_REFINE_APPLY_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4096; }();
+        const int lab_wgs = (int)((lab >> 8) & 0x1fffu), max_wgs = lab_wgs > 0 ? lab_wgs : 4096;
         const int wgs = tiles < max_wgs ? tiles : max_wgs;     // (the knots and their grid are built once per workgroup)
         hipLaunchKernelGGL(refine_apply_tiles, dim3(wgs), dim3(256), (size_t)n_knots * 2 * sizeof(float), (hipStream_t)stream, a, tiles_x, tiles);
     } else {
@@ -416,7 +420,7 @@ int dd_refine_fit(const float *points, int32_t n, const float *cam_from_world, c
     if (n > 0 && (!points || !z_mono_out || !z_metric_out || !scratch)) return fail("points / outputs / scratch is NULL");
     if (height <= 1 || width <= 1) return fail("height/width must be at least 2");
     if (depth_dtype != DD_F32 && depth_dtype != DD_F16) return fail("depth_dtype must be DD_F32 or DD_F16");
-    FitArgs a;
+    FitArgs a{};
     a.points = points; a.depth = depth; a.z_mono = z_mono_out; a.z_metric = z_metric_out; a.ratio = scratch; a.meta = meta_out;
     for (int k = 0; k < 12; ++k) a.E[k] = cam_from_world[k];
     for (int k = 0; k < 6; ++k) a.K[k] = calibration[k];

@@ -334,8 +334,10 @@ class ViewBatch:
                  conf_threshold: Optional[float] = None, normal: Optional[ArrayLike] = None,
                  rgb: Optional[ArrayLike] = None, stride: int = 1, semantics: str = "script",
                  rotate_normals: Optional[bool] = None, view_index_base: int = 0, device=None,
-                 tuning: int = 0, depth_positive_on_mask: bool = False, refine=None, refined_out=None):
-        """``refine``: per view ``(knots_x, knots_y, skip_smoothing)`` (or one tuple for a single view), sorted float32 device
+                 tuning: int = 0, depth_positive_on_mask: bool = False, refine=None, refined_out=None, lab: int = 0):
+        """``tuning``: ``DDViewBatch.tuning`` (``_lib.DD_TUNE_*``: what a caller may choose); ``lab``: the library's experiment
+        switches (``_lib.DD_LAB_*``, ``include/ddcore_lab.h``) for the calls made with this batch -- tests and A/B tools only.
+        ``refine``: per view ``(knots_x, knots_y, skip_smoothing)`` (or one tuple for a single view), sorted float32 device
         knots of the refiner's transfer curve: ``depth`` is then the RAW monocular map and the densify kernel refines it on
         the fly (``DD_REFINE``: ``depth_refiner.py:180-205`` fused with ``scripts/test.py:194-233``; stride 1, width <= 3071,
         2..512 knots).  ``refined_out``: ``True`` or a (V,H,W) float32 tensor to receive the refined, mask-zeroed map (the
@@ -429,6 +431,9 @@ class ViewBatch:
             self.rgb_passthrough = None
         self.view_index_base = int(view_index_base)
         self.tuning = int(tuning)
+        if self.tuning & ~_lib.DD_TUNE_ALL:
+            raise ValueError(f"tuning {self.tuning:#x}: reserved bits set (the experiment switches are `lab=` since ABI 14: _lib.DD_LAB_*)")
+        self.lab = int(lab)
 
         flags = 0
         if semantics == "script":
@@ -551,7 +556,8 @@ def count_valid(batch: ViewBatch) -> torch.Tensor:
     if batch.num_views == 0:
         return counts
     cb = batch.c_struct()
-    check(lib.dd_count_valid(C.byref(cb), counts.data_ptr(), _stream(batch.device)))
+    with _lib.lab_switches(batch.lab):
+        check(lib.dd_count_valid(C.byref(cb), counts.data_ptr(), _stream(batch.device)))
     return counts
 
 
@@ -582,7 +588,8 @@ def plan_batch(batch: ViewBatch, cursor: Optional[torch.Tensor] = None,
     else:
         ws = torch.zeros(max(nbytes, 1024), dtype=torch.uint8, device=batch.device)
         offsets = torch.empty(batch.num_views + 1, dtype=torch.int64, device=batch.device)
-    check(lib.dd_plan(C.byref(cb), cursor.data_ptr(), offsets.data_ptr(), ws.data_ptr(), ws.numel(), _stream(batch.device)))
+    with _lib.lab_switches(batch.lab):
+        check(lib.dd_plan(C.byref(cb), cursor.data_ptr(), offsets.data_ptr(), ws.data_ptr(), ws.numel(), _stream(batch.device)))
     return BatchPlan(offsets, ws)
 
 
@@ -634,7 +641,7 @@ class CloudBuilder:
         caller's other clouds; default: one of its own.  ``exclusive_gpu``: this process's densify stream has the GPU to itself (one
         process per GPU, the deployment of ``scripts/run_batch.py`` under ``torchrun``; default: the environment's ``DD_EXCLUSIVE_GPU``
         = 1, else False).  The single-pass kernel then takes its tiles by workgroup index instead of drawing tickets from one
-        contended counter (``DDViewBatch.tuning`` bit 22): 2-8 % faster -- but on a GPU that another launch of the kind shares
+        contended counter (``DD_TUNE_BY_INDEX``): 2-8 % faster -- but on a GPU that another launch of the kind shares
         (a second process, a second stream) two launches can hold each other's slots until a spin limit ends it and the batches
         are redone, so it is never assumed.
 
@@ -739,7 +746,7 @@ class CloudBuilder:
         two calls in flight occupies workgroup slots while it waits for the earlier one's scan: never more than 384 of the 512)."""
         if not (self.exclusive_gpu and self.overlap_small) or batch.stride != 1 or batch._knots is not None:
             return False
-        if tuning & (1 | 4 | 8 | 0x3F00 | _lib.DD_TUNE_ASSUME_DENSE | (1 << 26) | (3 << 18)):
+        if tuning & (1 | 4 | 8 | 0x3F00 | _lib.DD_TUNE_ASSUME_DENSE | (3 << 18)) or batch.lab & _lib.DD_LAB_LOOKBACK:
             return False
         _, H, W = batch.depth.shape
         # small calls only (a large batch fills the chip by itself and its launch latency is nothing): up to CHAIN_MAX_TILES tiles of
@@ -874,13 +881,14 @@ class CloudBuilder:
             cb = batch.c_struct()
             out = self._out_struct()
             offsets = _offsets if redo else self._offsets_slice(batch.num_views + 1)
-            if not redo and self._chained_ok(batch, batch.tuning):
-                ws = self._append_chained(batch, cb, out, offsets)
-            else:
-                self._join_side()
-                ws = self._workspace(batch.workspace_bytes())
-                check(lib.dd_unproject_compact(C.byref(cb), C.byref(out), offsets.data_ptr(), self.cursor.data_ptr(),
-                                               ws.data_ptr(), ws.numel(), _stream(self.device)))
+            with _lib.lab_switches(batch.lab):
+                if not redo and self._chained_ok(batch, batch.tuning):
+                    ws = self._append_chained(batch, cb, out, offsets)
+                else:
+                    self._join_side()
+                    ws = self._workspace(batch.workspace_bytes())
+                    check(lib.dd_unproject_compact(C.byref(cb), C.byref(out), offsets.data_ptr(), self.cursor.data_ptr(),
+                                                   ws.data_ptr(), ws.numel(), _stream(self.device)))
         finally:
             batch.tuning = saved
         if not redo:
@@ -983,8 +991,9 @@ class CloudBuilder:
         self._join_side()
         cb = batch.c_struct()
         out = self._out_struct()
-        check(lib.dd_scatter(C.byref(cb), C.byref(out), plan.view_offsets.data_ptr(), plan.workspace.data_ptr(),
-                             plan.workspace.numel(), _stream(self.device)))
+        with _lib.lab_switches(batch.lab):
+            check(lib.dd_scatter(C.byref(cb), C.byref(out), plan.view_offsets.data_ptr(), plan.workspace.data_ptr(),
+                                 plan.workspace.numel(), _stream(self.device)))
         self._retain_complete = False               # (a redo replays append() calls only: not with scatter() calls in between)
         self._retained.clear()
         self.cursor.copy_(plan.view_offsets[-1:], non_blocking=True)
@@ -1081,12 +1090,13 @@ class CloudBuilder:
         else:
             self.cursor.fill_(self._retain_base)
         for batch, offsets, _, _ in self._retained:
-            saved = batch.tuning
-            batch.tuning = (saved | 4) & ~(8 | 64 | _lib.DD_TUNE_ASSUME_DENSE)
+            saved, saved_lab = batch.tuning, batch.lab
+            batch.tuning = (saved | 4) & ~(8 | _lib.DD_TUNE_ASSUME_DENSE)
+            batch.lab = 0                                    # (a redo never runs with an injected fault or another experiment switch)
             try:
                 self.append(batch, _offsets=offsets)
             finally:
-                batch.tuning = saved
+                batch.tuning, batch.lab = saved, saved_lab
         self.healed += 1
         if not dense_miss and self.exclusive_gpu:
             # a scan that timed out while tiles were taken by workgroup index: the GPU was not this stream's alone after all (two
@@ -1114,7 +1124,7 @@ def unproject_views(depth: ArrayLike, intrinsics: ArrayLike, cam_from_world: Arr
                     semantics: str = "script", rotate_normals: Optional[bool] = None,
                     capacity: Union[None, int, str] = None, pixel_index: bool = True,
                     view_index: bool = False, device=None, tuning: int = 0, record: str = "rows",
-                    _allow_passthrough: bool = False) -> FusedCloud:
+                    _allow_passthrough: bool = False, lab: int = 0) -> FusedCloud:
     """Densify + fuse a stack of views: ``scripts/test.py:203-244`` per view and ``:262-266``.
 
     ``downsample_density`` is ``ProcessingConfig.downsample_density`` (``scripts/test.py:37``; the
@@ -1130,7 +1140,7 @@ def unproject_views(depth: ArrayLike, intrinsics: ArrayLike, cam_from_world: Arr
         raise ValueError("record must be 'rows', 'xyz_rgba' or 'both'")
     batch = ViewBatch(depth, intrinsics, cam_from_world, mask=mask, conf=conf, conf_threshold=conf_threshold,
                       normal=normal, rgb=rgb, stride=downsample_density, semantics=semantics,
-                      rotate_normals=rotate_normals, device=device, tuning=tuning)
+                      rotate_normals=rotate_normals, device=device, tuning=tuning, lab=lab)
     if batch.rgb_passthrough is not None and not _allow_passthrough:
         raise ValueError("the colours of some views stay non-uint8 in the reference (visualizer.py:341: valid colours above 1 are "
                          "handed on unchanged); a fused cloud carries uint8 colours -- convert the image, or go through "

@@ -12,7 +12,10 @@
  *    throws; dd_last_error() returns a thread-local message for the last error;
  *  - the caller owns every buffer (device memory unless stated); the compute entry
  *    points allocate nothing and keep no global mutable state; calls are re-entrant
- *    (the one allocator is the explicit DDArena object at the end of this header);
+ *    (the one allocator is the explicit DDArena object at the end of this header; the
+ *    one thing remembered is a property of the device, dd_chain_workgroup_limit);
+ *  - the switches of the library's own A/B experiments and fault-injection tests are
+ *    NOT here: include/ddcore_lab.h (a thread-local debug word, zero in production);
  *  - all work is enqueued asynchronously on `stream` (a hipStream_t passed as
  *    void*; NULL = the default stream).  Nothing synchronises the host.
  */
@@ -25,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 13
+#define DD_ABI_VERSION 14
 
 enum {
     DD_OK = 0,
@@ -47,6 +50,22 @@ enum { DD_F32 = 0, DD_F16 = 1 };
                                         (src/depthdensifier/depth_refiner.py:180-205 fused with scripts/test.py:194-233).
                                         dd_unproject_compact only, stride 1, width <= 3071, no DD_VALID_CONF; the validity
                                         rule is the script's: mask (or raw depth > 0 without one) AND refined depth > 0 */
+
+/* DDViewBatch.tuning: what a caller may choose (0 = the library decides).  The rows written are the same for every value. */
+#define DD_TUNE_GENERIC      0x1u        /* the scalar any-stride kernels even on stride-1 maps */
+#define DD_TUNE_TWO_PASS     0x4u        /* dd_unproject_compact as count + scans + scatter: no workgroup waits for another */
+#define DD_TUNE_SINGLE_PASS  0x8u        /* dd_unproject_compact as ONE kernel with an in-kernel scan (the default on stride-1 maps) */
+#define DD_TUNE_DENSE_TILES  0x80u       /* tiles whose pixels all survive skip the point list (line-aligned 16-byte stores; not with
+                                            xyz_rgba or rotated normals) */
+#define DD_TUNE_INTERLEAVE(k) ((((uint32_t)(k) - 1u) & 63u) << 8)   /* two-pass scatter: tiles of k = 2..64 stretches of the batch in turn, so
+                                            that consecutive workgroups write k distant regions (a DD_ARENA_BLOCKED array: 0.80 vs 0.66) */
+#define DD_TUNE_ASSUME_DENSE (1u << 17)  /* stride-1 maps without holes: no counting pass; the scatter verifies every tile and a miss sets
+                                            the workspace's error word to 2 -- rows, offsets and cursor are then void: redo with TWO_PASS */
+#define DD_TUNE_TILE_SMALL   (1u << 18)  /* single pass: 8192-pixel tiles (default up to 3072 tiles of 12288: a streamed view or a dozen) */
+#define DD_TUNE_TILE_LARGE   (3u << 18)  /* single pass: 12288-pixel tiles (default above) */
+#define DD_TUNE_BY_INDEX     (1u << 22)  /* single pass: tiles by workgroup index instead of by ticket -- 2-8 % faster, only on a GPU this
+                                            stream has to itself (two such launches sharing a GPU can hold each other's slots) */
+#define DD_TUNE_ALL (DD_TUNE_GENERIC | DD_TUNE_TWO_PASS | DD_TUNE_SINGLE_PASS | DD_TUNE_DENSE_TILES | (63u << 8) | DD_TUNE_ASSUME_DENSE | DD_TUNE_TILE_LARGE | DD_TUNE_BY_INDEX)
 
 /*
  * Per-view camera block, 32 floats (128 B), device memory, built on the host in
@@ -93,32 +112,8 @@ typedef struct DDViewBatch {
     float conf_threshold;
     uint32_t flags;
     int32_t view_index_base;  /* added to the per-point view index (global view id of view 0) */
-    uint32_t tuning;          /* 0 = default; 1 = force the scalar kernels; 4 / 8 = dd_unproject_compact as
-                                 plan + scatter / as the single-pass look-back kernel (default on stride-1 maps);
-                                 32 = rows in list order (no shift of the wave runs onto 128-byte lines; A/B);
-                                 64 = fault injection for tests: the look-back gives up at its first wait and sets the
-                                 workspace's error word; 128 = tiles whose pixels all survive take the list-free path
-                                 (LDS-staged, line-aligned 16-byte stores; same rows, a third of the instructions, not
-                                 faster -- DESIGN.md section 4; not with the 16-byte record or rotated normals);
-                                 bits 8-13 = K - 1: the scatter pass of the two-pass path (tuning 4 / dd_scatter) takes the tiles
-                                 of K stretches of the batch in turn, so that consecutive workgroups write K distant regions
-                                 of the output -- for ONE large row array whose thirds lie in different classes of HBM
-                                 (DD_ARENA_BLOCKED) that is 0.80 instead of 0.66 of the roofline; rows are the same for every K;
-                                 bit 17 (131072) = dd_unproject_compact on stride-1 maps SPECULATES that every visited pixel is
-                                 valid (a depth map without holes, no mask): no counting pass -- the plan is arithmetic (view v starts
-                                 v * H * W rows behind the cursor) and the scatter pass, which reads the validity inputs anyway,
-                                 verifies every tile; a tile that finds an invalid pixel sets the workspace's error word to 2
-                                 and the batch's rows, offsets and cursor are void: redo it with tuning = 4 (what CloudBuilder
-                                 does by itself).  Ignored with tuning 8, DD_REFINE and on strided maps;
-                                 bits 18-19 (ABI 11) = tile of the single-pass kernel on stride-1 maps: 0 = by the size of the batch
-                                 (up to 3072 tiles of 12288 pixels -- a streamed view or a dozen, scripts/test.py:131 -- 8 pixels per lane,
-                                 8192-pixel tiles of 16 waves, rows written past the L2; above, 16 pixels per lane, 12288-pixel tiles), 1 / 3 =
-                                 force the small / the large tile; bit 26 = the decoupled look-back of ABI <= 10 instead of the scan
-                                 service (one workgroup of the launch scans the tiles' counts, a tile polls its own first row), with
-                                 bits 20-21 = its polling lanes (0 / 1 = 16, 2 = 32, 3 = 64) and bit 22 = tiles by workgroup index
-                                 instead of by ticket; bits 27 / 28 (DD_REFINE, A/B switches) = the curve found by bisecting all
-                                 knots / one median per window, as before round 5's grid of buckets and shared sorted columns.
-                                 Same rows whatever these say */
+    uint32_t tuning;          /* 0 = the library chooses; else an OR of DD_TUNE_* above -- what a caller may decide.  Every
+                                 choice writes the same rows; reserved bits must be zero (DD_ERR_INVALID_ARG) */
     float *refined_out;       /* DD_REFINE: NULL, or (V,H,W) float32 receiving the refined, mask-zeroed depth -- the map the
                                  reference caches for the multi-view filter (scripts/test.py:194, 197-201) */
     int64_t *chain;           /* ABI 12: NULL, or (1) int64 device word that chains consecutive calls of ONE cloud across TWO streams, so
@@ -129,9 +124,9 @@ typedef struct DDViewBatch {
                                  its scan workgroup polls until the sequence equals chain_seq (mod 2^20) -- not from *cursor_dev, and when
                                  its scan is over stores (chain_seq + 1, row after the batch) there, and the row in *cursor_dev as usual.
                                  Calls that may be in flight together need a workspace and a view_offsets array each; two in flight at
-                                 most, on a GPU the process has to itself.  A call of at most 383 tiles of 6144 pixels (a 1080p view)
-                                 starts at once and waits inside its scan workgroup -- its tiles load and count meanwhile, and could
-                                 never occupy every slot; a larger one is preceded by a one-wave gate kernel on its stream that returns
+                                 most, on a GPU the process has to itself.  A call of fewer than dd_chain_workgroup_limit() tiles of 6144 pixels
+                                 (383 on a whole MI355X: a 1080p view) starts at once and waits inside its scan workgroup -- its tiles load
+                                 and count meanwhile, and could never occupy every slot; a larger one is preceded by a one-wave gate kernel on its stream that returns
                                  when the earlier call's scan is over, so that its workgroups never hold a slot while they wait for
                                  another launch.  Stride-1 maps and the scan service only (DD_ERR_UNSUPPORTED otherwise) */
     int64_t chain_seq;
@@ -231,6 +226,11 @@ int dd_stream_fork(void *event, void *from_stream, void *to_stream);
  * *overlap_out = 1 if it saw the flag.  `scratch_dev`: 8 bytes of device memory.  Synchronises both streams (about 50 us; call it
  * once per pair of side streams, outside any stream capture) and no other. */
 int dd_streams_overlap(void *stream_a, void *stream_b, int32_t *scratch_dev, int32_t *overlap_out);
+
+/* Workgroups (tiles + the scan) up to which a chained call (DDViewBatch.chain) runs WITHOUT a gate kernel on the current device: three
+ * quarters of the workgroup slots the device offers that kernel (occupancy x compute units: 384 on a whole MI355X, 48 on a CPX
+ * partition), so that a call waiting for its predecessor's scan can never hold every slot.  0 = unknown (every chained call is gated). */
+int32_t dd_chain_workgroup_limit(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-GPU fuse: what scripts/test.py:262-266 (np.concatenate of the per-view arrays)

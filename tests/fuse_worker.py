@@ -30,6 +30,19 @@ def main():
     from depthdensifier_amd import distributed as D
     from synth import make_views
 
+    repeat = int(os.environ.get("DD_FUSE_REPEAT", "1"))          # (soak: the whole exchange several times in one set of processes)
+    for _ in range(repeat):
+        n_points = body(rank, world, backend, dev)
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"rank {rank}/{world} [{backend}]: ok, {n_points} points" + (f", {repeat} executions" if repeat > 1 else ""))
+
+
+def body(rank, world, backend, dev):
+    import depthdensifier_amd as dd
+    from depthdensifier_amd import distributed as D
+    from synth import make_views
+
     V, H, W = int(os.environ.get("DD_FUSE_VIEWS", "9")), 120, 200
     d = make_views(77, V, H, W, rho=0.75, specials=True)
     d["mask"][min(3, V - 1)] = False                                          # an empty view
@@ -69,10 +82,10 @@ def main():
     same(cloud.colors.contiguous(), full.colors, "xyz_rgba colours view")
     fault = os.environ.get("DD_FUSE_FAULT_RANK")
     if fault is not None:
-        # an in-kernel scan gives up on ONE rank (fault injection, tuning bit 64): that rank heals its rows after they went out;
+        # an in-kernel scan gives up on ONE rank (fault injection, DD_LAB_FAULT_INJECT of include/ddcore_lab.h): that rank heals its rows after they went out;
         # every rank must still end up with the whole cloud (the re-exchange is agreed on collectively)
         bad = dd.ViewBatch(cut(d["depth"]), cut(params), cut(d["cam_from_world"]), mask=cut(d["mask"]), normal=cut(d["normal"]),
-                           rgb=cut(d["rgb"]), view_index_base=lo, device=dev, tuning=64 if rank == int(fault) else 0)
+                           rgb=cut(d["rgb"]), view_index_base=lo, device=dev, lab=2 if rank == int(fault) else 0)
         cloud, plan = D.fuse_replicated(bad, V, pixel_index=True, view_index=True, chunks=3)
         torch.cuda.synchronize()
         for name in ("points", "colors", "normals", "pixel_index", "view_index"):
@@ -102,9 +115,7 @@ def main():
         torch.cuda.synchronize()
         same(fused.points, full.points, "gather_cloud points")
         same(fused.colors, full.colors, "gather_cloud colours")
-    dist.barrier()
-    dist.destroy_process_group()
-    print(f"rank {rank}/{world} [{backend}]: ok, {len(full)} points")
+    return len(full)
 
 
 if __name__ == "__main__":

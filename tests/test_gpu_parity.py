@@ -11,6 +11,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+FAULT_INJECT = 2       # _lib.DD_LAB_FAULT_INJECT (include/ddcore_lab.h): an in-kernel scan gives up; `ViewBatch(lab=...)`
+
 XYZ_RTOL = 1e-4
 NORMAL_ATOL = 1e-6
 
@@ -629,7 +631,7 @@ def test_12mp_f16_dense_beyond_2_31_rows(dd, orc, tuning):
 
 @pytest.mark.parametrize("fields", ("all", "xyz"))
 def test_scan_timeout_is_healed_by_a_two_pass_redo(dd, fields):
-    """tuning bit 64 makes every look-back of the single-pass kernel give up at its first wait (what a workgroup parked for
+    """The fault-injection switch (``DD_LAB_FAULT_INJECT``, include/ddcore_lab.h) makes every look-back of the single-pass kernel give up at its first wait (what a workgroup parked for
     ~2 s would cause): the error word is set, rows are garbage.  finish() must notice, redo the retained batches with the
     dependency-free two-pass kernels into the SAME rows and offset tensors, and report it in `healed`."""
     import torch
@@ -645,12 +647,12 @@ def test_scan_timeout_is_healed_by_a_two_pass_redo(dd, fields):
     assert want_b.healed == 0
     # two chained batches, the second one sabotaged
     first = dd.ViewBatch(depth[:2], params[:2], E[:2], **{k: t[:2] for k, t in kw.items()})
-    second = dd.ViewBatch(depth[2:], params[2:], E[2:], view_index_base=2, tuning=64, **{k: t[2:] for k, t in kw.items()})
+    second = dd.ViewBatch(depth[2:], params[2:], E[2:], view_index_base=2, lab=FAULT_INJECT, **{k: t[2:] for k, t in kw.items()})
     b = dd.CloudBuilder(good.max_points, normals=fields == "all", colors=fields == "all", pixel_index=True)
     o1 = b.append(first)
     o2 = b.append(second)
     got = b.finish()
-    assert b.healed == 1 and second.tuning == 64
+    assert b.healed == 1 and second.lab == FAULT_INJECT and second.tuning == 0
     assert len(got) == len(want) and torch.equal(got.view_offsets, want.view_offsets)
     assert int(o1[-1]) == int(o2[0]) == int(want.view_offsets[2])                     # the offset tensors handed out were rewritten
     for name in ("points", "normals", "colors", "pixel_index"):
@@ -672,7 +674,7 @@ def test_scan_timeout_is_healed_by_a_two_pass_redo(dd, fields):
     # an input overwritten in place between append() and finish(): the redo would read other pixels -- refused, like before round 3
     b.reset()
     scratch = depth[2:].clone()
-    third = dd.ViewBatch(scratch, params[2:], E[2:], view_index_base=2, tuning=64, **{k: t[2:] for k, t in kw.items()})
+    third = dd.ViewBatch(scratch, params[2:], E[2:], view_index_base=2, lab=FAULT_INJECT, **{k: t[2:] for k, t in kw.items()})
     b.append(first)
     b.append(third)
     scratch.add_(1.0)
@@ -700,7 +702,7 @@ def test_check_async_reads_later_what_check_reads_now(dd):
     assert p1.result() == int(mask[:3].sum()) and p2.result() == int(mask[1:].sum())
     assert b.check() == int(mask[1:].sum())
     # a fault seen by a late reader: the cloud it was asked about is gone -> an error, not a silent redo of another cloud
-    bad = dd.ViewBatch(depth, params, E, mask=mask, tuning=64)
+    bad = dd.ViewBatch(depth, params, E, mask=mask, lab=FAULT_INJECT)
     b.reset(); b.append(bad)
     p3 = b.check_async()
     b.reset(); b.append(a)

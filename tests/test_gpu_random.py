@@ -56,7 +56,7 @@ def _case(seed):
         # round 5: the single-pass kernel's geometries -- tiles by workgroup index (bit 22), the decoupled look-back instead of the scan
         # service (bit 26), the small / the large tile forced (bits 18-19 = 1 / 3), 32 / 64 polling lanes (bits 20-21 = 2 / 3)
         opts["tuning"] |= (int(r5.integers(0, 2)) << 22) | (int(r5.integers(0, 2)) << 26) | (int(r5.choice([0, 1, 3])) << 18) | (int(r5.choice([0, 2, 3])) << 20)
-    return d, opts
+    return d, opts      # (opts["tuning"] is a variant word of tests/lab_bits.py: a product tuning + experiment switches)
 
 
 @pytest.mark.parametrize("seed", range(N_SEEDS))
@@ -65,6 +65,7 @@ def test_random_configuration(seed):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import depthdensifier_amd as dd
+    import lab_bits
     from oracle import densify_oracle as orc
 
     d, o = _case(seed)
@@ -76,7 +77,7 @@ def test_random_configuration(seed):
         depth32 = d["depth"].astype(np.float32)
         K = dd.intrinsics_matrix(d["params"])
         cloud = dd.unproject_views(depth32, K, d["cam_from_world"], mask=mask, normal=normal, rgb=rgb, semantics="viz",
-                                   view_index=True, tuning=o["tuning"])
+                                   view_index=True, **lab_bits.kw(o["tuning"]))
         with np.errstate(invalid="ignore", over="ignore"):
             ref = orc.densify_scene_viz(depth32, K, d["cam_from_world"], mask=mask, normal=normal, rgb=rgb)
         assert_cloud(cloud, ref, rad, normals="close")
@@ -84,7 +85,7 @@ def test_random_configuration(seed):
     conf = d["conf"].astype(o["conf_dtype"]) if o["use_conf"] else None
     thr = 0.37 if o["use_conf"] else None
     cloud = dd.unproject_views(d["depth"], d["params"], d["cam_from_world"], mask=mask, normal=normal, rgb=rgb, conf=conf,
-                               conf_threshold=thr, downsample_density=o["stride"], view_index=True, tuning=o["tuning"],
+                               conf_threshold=thr, downsample_density=o["stride"], view_index=True, **lab_bits.kw(o["tuning"]),
                                record=o["record"], capacity=o["capacity"])
     ref = orc.densify_scene_script(d["depth"], d["params"], d["cam_from_world"], mask=mask, normal=normal, rgb=rgb,
                                    stride=o["stride"], conf=conf, conf_threshold=thr)

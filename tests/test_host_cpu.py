@@ -23,11 +23,74 @@ def libmod():
 def test_header_symbols_are_exported(libmod):
     header = (ROOT / "include" / "ddcore.h").read_text()
     declared = set(re.findall(r"\b(dd_[a-z0-9_]+)\s*\(", header))
-    assert declared == set(libmod.EXPORTS)
+    lab = set(re.findall(r"\b(dd_[a-z0-9_]+)\s*\(", (ROOT / "include" / "ddcore_lab.h").read_text()))
+    assert lab == set(libmod.LAB_EXPORTS) and not (declared & lab)          # the experiment switches live in a header of their own
+    assert declared | lab == set(libmod.EXPORTS)
+    declared |= lab
     handle = C.CDLL(str(libmod.LIB_PATH))
     for sym in declared:
         assert getattr(handle, sym) is not None
     assert libmod.lib.dd_abi_version() == libmod.DD_ABI_VERSION
+
+
+def test_tuning_holds_only_what_a_caller_chooses(libmod):
+    """DDViewBatch.tuning carries the caller's choices (DD_TUNE_*), reserved bits are refused; the A/B and
+    fault-injection switches are a thread-local debug word behind include/ddcore_lab.h; no getenv in the compute sources; the
+    header's description of `tuning` is short."""
+    L = libmod.lib
+    header = (ROOT / "include" / "ddcore.h").read_text()
+    for name in ("GENERIC", "TWO_PASS", "SINGLE_PASS", "DENSE_TILES", "ASSUME_DENSE", "TILE_SMALL", "TILE_LARGE", "BY_INDEX"):
+        m = re.search(r"#define DD_TUNE_%s\s+\(?([0-9a-fx]+)u(?: << (\d+))?\)?" % name, header)
+        assert m, name
+        value = int(m.group(1), 0) << int(m.group(2) or 0)
+        assert value == getattr(libmod, "DD_TUNE_" + name), name
+    field = re.search(r"uint32_t tuning;(.*?)\n    float \*refined_out", header, re.S).group(1)
+    assert field.count("\n") <= 12
+    for bits in (32, 64, 3 << 20, 1 << 26, 1 << 27, 1 << 28, 1 << 30):       # where the experiment switches sat up to ABI 13
+        assert L.dd_workspace_bytes(C.byref(_batch(libmod, tuning=bits))) == -1 and b"reserved" in L.dd_last_error()
+    assert L.dd_workspace_bytes(C.byref(_batch(libmod, tuning=libmod.DD_TUNE_ALL))) > 0
+    assert L.dd_debug_tuning(libmod.DD_LAB_FAULT_INJECT) == 0 and L.dd_debug_tuning(0) == libmod.DD_LAB_FAULT_INJECT
+    import threading
+    seen = []
+    L.dd_debug_tuning(5)
+    t = threading.Thread(target=lambda: seen.append(L.dd_debug_tuning(0)))          # another thread: its own word
+    t.start(); t.join()
+    assert seen == [0] and L.dd_debug_tuning(0) == 5
+    for src in (ROOT / "depthdensifier_amd" / "csrc").glob("*.hip"):
+        hits = [ln for ln in src.read_text().splitlines() if "getenv(" in ln]
+        assert src.name == "ddarena.hip" and len(hits) == 2 or not hits, (src.name, hits)      # the arena's DEBUG / TRACE flags only
+
+
+def test_the_plan_of_a_batch_on_the_host(libmod):
+    """dd_debug_plan: which kernels a batch takes, decided on the host (no GPU): lean on stride-1 maps, generic otherwise; the small
+    tile for a streamed view, the large one for a scene; a gate only in front of a chained call."""
+    L = libmod.lib
+    out = (C.c_int32 * 8)()
+    plan = lambda **kw: (L.dd_debug_plan(C.byref(_batch(libmod, **kw)), out), list(out))[1]
+    small = plan(height=120, width=200)
+    assert small[:3] == [1, 1, 0] and small[5] == 8 and small[6] == 0 and small[7] == 2 * 6          # 6 tiles of 4096 per view
+    assert plan(height=1080, width=1920, num_views=200)[5] == 16
+    assert plan(height=120, width=200, stride=2)[:2] == [0, 0]
+    assert plan(height=120, width=200, tuning=libmod.DD_TUNE_TWO_PASS)[:2] == [1, 0]
+    assert plan(height=120, width=200, tuning=libmod.DD_TUNE_GENERIC)[0] == 0
+    assert plan(height=120, width=200, tuning=libmod.DD_TUNE_TILE_LARGE)[5] == 16
+    assert L.dd_chain_workgroup_limit() == 0             # no GPU here: unknown -> every chained call would be gated ...
+    assert plan(height=120, width=200, chain=0x3000)[6] == 1       # ... like this one
+
+
+def test_the_plan_does_not_depend_on_the_callers_stack(tmp_path):
+    """Round 6, the root cause of the rare GPU fault of the three-rank rehearsal: a member of the host-side plan that only chained calls
+    wrote was read by every call -- with whatever the stack held there.  tests/c_client/plan_stack_test.cpp paints the stack."""
+    import shutil
+    import subprocess
+    cxx = shutil.which("g++") or shutil.which("hipcc")
+    exe = tmp_path / "plan_stack_test"
+    lib_dir = ROOT / "depthdensifier_amd"
+    build = subprocess.run([cxx, "-std=c++17", "-O1", f"-I{ROOT / 'include'}", str(ROOT / "tests" / "c_client" / "plan_stack_test.cpp"),
+                            f"-L{lib_dir}", "-lddcore", f"-Wl,-rpath,{lib_dir}", "-o", str(exe)], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-1500:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert run.returncode == 0 and "OK" in run.stdout, run.stdout + run.stderr
 
 
 def test_struct_layout_matches_header(libmod):

@@ -8,11 +8,12 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+from lab_bits import CLASSIC, FAULT, W32, W64, kw, set_on      # variant words: a product tuning + experiment switches (tests/lab_bits.py)
+
 EPOCH_MAX = (1 << 18) - 1
 T_SMALL, T_LARGE, STATIC = 1 << 18, 3 << 18, 1 << 22
-W32, W64 = 2 << 20, 3 << 20
-CLASSIC = 1 << 26          # the decoupled look-back of rounds 1-4 (default since round 5: the scan service -- one workgroup of the launch
-                           # scans the tiles' counts, the tiles poll their own row)
+# CLASSIC: the decoupled look-back of rounds 1-4 (default since round 5: the scan service -- one workgroup of the launch scans the
+# tiles' counts, the tiles poll their own row)
 
 
 @pytest.fixture(scope="module")
@@ -78,7 +79,7 @@ def test_every_single_pass_geometry_writes_the_oracles_cloud(dd, orc, shape, dty
     first = None
     for tuning in (0, T_SMALL, T_LARGE, 8 | T_LARGE, CLASSIC, CLASSIC | T_SMALL, CLASSIC | T_SMALL | STATIC | W64, CLASSIC | T_LARGE,
                    CLASSIC | T_LARGE | STATIC, CLASSIC | T_LARGE | W32, CLASSIC | 8 | T_LARGE | W64):
-        cloud = dd.unproject_views(depth, params, E, mask=mask, normal=normal, rgb=rgb, capacity="max", tuning=tuning)
+        cloud = dd.unproject_views(depth, params, E, mask=mask, normal=normal, rgb=rgb, capacity="max", **kw(tuning))
         c = cloud.numpy()
         assert np.array_equal(c["view_offsets"], ref.view_offsets), tuning
         assert np.array_equal(c["pixel_index"].astype(np.int64), ref.pixel_index), tuning
@@ -123,7 +124,7 @@ def test_the_epoch_wraps_without_a_trace(dd, tuning):
     import torch
     V, H, W = 8, 64, 200
     depth, mask, normal, rgb, params, E = _case(9, V, H, W)
-    whole = dd.ViewBatch(depth, params, E, mask=mask, normal=normal, rgb=rgb, tuning=tuning)
+    whole = dd.ViewBatch(depth, params, E, mask=mask, normal=normal, rgb=rgb, **kw(tuning))
     b = dd.CloudBuilder(whole.max_points, normals=True, colors=True, pixel_index=True)
     b.append(whole)
     want = b.finish()
@@ -157,8 +158,7 @@ def test_two_pass_calls_between_single_pass_calls_share_the_workspace(dd):
         b.reset()
         for i, tuning in enumerate(order):
             sub = whole.slice(2 * i, 2 * i + 2)
-            sub.tuning = tuning
-            b.append(sub)
+            b.append(set_on(sub, tuning))
         _equal(b.finish(), want)
 
 
@@ -176,7 +176,7 @@ def test_appends_after_a_healed_give_up_start_from_a_clean_workspace(dd, how):
     b.append(whole.slice(0, 2))
     n2 = b.check()
     bad = whole.slice(2, 4)
-    bad.tuning = 64 | how
+    set_on(bad, FAULT | how)
     b.append(bad)
     # the sabotaged call has not touched a row of the first batch
     import torch
@@ -201,7 +201,7 @@ def test_a_check_covers_what_was_appended_when_it_was_asked_for(dd):
     want = b.finish()
     b.reset()
     A, B, Cc = whole.slice(0, 3), whole.slice(3, 6), whole.slice(6, 9)
-    B.tuning = 64                                    # every look-back of B that has to wait gives up
+    set_on(B, FAULT)                                 # every look-back of B that has to wait gives up
     b.append(A)
     p = b.check_async()
     b.append(B)
@@ -213,7 +213,7 @@ def test_a_check_covers_what_was_appended_when_it_was_asked_for(dd):
     _equal(got, want)
     # the same with the fault in A: the redo covers everything held, the answer is the count behind all of it
     b.reset()
-    A.tuning, B.tuning = 64, 0
+    set_on(A, FAULT); set_on(B, 0)
     b.append(A)
     p = b.check_async()
     b.append(B)
@@ -221,7 +221,7 @@ def test_a_check_covers_what_was_appended_when_it_was_asked_for(dd):
     b.append(Cc)
     _equal(b.finish(), want)
     # a reader that comes after a reset() finds nothing to redo: an error that says so
-    A.tuning = 64
+    set_on(A, FAULT)
     b.reset(); b.append(A)
     p = b.check_async()
     b.reset(); b.append(B)
@@ -255,7 +255,7 @@ def test_two_checks_in_flight_release_only_what_each_covers(dd, orc, order):
     depth, mask, normal, rgb, params, E = _case(47, V, H, W)
     want = dd.unproject_views(depth, params, E, mask=mask, normal=normal, rgb=rgb)
     one = lambda v, tuning=0, n=1: dd.ViewBatch(depth[v:v + n], params[v:v + n], E[v:v + n], mask=mask[v:v + n], normal=normal[v:v + n],
-                                                rgb=rgb[v:v + n], view_index_base=v, tuning=tuning)
+                                                rgb=rgb[v:v + n], view_index_base=v, **kw(tuning))
     b = dd.CloudBuilder(V * H * W, normals=True, colors=True, placement="first")
     offs = want.view_offsets.tolist()
     for v in (0, 1):
@@ -273,7 +273,7 @@ def test_two_checks_in_flight_release_only_what_each_covers(dd, orc, order):
         assert B.result() == offs[4] and len(b._retained) == 2 and b._retain_base == offs[4]
         assert A.result() == offs[2]                     # the older answer, read late: releases nothing more, moves nothing back
     assert len(b._retained) == 2 and b._retain_base == offs[4] and b._released == 4
-    b.append(one(6, tuning=64, n=2))                      # an in-kernel scan gives up here (two tiles: the second one's row is "unknown") ...
+    b.append(one(6, tuning=FAULT, n=2))                     # an in-kernel scan gives up here (two tiles: the second one's row is "unknown") ...
     b.append(one(8))
     cloud = b.finish()                                    # ... and the redo replays the batches of views 4..8 from the row behind view 3
     assert b.healed == 1
@@ -363,11 +363,11 @@ def test_small_appends_chained_across_two_streams_write_the_same_cloud(dd, shape
     # a give-up in the middle of a chain: the calls behind it learn from the chain word that their rows are unknown and write nothing
     b.reset()
     for i, s in enumerate(ones[:6]):
-        s.tuning = 64 if i == 2 else 0
+        set_on(s, FAULT if i == 2 else 0)
         b.append(s)
     s_bad = ones[2]
     got = b.finish()
-    s_bad.tuning = 0
+    set_on(s_bad, 0)
     assert b.healed == 1 and not b.exclusive_gpu                           # healed two-pass; tickets from here on
     assert torch.equal(got.points, want.points[:len(got)]) and len(got) == int(want.view_offsets[6])
 

@@ -16,7 +16,9 @@ import torch
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
 import bench  # noqa: E402
+import lab_bits  # noqa: E402
 import depthdensifier_amd as dd  # noqa: E402
 from depthdensifier_amd import _lib  # noqa: E402
 
@@ -38,6 +40,7 @@ def build(tag: str, flags: list) -> C.CDLL:
         return None
     lib = C.CDLL(str(out))
     lib.dd_unproject_compact.restype = C.c_int
+    lib.dd_debug_tuning.restype, lib.dd_debug_tuning.argtypes = C.c_uint32, [C.c_uint32]
     lib.dd_unproject_compact.argtypes = [C.POINTER(_lib.DDViewBatch), C.POINTER(_lib.DDCloudOut), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     return lib
 
@@ -68,7 +71,7 @@ def main():
     H, W = cfg["H"], cfg["W"]
     params = np.tile([0.8 * W, 0.8 * W, W / 2.0, H / 2.0], (a.views, 1))
     batch = dd.ViewBatch(scene["depth"], params, bench.ring_poses(ids, a.views), mask=scene["mask"], normal=scene["normal"], rgb=scene["rgb"],
-                         conf=scene["conf"], conf_threshold=cfg.get("conf"), device=dev, tuning=a.tuning)
+                         conf=scene["conf"], conf_threshold=cfg.get("conf"), device=dev, tuning=lab_bits.split(a.tuning)[0])
     builder = dd.CloudBuilder(batch.max_points, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=False, device=dev)
     cb, out = batch.c_struct(), builder._out_struct()
     ws = torch.zeros(4 * batch.workspace_bytes() + 4096, dtype=torch.uint8, device=dev)      # variants with smaller tiles need more
@@ -78,18 +81,20 @@ def main():
     tunings = {}
     for spec in a.variants:
         tag, _, fl = spec.partition(":")
-        name, _, tun = tag.partition("@")              # "name@16" = this variant runs with DDViewBatch.tuning = --tuning | 16
-        tunings[tag] = a.tuning | int(tun or 0)
+        name, _, tun = tag.partition("@")              # "name@16" = this variant runs with the variant word --tuning | 16 (tests/lab_bits.py:
+        tunings[tag] = lab_bits.split(a.tuning | int(tun or 0))      # a product tuning + experiment switches of include/ddcore_lab.h)
         libs.append((tag, build(name, [f for f in fl.split(",") if f]), []))
     ref = None
     for r in range(a.rounds + 1):
         for tag, lib, times in libs:
             builder.cursor.zero_()
-            cb.tuning = tunings[tag]
+            cb.tuning = tunings[tag][0]
+            lib.dd_debug_tuning(tunings[tag][1])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             rc = lib.dd_unproject_compact(C.byref(cb), C.byref(out), offs.data_ptr(), builder.cursor.data_ptr(), ws.data_ptr(), ws.numel(), stream)
             e1.record()
+            lib.dd_debug_tuning(0)
             torch.cuda.synchronize()
             assert rc == 0, (tag, rc)
             if r == 0:
@@ -107,8 +112,10 @@ def main():
                 continue
             for rep in range(2):
                 st.zero_(); builder.cursor.zero_()
-                cb.tuning = tunings[tag]
+                cb.tuning = tunings[tag][0]
+                lib.dd_debug_tuning(tunings[tag][1])
                 rc = lib.dd_unproject_compact(C.byref(cb), C.byref(out), offs.data_ptr(), builder.cursor.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+                lib.dd_debug_tuning(0)
                 torch.cuda.synchronize()
             s_ = st.cpu().numpy().astype(np.float64)
             ok = s_[:, 4] > 0

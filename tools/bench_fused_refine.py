@@ -11,7 +11,7 @@ import bench, depthdensifier_amd as dd
 from depthdensifier_amd.depth_refiner import DepthRefiner
 
 ap = argparse.ArgumentParser(); ap.add_argument("--views", type=int, default=64)
-ap.add_argument("--tuning", type=lambda x: int(x, 0), default=0, help="DDViewBatch.tuning of the fused batch (bit 27: bisect all knots, bit 28: one median per window)")
+ap.add_argument("--tuning", type=lambda x: int(x, 0), default=0, help="variant word of the fused batch (tests/lab_bits.py; bit 27: bisect all knots, bit 28: one median per window -- experiment switches of include/ddcore_lab.h)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 cfg = dict(bench.WORKLOADS["garden185"]); cfg["V"] = a.views
@@ -35,7 +35,9 @@ def unfused():
 
 fused_batch = dd.ViewBatch(scene["depth"], params, E, mask=scene["mask"], normal=scene["normal"], rgb=scene["rgb"], device=dev,
                            refine=[(kx, ky, False)] * V, refined_out=True)
-fused_batch.tuning = a.tuning
+sys.path.insert(0, str(ROOT / "tests"))
+import lab_bits
+lab_bits.set_on(fused_batch, a.tuning)
 def fused():
     b.reset(); b.append(fused_batch)
 

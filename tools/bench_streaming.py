@@ -23,7 +23,9 @@ import torch
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tools"))
+sys.path.insert(0, str(ROOT / "tests"))
 import bench  # noqa: E402
+import lab_bits  # noqa: E402  (variant words: a product tuning + the experiment switches of include/ddcore_lab.h)
 import depthdensifier_amd as dd  # noqa: E402
 from depthdensifier_amd._lib import lib, check  # noqa: E402
 
@@ -95,7 +97,7 @@ def main():
         for tag in a.variants.split(","):
             tun = tuning_of(tag)
             for s in subs:
-                s.tuning = tun
+                lab_bits.set_on(s, tun)
             res = {}
             # (i) the product's host path
             def chain_builder():
@@ -109,9 +111,13 @@ def main():
             ws = builder._workspace(max(s.workspace_bytes() for s in subs))
             sp = stream.cuda_stream
 
+            from depthdensifier_amd._lib import lab_switches
+            t_lab = lab_bits.split(tun)[1]
+
             def chain_abi():
                 builder.cursor.zero_()
-                for cs, offs in structs:
+                with lab_switches(t_lab):
+                  for cs, offs in structs:
                     rc = lib.dd_unproject_compact(C.byref(cs), C.byref(out), offs.data_ptr(), builder.cursor.data_ptr(), ws.data_ptr(), ws.numel(), sp)
                     assert rc == 0
             modes = [("builder.append", chain_builder), ("C ABI", chain_abi)]
@@ -187,7 +193,7 @@ def main():
                 print(f"k={k:3d} {tag:10s} {name:15s} chain {med:8.3f} ms (min {min(ts):7.3f})  per call {1e3 * med / len(subs):7.2f} us  frac {alg / med / 1e6 / 8000:5.3f}  "
                       f"host enqueue {float(np.median(hs)):7.3f} ms  calls {len(subs)}  rows {'ok' if ok else 'WRONG'} err {err}", flush=True)
             for s in subs:
-                s.tuning = 0
+                lab_bits.set_on(s, 0)
 
 
 if __name__ == "__main__":
