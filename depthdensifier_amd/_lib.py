@@ -59,6 +59,7 @@ EXPORTS = (
     "dd_arena_alloc",
     "dd_arena_free",
     "dd_arena_trim",
+    "dd_arena_set_pool",
     "dd_arena_classes",
     "dd_arena_probe",
     "dd_arena_stats",
@@ -245,6 +246,8 @@ def _load() -> C.CDLL:
     lib.dd_arena_free.argtypes = [C.c_void_p, C.c_void_p]
     lib.dd_arena_trim.restype = C.c_int
     lib.dd_arena_trim.argtypes = [C.c_void_p, C.c_int32]
+    lib.dd_arena_set_pool.restype = C.c_int
+    lib.dd_arena_set_pool.argtypes = [C.c_void_p, C.c_int32]
     lib.dd_arena_classes.restype = C.c_int
     lib.dd_arena_classes.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int32]
     lib.dd_arena_probe.restype = C.c_int

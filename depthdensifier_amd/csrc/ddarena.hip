@@ -629,6 +629,14 @@ int dd_arena_free(DDArena *A, void *ptr) {
     return afail(DD_ERR_INVALID_ARG, "ptr was not allocated by this arena");
 }
 
+int dd_arena_set_pool(DDArena *A, int32_t pool_chunks_per_class) {
+    if (!A) return afail(DD_ERR_INVALID_ARG, "arena is NULL");
+    if (pool_chunks_per_class < 0) return afail(DD_ERR_INVALID_ARG, "pool_chunks_per_class is negative");
+    std::lock_guard<std::mutex> lock(A->mu);
+    A->pool_per_class = pool_chunks_per_class;      // (nothing is released, nothing is unmapped: only what happens to chunks freed from now on)
+    return DD_OK;
+}
+
 int dd_arena_trim(DDArena *A, int32_t pool_chunks_per_class) {
     if (!A) return afail(DD_ERR_INVALID_ARG, "arena is NULL");
     std::lock_guard<std::mutex> lock(A->mu);

@@ -68,6 +68,12 @@ class ProcessingConfig:
     """Consecutive equally sized views densified by ONE kernel launch at full density (downsample_density = 1): their fits are
     enqueued back to back and read in one go, their maps stacked on the device, one ViewBatch / dd_unproject_compact with a
     transfer curve per view.  1 = a launch per view (rounds 1-2).  Same model either way."""
+    exclusive_gpu: Optional[bool] = None
+    """This process's densify stream has its GPU to itself -- the reference is ONE process that owns its GPU, and scripts/run_batch.py
+    under torchrun is one process per GPU: the single-pass kernel then takes its tiles by workgroup index and small appends are
+    chained across two side streams (CloudBuilder.exclusive_gpu; a launch that finds the GPU shared after all is redone and the
+    cloud falls back to tickets by itself).  None (default) = yes, unless DD_EXCLUSIVE_GPU=0 or the job's local ranks outnumber
+    the visible GPUs (a rehearsal: ranks share a card)."""
     shard_views: bool = True
     """Under torchrun (one process per GPU): shard this scan's views over the ranks.  The batch driver turns it
     off because it shards by scan."""
@@ -133,6 +139,17 @@ class _Ranks:
             import torch.distributed as dist
             dist.barrier()
             dist.destroy_process_group()
+
+
+def _exclusive_gpu(processing: "ProcessingConfig") -> bool:
+    """``ProcessingConfig.exclusive_gpu`` resolved: an explicit choice stands; otherwise on, unless the environment says
+    ``DD_EXCLUSIVE_GPU=0`` or more local ranks than GPUs were started (they share a card)."""
+    if processing.exclusive_gpu is not None:
+        return bool(processing.exclusive_gpu)
+    if os.environ.get("DD_EXCLUSIVE_GPU") is not None:
+        return os.environ["DD_EXCLUSIVE_GPU"] == "1"
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    return local_world <= max(1, torch.cuda.device_count())
 
 
 def _votes_single(cloud, cached, depth_threshold):
@@ -207,7 +224,7 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
         capacity += (-(-ph // s)) * (-(-pw // s))
     # (views are appended a few at a time here: launches of 26 us whose rows sit in one chunk anyway -- the default rule applies: a
     # placed cloud when the scan is large or the arena already holds classified spares from an earlier scan, no scouting otherwise)
-    builder = CloudBuilder(capacity, normals=True, colors=True, pixel_index=False, device=device)
+    builder = CloudBuilder(capacity, normals=True, colors=True, pixel_index=False, device=device, exclusive_gpu=_exclusive_gpu(config.processing))
     cached = []                                                                 # :128 cached_refinement_data
     stage = {"image_decode": 0.0, "depth_source": 0.0, "refine": 0.0, "densify": 0.0}     # host seconds per stage
     clock = time.perf_counter

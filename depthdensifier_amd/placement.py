@@ -195,7 +195,7 @@ def keep_everything(device) -> None:
     request.  For a process under ``rocprofv3``: with the profiler loaded ``hipMemRelease`` does not return the memory to the device
     (measured: ``tools/arena_free_probe.py``, ``profiles/r05_arena_free_under_rocprofv3.txt``), so a chunk that is released is lost
     until the process ends, while a pooled one is used again."""
-    get_arena(device).trim(1 << 20)
+    _acheck(lib.dd_arena_set_pool(get_arena(device)._handle, 1 << 20))      # (not trim(): that would release every spare chunk and the mapped cache right now)
 
 
 def trim(device=None) -> None:

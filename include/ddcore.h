@@ -408,6 +408,9 @@ int dd_arena_alloc(DDArena *arena, int32_t n, const int64_t *sizes, const int32_
 int dd_arena_free(DDArena *arena, void *ptr);
 /* Empties the cache and gives every spare chunk back to the driver; pool_chunks_per_class >= 0 also sets how many are kept from now on. */
 int dd_arena_trim(DDArena *arena, int32_t pool_chunks_per_class);
+/* Only sets how many spare chunks per class are kept from now on (ABI 14): nothing is released, the cache stays mapped.  For a process in
+ * which released physical memory does not come back to the device (under rocprofv3): keep everything, give nothing away. */
+int dd_arena_set_pool(DDArena *arena, int32_t pool_chunks_per_class);
 /* Class of every chunk behind an array: returns the number of chunks, writes min(that, capacity) entries. */
 int dd_arena_classes(DDArena *arena, const void *ptr, int32_t *classes_out, int32_t capacity);
 /* The probe on two windows (probe_bytes each) chosen by the caller, milliseconds (diagnostics, tests). */
