@@ -24,6 +24,7 @@ LIB_PATH = Path(os.environ.get("DDCORE_LIB", _HERE / "libddcore.so"))
 DD_ABI_VERSION = 14
 DD_OK = 0
 DD_F32, DD_F16 = 0, 1
+DD_NPY_F32, DD_NPY_F16, DD_NPY_U8, DD_NPY_BOOL = 0, 1, 2, 3
 DD_VALID_DEPTH_POSITIVE = 0x1
 DD_VALID_MASK = 0x2
 DD_VALID_CONF = 0x4
@@ -50,9 +51,14 @@ EXPORTS = (
     "dd_refine_apply",
     "dd_refine_last_error",
     "dd_refine_fit",
+    "dd_refine_fit_async",
     "dd_sort_knots",
     "dd_allgatherv",
     "dd_comm_last_error",
+    "dd_npy_header",
+    "dd_npy_read",
+    "dd_upload_async",
+    "dd_ingest_last_error",
     "dd_format_points3d",
     "dd_model_last_error",
     "dd_arena_create",
@@ -144,7 +150,7 @@ def DD_TUNE_INTERLEAVE(k: int) -> int:
 
 # include/ddcore_lab.h: the thread-local experiment switches (tests, A/B tools) -- never set by the product path
 DD_LAB_LIST_ORDER, DD_LAB_FAULT_INJECT, DD_LAB_POLL_LANES_32, DD_LAB_POLL_LANES_64 = 1, 2, 4, 8
-DD_LAB_LOOKBACK, DD_LAB_REFINE_BISECT, DD_LAB_REFINE_MEDIAN9, DD_LAB_APPLY_PLAIN = 16, 32, 64, 128
+DD_LAB_LOOKBACK, DD_LAB_APPLY_PLAIN = 16, 128
 
 
 def DD_LAB_APPLY_WGS(n: int) -> int:
@@ -228,12 +234,23 @@ def _load() -> C.CDLL:
     lib.dd_refine_fit.restype = C.c_int
     lib.dd_refine_fit.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.dd_refine_fit_async.restype = C.c_int
+    lib.dd_refine_fit_async.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.dd_sort_knots.restype = C.c_int
     lib.dd_sort_knots.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.dd_allgatherv.restype = C.c_int
     lib.dd_allgatherv.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(DDCloudOut), C.POINTER(C.c_int64), C.c_int32, C.c_void_p]
     lib.dd_comm_last_error.restype = C.c_char_p
     lib.dd_comm_last_error.argtypes = []
+    lib.dd_npy_header.restype = C.c_int
+    lib.dd_npy_header.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.dd_npy_read.restype = C.c_int
+    lib.dd_npy_read.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.c_void_p, C.c_int64]
+    lib.dd_upload_async.restype = C.c_int
+    lib.dd_upload_async.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]
+    lib.dd_ingest_last_error.restype = C.c_char_p
+    lib.dd_ingest_last_error.argtypes = []
     lib.dd_format_points3d.restype = C.c_int
     lib.dd_format_points3d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.dd_model_last_error.restype = C.c_char_p

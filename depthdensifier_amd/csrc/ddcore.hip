@@ -106,7 +106,6 @@ struct KArgs {
     WsHeader *hdr;
     unsigned long long *gran;     // look-back granules, one per tile of the single-pass tiling
     unsigned long long *pref;     // scan service: the first row of every tile, written by the service workgroup (same tags as the granules)
-    int refine_plain;             // DD_REFINE, tuning bits 27 / 28 (A/B switches): 1 = bisect all knots, 2 = one median per window
     int scan_service;             // single-pass lean kernel: one workgroup of the launch scans the tiles' counts, the tiles poll their own row
     unsigned long long *chain;    // ABI 12: the word that chains this call behind the previous one of the same cloud on another stream (or NULL)
     unsigned chain_seq;           // ... and the sequence number the word must show before this call's scan may start
@@ -1160,8 +1159,11 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[LT * 6];
     float *const s_d = reinterpret_cast<float *>(s_raw);                              // 4 B per pixel
     unsigned short *const s_q = reinterpret_cast<unsigned short *>(s_raw + LT * 4);  // 2 B per pixel
-    __shared__ float s_knots[REFINE ? 2 * REFINE_MAX_KNOTS : 1];
-    __shared__ unsigned short s_grid[REFINE ? ddmath::LUT_BUCKETS : 1];      // where in the knots to start looking (ddrefine_math.h)
+    // the fused refine stage's transfer curve (ddrefine_math.h): knots {x, y}, reciprocal widths of the intervals, the grid of buckets.
+    // (LDS is the budget: 73728 + 7680 + ... = 81.5 KB -- two workgroups still share a CU's 160 KiB)
+    __shared__ float2 s_kxy[REFINE ? REFINE_MAX_KNOTS : 1];
+    __shared__ float s_inv[REFINE ? REFINE_MAX_KNOTS : 1];
+    __shared__ unsigned short s_grid[REFINE ? ddmath::CURVE_GRID_WORDS : 2];
     __shared__ unsigned s_tot[NW];
     __shared__ long long s_excl;
     __shared__ unsigned s_ticket;
@@ -1237,64 +1239,53 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
         static_assert(sizeof(DepthT) == 4 && SINGLE_PASS, "the fused refine stage runs in the float32 single-pass instantiation");
         // ---- src/depthdensifier/depth_refiner.py:180-205 on this tile, from the RAW depth (scripts/test.py:179-194 fused in) ----
         const DDViewParams *vp = a.params + v;
-        const int nk = vp->n_knots < REFINE_MAX_KNOTS ? vp->n_knots : REFINE_MAX_KNOTS;      // wave-uniform; 2..512 by contract (the clamp keeps a bad value inside the LDS array)
-        float *const s_kx = s_knots, *const s_ky = s_knots + REFINE_MAX_KNOTS;
-        for (int i = tid; i < nk; i += BT) { s_kx[i] = vp->knots_x[i]; s_ky[i] = vp->knots_y[i]; }
+        const int nk = vp->n_knots < REFINE_MAX_KNOTS ? vp->n_knots : REFINE_MAX_KNOTS;      // wave-uniform; 2..512 by contract (the clamp keeps a bad value inside the LDS arrays)
         // transformed values of the tile plus W + 1 pixels either side (a 3x3 window of a pixel of the tile reaches one
         // row up and down); replicate padding = clamped coordinates, so nothing outside the view is ever needed
         float *const s_val = reinterpret_cast<float *>(s_raw);
         const unsigned Wd = (unsigned)a.W, Hd = (unsigned)a.H;
         const unsigned lo = q0 > Wd + 1u ? q0 - (Wd + 1u) : 0u;
         const unsigned hi = (q0 + (unsigned)LT + Wd + 1u) < a.P ? (q0 + (unsigned)LT + Wd + 1u) : a.P;
-        __syncthreads();
-        // Round 5: this stage is bound by the vector ALU, not by memory (24 us per 1080p view where the plain kernel takes 14): the curve
-        // is found through a grid of buckets instead of a bisection of all knots (~10 dependent LDS reads -> ~2), and four consecutive
-        // windows share their sorted columns (median9x4).  Same bits as ddmath::lut / median9 (dd_refine_apply), which the tests compare.
-        const ddmath::LutGrid grid = ddmath::lut_grid(s_kx, nk);
-        for (int j = tid; j < ddmath::LUT_BUCKETS; j += BT) s_grid[j] = ddmath::lut_grid_entry(s_kx, nk, grid, j);
-        __syncthreads();
+        // Rounds 5-6: this stage is bound by the vector ALU, not by memory (24 us per 1080p view where the plain kernel takes 14).  The
+        // curve's interval is found through a grid of buckets (the knots that share the depth's bucket: ~1), the blend reads both knots
+        // with one LDS access and multiplies by the interval's reciprocal width instead of dividing (ddrefine_math.h), four values per
+        // lane and step with their bisections in lock step; four consecutive windows share their sorted columns (median9x4).
+        const ddmath::Curve curve = ddmath::curve_build(s_kxy, s_inv, s_grid, vp->knots_x, vp->knots_y, nk, tid, BT);
         // (tried in round 2: batches of 7 pixels per lane with their loads issued together and a fixed-trip lockstep search --
         // 6 % SLOWER on the same box; the other waves of the CU already hide these latencies and the early-exit search does less work)
         bool any_nan = false;
-        if (a.refine_plain & 1) {
-            for (unsigned e = lo + (unsigned)tid; e < hi; e += (unsigned)BT) {
-                const long long p = vbase + e;
-                const float raw = a.raw_f16 ? (float)reinterpret_cast<const _Float16 *>(a.depth)[p] : reinterpret_cast<const float *>(a.depth)[p];
-                const bool mk = a.mask ? (a.mask[p] != 0) : (raw > 0.0f);         // depth_refiner.py:238-241
-                const float val = mk ? ddmath::lut(s_kx, s_ky, nk, raw) : 0.0f;   // :185-191
-                any_nan |= val != val;
-                s_val[e - lo] = val;
-            }
-        } else {
-            // four consecutive values per lane and step: one wide load of the depth, one of the mask, four look-ups in lock step
+        {
+            // four consecutive values per lane and step: one wide load of the depth, one of the mask, four look-ups in lock step.
+            // Scalar bases + 32-bit byte offsets (the window is < 2^16 values): no 64-bit address arithmetic per lane.
             const unsigned cnt = hi - lo;
-            const long long pb = vbase + lo;
+            const unsigned char *const dbase = reinterpret_cast<const unsigned char *>(a.depth) + (vbase + lo) * (a.raw_f16 ? 2 : 4);
+            const unsigned char *const mbase = a.mask ? a.mask + vbase + lo : nullptr;
             for (unsigned e4 = (unsigned)tid * 4u; e4 < cnt; e4 += (unsigned)BT * 4u) {
                 float raw[4], val[4];
                 bool mk[4];
                 const bool whole = e4 + 4u <= cnt;
                 if (whole) {
                     if (a.raw_f16) {
-                        const u32x2 w = *reinterpret_cast<const u32x2_unaligned *>(reinterpret_cast<const _Float16 *>(a.depth) + pb + e4);
+                        const u32x2 w = *reinterpret_cast<const u32x2_unaligned *>(dbase + e4 * 2u);
                         raw[0] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w.x & 0xffffu)); raw[1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w.x >> 16));
                         raw[2] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w.y & 0xffffu)); raw[3] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w.y >> 16));
                     } else {
-                        const u32x4 w = *reinterpret_cast<const u32x4_unaligned *>(reinterpret_cast<const float *>(a.depth) + pb + e4);
+                        const u32x4 w = *reinterpret_cast<const u32x4_unaligned *>(dbase + e4 * 4u);
                         raw[0] = __uint_as_float(w.x); raw[1] = __uint_as_float(w.y); raw[2] = __uint_as_float(w.z); raw[3] = __uint_as_float(w.w);
                     }
-                    const unsigned m4 = a.mask ? *reinterpret_cast<const u32_unaligned *>(a.mask + pb + e4) : 0u;
+                    const unsigned m4 = mbase ? *reinterpret_cast<const u32_unaligned *>(mbase + e4) : 0u;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) mk[k] = a.mask ? ((m4 >> (8 * k)) & 0xffu) != 0u : (raw[k] > 0.0f);      // depth_refiner.py:238-241
+                    for (int k = 0; k < 4; ++k) mk[k] = mbase ? ((m4 >> (8 * k)) & 0xffu) != 0u : (raw[k] > 0.0f);      // depth_refiner.py:238-241
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const bool in = e4 + (unsigned)k < cnt;
-                        const long long p = pb + e4 + (in ? k : 0);
-                        raw[k] = a.raw_f16 ? (float)reinterpret_cast<const _Float16 *>(a.depth)[p] : reinterpret_cast<const float *>(a.depth)[p];
-                        mk[k] = in && (a.mask ? (a.mask[p] != 0) : (raw[k] > 0.0f));
+                        const unsigned e = e4 + (in ? (unsigned)k : 0u);
+                        raw[k] = a.raw_f16 ? (float)*reinterpret_cast<const _Float16 *>(dbase + e * 2u) : *reinterpret_cast<const float *>(dbase + e * 4u);
+                        mk[k] = in && (mbase ? (mbase[e] != 0) : (raw[k] > 0.0f));
                     }
                 }
-                ddmath::lut_grid_eval4(s_kx, s_ky, nk, grid, s_grid, raw, mk, val);          // :185-191
+                ddmath::curve_eval4(curve, raw, mk, val);                                     // :185-191
                 any_nan |= (val[0] != val[0]) | (val[1] != val[1]) | (val[2] != val[2]) | (val[3] != val[3]);
                 if (whole) *reinterpret_cast<float4 *>(s_val + e4) = make_float4(val[0], val[1], val[2], val[3]);
                 else {
@@ -1316,7 +1307,7 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
             y = y0g; x = x0g;
             unsigned b = 0;
             // four windows of one image row, none at the left or right border, no NaN in the tile: their columns are sorted once
-            const bool fast = smooth && !tile_nan && !(a.refine_plain & 2) && VEC == 4 && qb + 4u <= a.P && x >= 1u && x + 5u <= Wd;
+            const bool fast = smooth && !tile_nan && VEC == 4 && qb + 4u <= a.P && x >= 1u && x + 5u <= Wd;
             if (fast) {
                 const unsigned ym = y ? y - 1u : 0u, yp = y + 1u < Hd ? y + 1u : Hd - 1u;
                 const float *const r1 = s_val + (y * Wd + x - 1u - lo);
@@ -2008,7 +1999,6 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
         const bool small = (tsel == 1u || (tsel == 0u && big_tiles <= SP_SMALL_BATCH_TILES)) && !p.refine;
         p.sp_pxt = small ? SP_PXT_SMALL : L_PXT;
         a.scan_service = p.lean && (lab & DD_LAB_LOOKBACK) == 0u;
-        a.refine_plain = ((lab & DD_LAB_REFINE_BISECT) ? 1 : 0) | ((lab & DD_LAB_REFINE_MEDIAN9) ? 2 : 0);
         a.static_tiles = (int)((b->tuning >> 22) & 1u);
         a.lb_lanes = wsel == 2u ? 32u : wsel == 3u ? 64u : (unsigned)LB_LANES;
         if (b->chain) {

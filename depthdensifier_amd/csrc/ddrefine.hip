@@ -95,15 +95,12 @@ constexpr int PSTRIDE = PHW + 1;             // LDS row stride (67 words: rows s
 
 __global__ __launch_bounds__(256) void refine_apply_tiles(const RArgs a, const int tiles_x, const int tiles) {
     __shared__ float s_val[PHH * PSTRIDE];
-    extern __shared__ float s_knots[];                 // 2 n floats: the workgroup's LDS follows the number of knots (more workgroups per CU)
-    float *const s_kx = s_knots, *const s_ky = s_knots + a.n;
-    __shared__ unsigned short s_grid[ddmath::LUT_BUCKETS];
+    extern __shared__ float2 s_knots[];                // 3 n floats: n knots {x, y}, then the n reciprocal interval widths -- the workgroup's
+    float2 *const s_kxy = s_knots;                     // LDS follows the number of knots (more workgroups per CU)
+    float *const s_inv = reinterpret_cast<float *>(s_knots + a.n);
+    __shared__ unsigned short s_grid[ddmath::CURVE_GRID_WORDS];
     const int tid = threadIdx.x;
-    for (int i = tid; i < a.n; i += 256) { s_kx[i] = a.kx[i]; s_ky[i] = a.ky[i]; }
-    __syncthreads();
-    const ddmath::LutGrid grid = ddmath::lut_grid(s_kx, a.n);
-    for (int j = tid; j < ddmath::LUT_BUCKETS; j += 256) s_grid[j] = ddmath::lut_grid_entry(s_kx, a.n, grid, j);
-    __syncthreads();
+    const ddmath::Curve curve = ddmath::curve_build(s_kxy, s_inv, s_grid, a.kx, a.ky, a.n, tid, 256);
     for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
         const int x0 = tx * PW, y0 = ty * PH;
@@ -126,7 +123,7 @@ __global__ __launch_bounds__(256) void refine_apply_tiles(const RArgs a, const i
                 mk[k] = in && (a.mask ? (a.mask[idx] != 0) : (d[k] > 0.0f));      // :238-241
                 at[k] = in ? ly * PSTRIDE + lx : -1;
             }
-            ddmath::lut_grid_eval4(s_kx, s_ky, a.n, grid, s_grid, d, mk, val);    // :185-191
+            ddmath::curve_eval4(curve, d, mk, val);                               // :185-191
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (at[k] >= 0) { s_val[at[k]] = val[k]; any_nan |= val[k] != val[k]; }
@@ -378,6 +375,23 @@ __global__ __launch_bounds__(1024) void sort_knots_kernel(const float *x, const 
 
 thread_local char g_rerr[192] = "";
 
+// the number of masked pixels of a view (mask != 0, or depth > 0 without a mask: depth_refiner.py:238-241), clamped to 2^31 - 1
+// (what DepthRefiner needs to choose between the curve and the degenerate branches of :143-154)
+__global__ __launch_bounds__(256) void count_masked_kernel(const uint8_t *mask, const void *depth, const int f16, const long long hw, int *out) {
+    long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 64;
+    int cnt = 0;
+    for (int k = 0; k < 64 && i + k < hw; ++k) {
+        const long long j = i + k;
+        cnt += mask ? (mask[j] != 0) : ((f16 ? (float)reinterpret_cast<const _Float16 *>(depth)[j] : reinterpret_cast<const float *>(depth)[j]) > 0.0f);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if ((threadIdx.x & 63) == 0 && cnt) {
+        const int before = atomicAdd(out, cnt);
+        if (before < 0 || before + cnt < 0) atomicExch(out, 0x7fffffff);      // (saturates: views of 2^31 pixels do not exist on this path)
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -402,7 +416,7 @@ int dd_refine_apply(const void *depth, int32_t depth_dtype, const uint8_t *mask,
         const int tiles_x = (width + PW - 1) / PW, tiles = tiles_x * ((height + PH - 1) / PH);
         const int lab_wgs = (int)((lab >> 8) & 0x1fffu), max_wgs = lab_wgs > 0 ? lab_wgs : 4096;
         const int wgs = tiles < max_wgs ? tiles : max_wgs;     // (the knots and their grid are built once per workgroup)
-        hipLaunchKernelGGL(refine_apply_tiles, dim3(wgs), dim3(256), (size_t)n_knots * 2 * sizeof(float), (hipStream_t)stream, a, tiles_x, tiles);
+        hipLaunchKernelGGL(refine_apply_tiles, dim3(wgs), dim3(256), (size_t)n_knots * 3 * sizeof(float), (hipStream_t)stream, a, tiles_x, tiles);
     } else {
         const dim3 grid((width + TW - 1) / TW, (height + TH - 1) / TH);
         hipLaunchKernelGGL(refine_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -428,6 +442,30 @@ int dd_refine_fit(const float *points, int32_t n, const float *cam_from_world, c
     a.edge_margin = edge_margin; a.robust = robust; a.half_io = half_precision_io;
     hipLaunchKernelGGL(refine_fit_kernel, dim3(1), dim3(FIT_T), 0, (hipStream_t)stream, a);
     if (hipGetLastError() != hipSuccess) { snprintf(g_rerr, sizeof(g_rerr), "refine_fit launch failed"); return DD_ERR_LAUNCH; }
+    return DD_OK;
+}
+
+int dd_refine_fit_async(const float *points_host, int32_t n, const float *cam_from_world, const float *calibration, const void *depth,
+                        int32_t depth_dtype, int32_t height, int32_t width, int32_t edge_margin, int32_t robust, float outlier_threshold,
+                        int32_t half_precision_io, const uint8_t *mask, float *work, int32_t *meta_dev, int32_t *meta_host,
+                        void *ready_event, void *stream) {
+    auto fail = [](const char *m) { snprintf(g_rerr, sizeof(g_rerr), "%s", m); return DD_ERR_INVALID_ARG; };
+    if (n < 0) return fail("n is negative");
+    if (!meta_dev || !meta_host) return fail("meta_dev / meta_host is NULL");
+    if (n > 0 && (!points_host || !work)) return fail("points_host / work is NULL");
+    hipStream_t s = (hipStream_t)stream;
+    // one stream, in order: the sparse points up, the result words cleared, the fit, the number of masked pixels, the words down, the event
+    if (n > 0 && hipMemcpyAsync(work, points_host, (size_t)n * 12, hipMemcpyHostToDevice, s) != hipSuccess) { (void)hipGetLastError(); snprintf(g_rerr, sizeof(g_rerr), "hipMemcpyAsync(points) failed"); return DD_ERR_LAUNCH; }
+    if (hipMemsetAsync(meta_dev, 0, 32, s) != hipSuccess) { (void)hipGetLastError(); snprintf(g_rerr, sizeof(g_rerr), "hipMemsetAsync(meta) failed"); return DD_ERR_LAUNCH; }
+    float *const z_mono = work + (size_t)3 * n, *const z_metric = z_mono + n, *const scratch = z_metric + n;
+    int rc = dd_refine_fit(work, n, cam_from_world, calibration, depth, depth_dtype, height, width, edge_margin, robust, outlier_threshold,
+                           half_precision_io, z_mono, z_metric, scratch, meta_dev, stream);
+    if (rc != DD_OK) return rc;
+    const long long hw = (long long)height * width;
+    hipLaunchKernelGGL(count_masked_kernel, dim3((unsigned)((hw + 16383) / 16384)), dim3(256), 0, s, mask, depth, depth_dtype == DD_F16 ? 1 : 0, hw, meta_dev + 5);
+    if (hipGetLastError() != hipSuccess) { snprintf(g_rerr, sizeof(g_rerr), "count_masked launch failed"); return DD_ERR_LAUNCH; }
+    if (hipMemcpyAsync(meta_host, meta_dev, 32, hipMemcpyDeviceToHost, s) != hipSuccess) { (void)hipGetLastError(); snprintf(g_rerr, sizeof(g_rerr), "hipMemcpyAsync(meta) failed"); return DD_ERR_LAUNCH; }
+    if (ready_event && hipEventRecord((hipEvent_t)ready_event, s) != hipSuccess) { (void)hipGetLastError(); snprintf(g_rerr, sizeof(g_rerr), "hipEventRecord failed"); return DD_ERR_LAUNCH; }
     return DD_OK;
 }
 

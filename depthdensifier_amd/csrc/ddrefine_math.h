@@ -9,19 +9,24 @@
 
 namespace ddmath {
 
-// the linear blend of :160-176 on the interval torch.searchsorted(xs, d, right=False) selects: `lo` = first index with kx[lo] >= d
-__device__ __forceinline__ float lut_blend(const float *kx, const float *ky, int n, float d, int lo) {
-#pragma clang fp contract(off)   // the reference rounds after the multiply (separate tensor ops): no FMA here
-    const int i = lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
-    const float x0 = kx[i - 1], x1 = kx[i], y0 = ky[i - 1], y1 = ky[i];
+// The linear blend of :160-176 between the knots (x0, y0) and (x1, y1).  Round 6: t = (d - x0) * (1 / dx) instead of (d - x0) / dx --
+// the reciprocal of an interval is a property of the CURVE (looked up once per interval, `Curve::inv`), the division was a tenth of
+// the fused refine stage's per-pixel instructions.  Differs from the reference's quotient by at most two ulps of t, i.e. by
+// 1.2e-7 |y1 - y0| in the value: inside the 4e-6-of-range float32 budget of tests/test_refiner.py (the golden is the bar);
+// every kernel of the library evaluates the curve through these two functions, so they agree with each other bit for bit.
+__device__ __forceinline__ float inv_dx(float x0, float x1) {
     float dx = x1 - x0;
-    if (dx == 0.0f) dx = 1e-6f;
-    float t = (d - x0) / dx;
+    if (dx == 0.0f) dx = 1e-6f;             // :165-166
+    return 1.0f / dx;
+}
+__device__ __forceinline__ float blend(float d, float x0, float y0, float y1, float inv) {
+#pragma clang fp contract(off)   // the reference rounds after every tensor op: no FMA here
+    float t = (d - x0) * inv;
     t = fminf(fmaxf(t, 0.0f), 1.0f);
     return fmaxf(y0 + t * (y1 - y0), 1e-3f);
 }
 
-// torch.searchsorted(xs, d, right=False) clamped to [1, n-1], then the blend
+// torch.searchsorted(xs, d, right=False) clamped to [1, n-1], then the blend: the plain form (any number of knots, global or LDS arrays)
 __device__ __forceinline__ float lut(const float *kx, const float *ky, int n, float d) {
     if (d != d) return d;                   // torch.clamp / torch.maximum propagate a NaN depth (:168-176): the pixel later fails depth > 0
     int lo = 0, hi = n;                     // first index with kx[i] >= d
@@ -29,65 +34,99 @@ __device__ __forceinline__ float lut(const float *kx, const float *ky, int n, fl
         const int mid = (lo + hi) >> 1;
         if (kx[mid] < d) lo = mid + 1; else hi = mid;
     }
-    return lut_blend(kx, ky, n, d, lo);
+    const int i = lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
+    return blend(d, kx[i - 1], ky[i - 1], ky[i], inv_dx(kx[i - 1], kx[i]));
 }
 
-// The same value found faster (the densify kernel's fused refine stage evaluates the curve 16 000 times per tile): a grid of
-// LUT_BUCKETS equal buckets over [kx[0], kx[n-1]] holds, per bucket, a knot index that is known to lie at or before the answer;
-// the bisection then runs over three buckets' worth of knots (~1 knot per bucket).  The interval is the one `lut` finds --
-// lower_bound is monotone, and both ends are lower_bounds of values a whole bucket away from any depth of the bucket, far more
-// than the rounding of either side (the grid is switched off, inv = 0, when a bucket is not much wider than an ulp of the knots).
-#ifndef DD_LUT_BUCKETS
-#define DD_LUT_BUCKETS 512          // (1024: the same speed, 1 KiB more LDS per workgroup)
+// ==================================================================================================
+// The curve as the kernels keep it in LDS (round 6): the knots interleaved {x, y} (one 16-byte read fetches both ends of an
+// interval), the reciprocal width of every interval, and a grid of CURVE_BUCKETS equal buckets over [x_first, x_last] that says
+// where in the knots to look: entry j = the number of knots whose BUCKET is below j.  The bucket function is monotone in its
+// argument (a rounded subtraction of a constant, a rounded multiplication by a positive constant, a clamp, a truncation), so for a
+// depth d of bucket b every knot of a lower bucket is < d and every knot of a higher bucket is > d: lower_bound(d) lies in
+// [grid[b], grid[b + 1]] -- exactly the knots that share d's bucket (about one on average), whatever the rounding does.
+// (Round 5 derived the grid from bucket EDGES computed on their own and had to search three buckets to be safe.)
+// ==================================================================================================
+#ifndef DD_CURVE_BUCKETS
+#define DD_CURVE_BUCKETS 768
 #endif
-constexpr int LUT_BUCKETS = DD_LUT_BUCKETS;
+constexpr int CURVE_BUCKETS = DD_CURVE_BUCKETS;
+constexpr int CURVE_GRID_WORDS = CURVE_BUCKETS + 2;             // entries 0 .. CURVE_BUCKETS, padded to an even count
 
-struct LutGrid {
-    float x0, inv;                          // bucket of d: (d - x0) * inv, clamped to [0, LUT_BUCKETS - 1]
+struct Curve {
+    const float2 *kxy;            // n knots {x, y}, ascending x
+    const float *inv;             // inv[i] = inv_dx(x[i-1], x[i]) for i in [1, n)
+    const unsigned short *grid;   // CURVE_BUCKETS + 1 entries
+    int n;
+    float x0, scale;              // bucket of d: (d - x0) * scale, clamped to [0, CURVE_BUCKETS - 1]; scale 0 = everything in bucket 0
 };
-__device__ __forceinline__ LutGrid lut_grid(const float *kx, int n) {
-    const float x0 = kx[0], xn = kx[n - 1], range = xn - x0;
-    const bool ok = range > fmaxf(fabsf(x0), fabsf(xn)) * (1.0f / 128.0f) && range < 3.0e38f;
-    return LutGrid{x0, ok ? (float)LUT_BUCKETS / range : 0.0f};
+__device__ __forceinline__ int curve_bucket(float d, float x0, float scale) {
+    return (int)fminf(fmaxf((d - x0) * scale, 0.0f), (float)(CURVE_BUCKETS - 1));      // (NaN -> bucket 0: fmaxf returns the other operand)
 }
-// entry j of the grid: the first knot >= the lower edge of bucket j - 1 (0 for the first bucket and for a grid switched off)
-__device__ __forceinline__ unsigned short lut_grid_entry(const float *kx, int n, const LutGrid g, int j) {
-    if (j < 1 || g.inv == 0.0f) return 0;
-    const float edge = g.x0 + (float)(j - 1) * ((kx[n - 1] - g.x0) * (1.0f / (float)LUT_BUCKETS));
-    int lo = 0, hi = n;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (kx[mid] < edge) lo = mid + 1; else hi = mid;
+// the grid is useless where a bucket is not much wider than an ulp of the knots, or the range is not finite: one bucket then
+__device__ __forceinline__ float curve_scale(float x_first, float x_last) {
+    const float range = x_last - x_first;
+    const bool ok = range > fmaxf(fabsf(x_first), fabsf(x_last)) * (1.0f / 128.0f) && range < 3.0e38f;
+    return ok ? (float)CURVE_BUCKETS / range : 0.0f;
+}
+// Builds the curve in LDS from the sorted knots in memory; all `nthreads` threads of the workgroup call it (it contains barriers).
+__device__ __forceinline__ Curve curve_build(float2 *s_kxy, float *s_inv, unsigned short *s_grid, const float *kx, const float *ky, int n,
+                                             int tid, int nthreads) {
+    for (int i = tid; i < n; i += nthreads) s_kxy[i] = make_float2(kx[i], ky[i]);
+    __syncthreads();
+    Curve c;
+    c.kxy = s_kxy; c.inv = s_inv; c.grid = s_grid; c.n = n;
+    c.x0 = s_kxy[0].x;
+    c.scale = curve_scale(c.x0, s_kxy[n - 1].x);
+    for (int i = tid + 1; i < n; i += nthreads) s_inv[i] = inv_dx(s_kxy[i - 1].x, s_kxy[i].x);
+    for (int j = tid; j <= CURVE_BUCKETS; j += nthreads) {      // knots with a bucket below j: lower_bound over the (ascending) buckets of the knots
+        int lo = 0, hi = n;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (curve_bucket(s_kxy[mid].x, c.x0, c.scale) < j) lo = mid + 1; else hi = mid;
+        }
+        s_grid[j] = (unsigned short)lo;
     }
-    return (unsigned short)lo;
+    __syncthreads();
+    return c;
 }
-// Four values at once, their bisections in lock step (the four chains of dependent LDS reads overlap; the trip count is what the
-// slowest lane of the wave needs -- two or three steps with a grid, not ten).  For each value the answer lies between the entry of
-// its bucket (every knot before it is < d) and the entry three buckets on (the first knot >= an edge a whole bucket above d).
-// out[k] = 0 where !mk[k].
-__device__ __forceinline__ void lut_grid_eval4(const float *kx, const float *ky, int n, const LutGrid g, const unsigned short *grid,
-                                               const float (&d)[4], const bool (&mk)[4], float (&out)[4]) {
+__device__ __forceinline__ float curve_blend(const Curve &c, float d, int lo) {
+    const int i = lo < 1 ? 1 : (lo > c.n - 1 ? c.n - 1 : lo);
+    const float2 a = c.kxy[i - 1], b = c.kxy[i];
+    return blend(d, a.x, a.y, b.y, c.inv[i]);
+}
+// Four values at once, their (short) bisections in lock step: the four chains of dependent LDS reads overlap, and the trip count is
+// what the slowest lane of the wave needs.  out[k] = 0 where !mk[k]; a NaN depth comes back as it is.
+__device__ __forceinline__ void curve_eval4(const Curve &c, const float (&d)[4], const bool (&mk)[4], float (&out)[4]) {
     int base[4], len[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int b = (int)fminf(fmaxf((d[k] - g.x0) * g.inv, 0.0f), (float)(LUT_BUCKETS - 1));      // (NaN -> bucket 0; its result is d itself)
-        base[k] = grid[b];
-        len[k] = ((g.inv != 0.0f && b + 3 < LUT_BUCKETS) ? (int)grid[b + 3] : n) - base[k];
+        const int b = curve_bucket(d[k], c.x0, c.scale);
+        base[k] = c.grid[b];
+        len[k] = (int)c.grid[b + 1] - base[k];
         if (!mk[k] || d[k] != d[k]) len[k] = 0;
     }
-    // (tried: the range scanned four knots per step with independent reads instead of halved -- 20.7 against 19.6 us per view; the
-    //  count of knots below d built from its top bit down with wave-uniform steps, 8 instead of 13 instructions per step -- 19.8)
     while (__any((len[0] | len[1] | len[2] | len[3]) > 0)) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                  // lower_bound of d[k] in [base, base + len]
             const int half = len[k] >> 1;
-            const bool right = len[k] > 0 && kx[base[k] + half] < d[k];
+            const bool right = len[k] > 0 && c.kxy[base[k] + half].x < d[k];
             base[k] = right ? base[k] + half + 1 : base[k];
             len[k] = right ? len[k] - half - 1 : half;
         }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) out[k] = !mk[k] ? 0.0f : (d[k] != d[k]) ? d[k] : lut_blend(kx, ky, n, d[k], base[k]);
+    for (int k = 0; k < 4; ++k) out[k] = !mk[k] ? 0.0f : (d[k] != d[k]) ? d[k] : curve_blend(c, d[k], base[k]);
+}
+__device__ __forceinline__ float curve_eval(const Curve &c, float d) {      // one value (ragged ends)
+    if (d != d) return d;
+    const int b = curve_bucket(d, c.x0, c.scale);
+    int lo = c.grid[b], hi = c.grid[b + 1];
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (c.kxy[mid].x < d) lo = mid + 1; else hi = mid;
+    }
+    return curve_blend(c, d, lo);
 }
 
 // median of 9; NaN in -> NaN out like torch.median.  Default: the three-instruction column sort + v_med3 form -- sort

@@ -159,13 +159,38 @@ class _PinnedRing:
         with self._lock:
             return self._upload(arr, device)
 
+    def stage(self, arr: np.ndarray):
+        """``arr`` copied into a page-locked slot WITHOUT an upload of its own: ``(address, slot)`` for a native call that reads the
+        slot on a stream (``dd_refine_fit_async`` copies the sparse points up itself); the caller then hands ``slot`` and an event
+        recorded behind that stream operation to ``staged_until``.  None if the array does not fit a slot."""
+        arr = np.ascontiguousarray(arr)
+        if arr.nbytes == 0 or arr.nbytes > self.nbytes:
+            return None
+        with self._lock:
+            if not self._bufs:
+                self._allocate()
+            k = self._next % self.slots
+            self._next += 1
+            if self._events[k] is not None:
+                self._events[k].synchronize()
+                self._events[k] = None
+            self._views[k][:arr.nbytes] = arr.view(np.uint8).reshape(-1)
+            return self._ptrs[k], k
+
+    def staged_until(self, slot: int, event) -> None:
+        self._events[slot] = event
+
+    def _allocate(self) -> None:
+        # one page-locked block for all slots (a pinned allocation costs ~0.3 ms whatever its size)
+        block = torch.empty(self.slots * self.nbytes, dtype=torch.uint8, pin_memory=True)
+        self._bufs = [block[i * self.nbytes:(i + 1) * self.nbytes] for i in range(self.slots)]
+        self._views = [b.numpy() for b in self._bufs]
+        self._ptrs = [b.data_ptr() for b in self._bufs]
+        self._events = [None] * self.slots
+
     def _upload(self, arr: np.ndarray, device: torch.device) -> torch.Tensor:
         if not self._bufs:
-            # one page-locked block for all slots (a pinned allocation costs ~0.3 ms whatever its size)
-            block = torch.empty(self.slots * self.nbytes, dtype=torch.uint8, pin_memory=True)
-            self._bufs = [block[i * self.nbytes:(i + 1) * self.nbytes] for i in range(self.slots)]
-            self._views = [b.numpy() for b in self._bufs]
-            self._events = [None] * self.slots
+            self._allocate()
         k = self._next % self.slots
         self._next += 1
         if self._events[k] is not None:

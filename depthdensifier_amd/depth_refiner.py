@@ -21,6 +21,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Any, Optional, Union
 
+import time
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -113,9 +115,11 @@ class DepthRefiner:
         keep = torch.abs(r - med) < thr
         return z_metric[keep], z_mono[keep], int((~keep).sum().item())
 
-    def _lut_interpolate(self, d: torch.Tensor, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    def _lut_interpolate(self, d: torch.Tensor, x: torch.Tensor, y: torch.Tensor, reciprocal: bool = False) -> torch.Tensor:
         """Piecewise-linear transfer curve through the sorted knots ``(x, y)`` (``depth_refiner.py:141-178``);
-        clamped at the end knots, floored at 1e-3."""
+        clamped at the end knots, floored at 1e-3.  ``reciprocal``: ``t = (d - x0) * (1 / dx)`` instead of the reference's
+        ``(d - x0) / dx`` -- what the HIP kernels compute since round 6 (the reciprocal is a property of the interval,
+        ``csrc/ddrefine_math.h``; at most two ulps of ``t`` apart): the tests' exact oracle for them."""
         if len(d) < 4:
             return d * torch.median(y / (d + 1e-6))
         order = torch.argsort(x)
@@ -126,7 +130,7 @@ class DepthRefiner:
         x0, x1, y0, y1 = xs[hi - 1], xs[hi], ys[hi - 1], ys[hi]
         dx = x1 - x0
         dx = torch.where(dx == 0, torch.tensor(1e-6, device=self.device, dtype=self.dtype), dx)
-        t = torch.clamp((d - x0) / dx, 0, 1)
+        t = torch.clamp((d - x0) * (1.0 / dx) if reciprocal else (d - x0) / dx, 0, 1)
         out = y0 + t * (y1 - y0)
         return torch.maximum(out, torch.tensor(1e-3, device=self.device, dtype=self.dtype))
 
@@ -161,32 +165,63 @@ class DepthRefiner:
             raise DDCoreError(rc, lib.dd_refine_last_error().decode())
         return out
 
-    def _apply_curve(self, depth: torch.Tensor, mask: torch.Tensor, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    def _apply_curve(self, depth: torch.Tensor, mask: torch.Tensor, x: torch.Tensor, y: torch.Tensor, reciprocal: bool = False) -> torch.Tensor:
         """``depth_refiner.py:180-205``: curve on masked pixels, 3x3 median, zeros outside the mask."""
         if depth.is_cuda and len(x) >= 2 and int(mask.sum().item()) >= 4:       # (:143-145, 153-154 keep the tensor path)
             return self._apply_curve_hip(depth, mask, x, y)
         out = torch.zeros_like(depth)
         if mask.any():
-            out[mask] = self._lut_interpolate(depth[mask], x, y)
+            out[mask] = self._lut_interpolate(depth[mask], x, y, reciprocal)
         if not self.skip_smoothing:
             out = median3x3(out)
         out[~mask] = 0
         return out
 
-    def _fit_launch(self, depth: torch.Tensor, points3D: ArrayLike, cam_from_world: ArrayLike, K: ArrayLike, also: Optional[torch.Tensor] = None):
+    def _fit_launch(self, depth: torch.Tensor, points3D: ArrayLike, cam_from_world: ArrayLike, K: ArrayLike, mask_or_count: Optional[torch.Tensor] = None):
         """The correspondence half (``depth_refiner.py:244-299``) as ONE kernel launch (``dd_refine_fit``,
         ``csrc/ddrefine.hip``) instead of ~25 tensor launches and several synchronisations; the eight result words are
         copied to page-locked host memory asynchronously and an event marks them ready, so the caller may enqueue other
         work (the next view's uploads and fit) before ``_fit_finish`` reads them.  In the reference's FP16 mode (``:85-86``)
         the inputs and the correspondences are quantised to half like there; the arithmetic in between is float32 (no
-        golden exists for that mode, and this is at least as close to the FP32 result).  ``also``: a device count the caller
-        wants on the host as well; it rides along in the same read."""
+        golden exists for that mode, and this is at least as close to the FP32 result).  ``mask_or_count``: the view's mask (bool / uint8,
+        (H,W): its number of set pixels rides along in the same read; None counts ``depth > 0``) or a 0-dim device count."""
         import ctypes as C
         from ._lib import DD_F16, DD_F32, DDCoreError, lib
         half = self.dtype == torch.float16
         q = (lambda a: np.asarray(a, dtype=np.float64).astype(np.float16).astype(np.float32)) if half else (lambda a: np.asarray(a, dtype=np.float32))
         E = q(cam_from_world.cpu().numpy() if isinstance(cam_from_world, torch.Tensor) else cam_from_world)[:3, :4].reshape(-1)
         Kq = q(K.cpu().numpy() if isinstance(K, torch.Tensor) else K)[:2, :3].reshape(-1)
+        d = depth.contiguous()
+        stream = torch.cuda.current_stream(self.device)
+        # page-locked result slots with their events: a handle OWNS its slot from here until _fit_finish hands it back, so any number
+        # of begun handles may be open at once (the free list grows on demand; the pipeline's one-group lag uses two groups' worth)
+        if not hasattr(self, "_meta_free"):
+            self._meta_free = []
+        if self._meta_free:
+            host, ready = self._meta_free.pop()
+        else:
+            host, ready = torch.empty(8, dtype=torch.int32, pin_memory=True), torch.cuda.Event()
+            ready.record(stream)                      # (creates the underlying event: its handle goes to the native call)
+        staged = None
+        if isinstance(points3D, np.ndarray):
+            from .densify import _small
+            staged = _small.stage(np.ascontiguousarray(points3D, dtype=np.float32).reshape(-1, 3))
+        if staged is not None and isinstance(mask_or_count, (torch.Tensor, type(None))) and (mask_or_count is None or mask_or_count.dtype in (torch.bool, torch.uint8)):
+            # ONE native call: points up, fit, masked-pixel count, result words down, event (dd_refine_fit_async) -- the calls the host
+            # makes per view are what bounds the loop around the kernels (profiles/r06_bench_pipeline.txt)
+            n = int(np.asarray(points3D).reshape(-1, 3).shape[0])
+            work = torch.empty(6 * max(n, 1) + 8, dtype=torch.float32, device=self.device)
+            m = mask_or_count
+            rc = lib.dd_refine_fit_async(staged[0], n, (C.c_float * 12)(*E.tolist()), (C.c_float * 6)(*Kq.tolist()), d.data_ptr(),
+                                         DD_F16 if d.dtype == torch.float16 else DD_F32, d.shape[0], d.shape[1], int(self.edge_margin),
+                                         1 if self.robust else 0, float(self.outlier_threshold), 1 if half else 0,
+                                         None if m is None else m.data_ptr(), work.data_ptr(), work.data_ptr() + 24 * max(n, 1), host.data_ptr(),
+                                         ready.cuda_event, stream.cuda_stream)
+            if rc < 0:
+                raise DDCoreError(rc, lib.dd_refine_last_error().decode())
+            _small.staged_until(staged[1], ready)
+            nn = max(n, 1)
+            return {"work": work, "n": nn, "host": host, "ready": ready, "keep": (d, m)}
         if isinstance(points3D, np.ndarray):
             from .densify import upload_small
             pts = upload_small(np.ascontiguousarray(points3D, dtype=np.float32).reshape(-1, 3), self.device)   # no host wait
@@ -195,23 +230,16 @@ class DepthRefiner:
         n = int(pts.shape[0])
         buf = torch.empty((3, max(n, 1)), dtype=torch.float32, device=self.device)
         meta = torch.zeros(8, dtype=torch.int32, device=self.device)
-        d = depth.contiguous()
-        stream = torch.cuda.current_stream(self.device)
         rc = lib.dd_refine_fit(pts.data_ptr(), n, (C.c_float * 12)(*E.tolist()), (C.c_float * 6)(*Kq.tolist()), d.data_ptr(),
                                DD_F16 if d.dtype == torch.float16 else DD_F32, d.shape[0], d.shape[1], int(self.edge_margin),
                                1 if self.robust else 0, float(self.outlier_threshold), 1 if half else 0,
                                buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), meta.data_ptr(), stream.cuda_stream)
         if rc < 0:
             raise DDCoreError(rc, lib.dd_refine_last_error().decode())
-        if also is not None:
-            meta[5] = also.to(torch.int32)
-        # page-locked result slots: a handle OWNS its slot from here until _fit_finish hands it back, so any number of
-        # begun handles may be open at once (the free list grows on demand; the pipeline's one-view lag uses two)
-        if not hasattr(self, "_meta_free"):
-            self._meta_free = []
-        host = self._meta_free.pop() if self._meta_free else torch.empty(8, dtype=torch.int32, pin_memory=True)
+        src = mask_or_count if mask_or_count is not None else d > 0          # depth_refiner.py:241
+        also = src if src.dim() == 0 else src.sum().clamp(max=2 ** 31 - 1)
+        meta[5] = also.to(torch.int32)
         host.copy_(meta, non_blocking=True)
-        ready = torch.cuda.Event()
         ready.record(stream)
         return {"buf": buf, "meta": meta, "host": host, "ready": ready, "keep": (pts, d)}
 
@@ -219,11 +247,16 @@ class DepthRefiner:
         """``(z_mono, z_metric, in_bounds, positive, kept, removed, scale, extra)``: the one synchronisation of the fit."""
         if fit.get("host") is None:
             raise RuntimeError("finish_refine: this handle has been finished already")
+        t0 = time.perf_counter()
         fit["ready"].synchronize()
+        self.wait_seconds = getattr(self, "wait_seconds", 0.0) + time.perf_counter() - t0      # (host time spent waiting for the GPU: the pipeline's report)
         inb, pos, kept, removed, scale_bits, extra = fit["host"][:6].tolist()
-        self._meta_free.append(fit["host"])                      # the slot is free for the next begun handle
+        self._meta_free.append((fit["host"], fit["ready"]))      # the slot (and its event) is free for the next begun handle
         fit["host"] = None
         scale = float(np.array([scale_bits], dtype=np.int32).view(np.float32)[0])
+        if "work" in fit:                                        # (dd_refine_fit_async: points, z_mono, z_metric, scratch in one array)
+            w, n = fit["work"], fit["n"]
+            return w[3 * n:3 * n + kept], w[4 * n:4 * n + kept], inb, pos, kept, removed, scale, extra
         buf = fit["buf"]
         return buf[0][:kept], buf[1][:kept], inb, pos, kept, removed, scale, extra
 
@@ -259,18 +292,22 @@ class DepthRefiner:
             print(f"[DepthRefiner] Input depth shape: {tuple(depth_map.shape)}")
             print(f"[DepthRefiner] COLMAP points: {len(points3D)}")
         depth = self._to(depth_map)
-        m = self._to(mask, torch.bool) if mask is not None else depth > 0
+        gpu_fit = depth.is_cuda and depth.dim() == 2 and min(depth.shape) >= 2
+        # (on the GPU path a missing mask stays None -- the kernels test depth > 0 themselves -- and is only made when a tensor branch asks)
+        m = self._to(mask, torch.bool) if mask is not None else (None if gpu_fit else depth > 0)
         h = dict(depth_map=depth_map, depth=depth, m=m, points3D=points3D, cam_from_world=cam_from_world, K=K,
                  return_tensor=return_tensor, generator=generator, fit_only=fit_only)
-        if depth.is_cuda and depth.dim() == 2 and min(depth.shape) >= 2:
+        if gpu_fit:
             # GPU: the whole correspondence half is one hand-written kernel (the number of masked pixels, needed later to
-            # choose the apply path, is read in the fit's own synchronisation)
-            h["fit"] = self._fit_launch(depth, points3D, cam_from_world, K, also=m.sum().clamp(max=2 ** 31 - 1))
+            # choose the apply path, is counted beside it and read in the fit's own synchronisation)
+            h["fit"] = self._fit_launch(depth, points3D, cam_from_world, K, mask_or_count=m.contiguous() if m is not None else None)
         return h
 
     def finish_refine(self, h: dict) -> dict[str, Any]:
         """Second half of ``refine_depth``: waits for the fit (GPU) and produces the result dictionary."""
         depth_map, depth, m = h["depth_map"], h["depth"], h["m"]
+        if m is None and not (h["fit_only"] and "fit" in h):
+            m = depth > 0                                        # depth_refiner.py:241 (only the apply paths need the tensor)
         points3D, cam_from_world, K = h["points3D"], h["cam_from_world"], h["K"]
         return_tensor, generator, fit_only = h["return_tensor"], h["generator"], h["fit_only"]
 
@@ -308,6 +345,8 @@ class DepthRefiner:
                     return {"refined_depth": None, "curve": (kx, ky, bool(self.skip_smoothing)), "raw_depth": depth,
                             "num_correspondences": n_corr, "outliers_removed": removed, "scale_factor": scale}
             scale = float(scale)
+            if m is None:
+                m = depth > 0                                    # depth_refiner.py:241
             refined = self._apply_curve(depth, m, z_mono, z_metric)
             if self.verbose > 0:
                 print(f"[DepthRefiner] Refined using {n_corr} correspondences")

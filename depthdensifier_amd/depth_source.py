@@ -55,6 +55,10 @@ class StagingSlot:
             self._bufs[key] = t
         return t.numpy()
 
+    def pointer(self, key: str) -> int:
+        """Address of the buffer ``array(key, ...)`` returned last (for the native readers, ``dd_npy_read``)."""
+        return self._bufs[key].data_ptr()
+
     def put(self, key: str, arr: np.ndarray) -> np.ndarray:
         dst = self.array(key, arr.shape, arr.dtype)
         np.copyto(dst, arr)
@@ -108,8 +112,17 @@ class CachedSource(DepthSource):
         self.dir = Path(cache_dir)
         if not self.dir.is_dir():
             raise FileNotFoundError(f"depth cache directory not found: {self.dir}")
+        self._stems: dict = {}            # image name -> stem of its files (looked up once)
+        self._npy: dict = {}              # stem -> None (no .npy layout) or {key: (path bytes, dtype code, numpy dtype, shape)} from the headers
+        self._lock = threading.Lock()
 
     def _stem(self, image_name: str) -> str:
+        got = self._stems.get(image_name)
+        if got is None:
+            got = self._stems[image_name] = self._find_stem(image_name)
+        return got
+
+    def _find_stem(self, image_name: str) -> str:
         # COLMAP image names may carry sub-folders ("cam1/0001.jpg"): a cache laid out the same way wins, so that two
         # cameras' "0001" do not collide; otherwise the flat <stem> files
         nested, flat = str(Path(image_name).with_suffix("")), Path(image_name).stem
@@ -121,8 +134,60 @@ class CachedSource(DepthSource):
         f = self.dir / (self._stem(image_name) + "_rgb.npy")
         return np.load(f, mmap_mode="r") if f.exists() else None
 
+    # ---- the .npy layout read natively (csrc/ddingest.hip): an I/O thread holds the interpreter lock for a few microseconds per view,
+    # not for the header parsing and array handling of np.load -- sixteen such threads made every call of the main thread queue for
+    # the lock (profiles/r06_bench_pipeline.txt) ----
+    _NPY_DTYPES = {0: np.float32, 1: np.float16, 2: np.uint8, 3: np.bool_}
+
+    def _npy_files(self, stem: str):
+        """{key: (path, dtype code, numpy dtype, shape)} of the view's .npy files from their headers, or None (no .npy layout)."""
+        got = self._npy.get(stem, False)
+        if got is not False:
+            return got
+        import ctypes as C
+        from ._lib import lib
+        files = {}
+        for key in ("depth", "mask", "normal", "rgb"):
+            f = self.dir / f"{stem}_{key}.npy"
+            if not f.exists():
+                continue
+            dt, nd, shape = C.c_int32(), C.c_int32(), (C.c_int64 * 4)()
+            if lib.dd_npy_header(str(f).encode(), C.byref(dt), C.byref(nd), shape, None) < 0:
+                files = None                     # (an element type the native reader does not take, say float64: np.load handles it)
+                break
+            files[key] = (str(f).encode(), int(dt.value), self._NPY_DTYPES[int(dt.value)], tuple(int(shape[k]) for k in range(nd.value)))
+        if files is not None and "depth" not in files:
+            files = None
+        with self._lock:
+            self._npy[stem] = files
+        return files
+
+    def _read_native(self, spec, key: str, staging: "StagingSlot") -> np.ndarray:
+        import ctypes as C
+        from ._lib import lib
+        path, code, dtype, shape = spec
+        dst = staging.array(key, shape, dtype)
+        rc = lib.dd_npy_read(path, code, len(shape), (C.c_int64 * 4)(*shape), staging.pointer(key), dst.nbytes)
+        if rc < 0:
+            raise OSError(f"libddcore: {lib.dd_ingest_last_error().decode('utf-8', 'replace')}")
+        return dst
+
+    def read_rgb(self, image_name: str, hw: tuple, staging: "StagingSlot") -> Optional[np.ndarray]:
+        """The cached image at processing resolution read straight into the staging slot, or None (no such file, or another size)."""
+        files = self._npy_files(self._stem(image_name))
+        if not files or "rgb" not in files or files["rgb"][3] != (hw[0], hw[1], 3) or files["rgb"][1] != 2:
+            return None
+        return self._read_native(files["rgb"], "rgb", staging)
+
     def prepare(self, image_name, rgb_u8, staging=None):
         stem = self._stem(image_name)
+        if staging is not None:
+            files = self._npy_files(stem)
+            if files is not None:
+                h, w = rgb_u8.shape[:2]
+                if files["depth"][3] != (h, w):
+                    raise ValueError(f"{files['depth'][0].decode()}: depth is {files['depth'][3]}, image at processing resolution is {(h, w)}")
+                return {k: self._read_native(files[k], k, staging) for k in ("depth", "mask", "normal") if k in files}
         f = self.dir / (stem + ".npz")
         keep = (lambda k, a: staging.put(k, a)) if staging is not None else (lambda k, a: np.asarray(a))
         if f.exists():

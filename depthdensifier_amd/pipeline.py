@@ -219,8 +219,9 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
     # capacity from the size the views are really processed at -- the image files', which the reference reconciles
     # with the model through camera.rescale (:172-173); the sparse model's camera may have another size
     capacity = 0
+    sizes = {}                                                                  # image name -> (width, height) it is processed at
     for im in mine:
-        pw, ph = _processing_size(config.paths.image_dir / im.name, f)
+        pw, ph = sizes[im.name] = _processing_size(config.paths.image_dir / im.name, f)
         capacity += (-(-ph // s)) * (-(-pw // s))
     # (views are appended a few at a time here: launches of 26 us whose rows sit in one chunk anyway -- the default rule applies: a
     # placed cloud when the scan is large or the arena already holds classified spares from an earlier scan, no scouting otherwise)
@@ -228,10 +229,24 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
     cached = []                                                                 # :128 cached_refinement_data
     stage = {"image_decode": 0.0, "depth_source": 0.0, "refine": 0.0, "densify": 0.0}     # host seconds per stage
     clock = time.perf_counter
+    detail: dict = {}                                                          # finer: seconds per step of the loop (report["loop_detail"])
+
+    def lap(key: str, t_from: float) -> float:
+        now = clock()
+        detail[key] = detail.get(key, 0.0) + (now - t_from)
+        return now
+
+    read_rgb = getattr(source, "read_rgb", None)
 
     def fetch(im, slot=None):                                                   # no GPU work: safe on an I/O thread
+        pw, ph = sizes[im.name]
+        if slot is not None and read_rgb is not None:                           # cached image + staging slot: read natively, straight into the slot
+            slot.wait()                                                         # the uploads of the slot's previous view are done
+            rgb = read_rgb(im.name, (ph, pw), slot)
+            if rgb is not None:
+                return rgb, source.prepare(im.name, rgb, staging=slot), slot
         rgb = source.cached_rgb(im.name)                                        # the cache may hold the resized image itself
-        if rgb is None or tuple(rgb.shape[:2]) != _processing_size(config.paths.image_dir / im.name, f)[::-1]:
+        if rgb is None or tuple(rgb.shape[:2]) != (ph, pw):
             rgb = _load_rgb(config.paths.image_dir / im.name, f)                # :145-152
         if slot is None:
             rgb = np.array(rgb) if isinstance(rgb, np.memmap) else rgb        # (a private, writable copy of a memory-mapped image)
@@ -254,8 +269,9 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
 
     def begin(k, image) -> dict:
         """Everything of a view up to the ENQUEUED correspondence fit: nothing here waits for the GPU."""
+        t0_ = clock()
         pts_world = rec.xyz_of(image.observed_point3D_ids())                    # :139
-        t1 = clock()
+        t1 = lap("sparse_points", t0_)
         if pool:
             rgb, prepared, slot = pending.popleft().result()
             if k + ahead < len(mine):                                           # its slot was released two views ago at the latest
@@ -263,12 +279,13 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
         else:
             rgb, prepared, slot = fetch(image)
         new_h, new_w = rgb.shape[:2]
-        t2 = clock()
+        t2 = lap("wait_for_io_thread", t1)
         maps = source.infer(image.name, rgb, device, prepared=prepared)         # :161-168, stays on device
+        tx = lap("upload_maps", t2)
         rgb_dev = torch.from_numpy(rgb).to(device, non_blocking=True)           # :215 the colours, uploaded with the maps
         if slot is not None:
             slot.release(torch.cuda.current_stream(device))                     # every upload from the slot is enqueued by now
-        t3 = clock()
+        t3 = lap("upload_rgb_release_slot", tx)
         camera = rec.cameras[image.camera_id]
         camera.rescale(new_width=new_w, new_height=new_h)                       # :172-173 (in place, like the reference)
         E = image.cam_from_world().matrix()[:3, :]                              # :177
@@ -279,9 +296,10 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
         if normal is None:
             normal = torch.zeros((new_h, new_w, 3), dtype=torch.float32, device=device)
         fuse = s == 1 and new_w <= 3071          # full density: the densify kernel applies the transfer curve itself
+        tc = lap("camera", t3)
         handle = refiner.begin_refine(depth_map=maps["depth"], normal_map=normal, points3D=pts_world, cam_from_world=E, K=K,
                                       mask=maps["mask"], return_tensor=True, fit_only=fuse)   # :179-186, first half
-        t4 = clock()
+        t4 = lap("begin_refine", tc)
         stage["image_decode"] += t2 - t1; stage["depth_source"] += t3 - t2; stage["refine"] += t4 - t3
         # (the camera may be rescaled again by the next view before this one is finished: its intrinsics are taken now)
         return dict(rgb=rgb_dev, maps=maps, normal=normal, E=E, K=K, pinhole=camera.pinhole_params().copy(), handle=handle)
@@ -305,8 +323,10 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
         runs of consecutive views with a curve and one size go together, anything else (early exits of the refiner, a coarser
         density, very wide images) view by view.  View order is preserved."""
         t3 = clock()
+        w0 = getattr(refiner, "wait_seconds", 0.0)
         results = [refiner.finish_refine(v["handle"]) for v in group]
-        t4 = clock()
+        t4 = lap("finish_refine", t3)
+        detail["finish_refine_of_which_waiting_for_the_gpu"] = detail.get("finish_refine_of_which_waiting_for_the_gpu", 0.0) + getattr(refiner, "wait_seconds", 0.0) - w0
         run: list = []
         for v, res in zip(group, results):
             maps = v["maps"]
@@ -328,7 +348,7 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
             cached.append(dict(depth=refined, mask=maps["mask"], K=v["K"], E=v["E"]))         # :197-201
         if run:
             densify_run(run)
-        t5 = clock()
+        t5 = lap("densify_launch", t4)
         stage["refine"] += t4 - t3; stage["densify"] += t5 - t4
 
     # Groups of `views_per_launch` views, one group of lag: while the GPU runs group g's uploads and fits, the host starts
@@ -352,7 +372,7 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
         pool.shutdown(wait=False, cancel_futures=True)
     say(f"-> Image processing loop finished in {time.time() - t_loop:.2f}s.")
 
-    report = {"views": num_views, "dense_points": 0, "removed": 0, "timings": stage}
+    report = {"views": num_views, "dense_points": 0, "removed": 0, "timings": stage, "loop_detail": detail, "loop_seconds": time.time() - t_loop}
     if num_views == 0:
         say("No dense points were generated. Skipping save.")                   # :366-367
         return report

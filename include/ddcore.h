@@ -310,6 +310,21 @@ int dd_compact_cloud(const DDCloudOut *in, int64_t n, const int32_t *votes_dev, 
                      void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * getting a view's precomputed maps into HBM (the stand-in for scripts/test.py:143-168 where MoGe is not
+ * installed) without the interpreter: ctypes releases its lock during a foreign call, so prefetch threads that call these do not
+ * make the main thread queue for it.  Host functions; dd_ingest_last_error() has the message of a negative return.
+ * ------------------------------------------------------------------------------------------- */
+enum { DD_NPY_F32 = 0, DD_NPY_F16 = 1, DD_NPY_U8 = 2, DD_NPY_BOOL = 3 };
+/* Header of a .npy file (format versions 1-3, C order, up to 4 dimensions, one of the four element types above). */
+int dd_npy_header(const char *path, int32_t *dtype_out, int32_t *ndim_out, int64_t *shape_out /* [4] */, int64_t *data_offset_out);
+/* Reads the array of a .npy file into dst (e.g. a page-locked staging buffer) after checking element type and shape against what
+ * the caller expects (U8 and BOOL are interchangeable): open / pread / close, no allocation, no temporary. */
+int dd_npy_read(const char *path, int32_t expect_dtype, int32_t expect_ndim, const int64_t *expect_shape, void *dst, int64_t dst_bytes);
+/* n host -> device copies on `stream` and, behind them, `event` (a hipEvent_t or NULL) -- one call instead of n + 1. */
+int dd_upload_async(int32_t n, const void *const *src_host, void *const *dst_dev, const int64_t *nbytes, void *event, void *stream);
+const char *dd_ingest_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
  * the per-pixel half of DepthRefiner as one kernel --
  * src/depthdensifier/depth_refiner.py:180-205 (_apply_transformation) with :141-178
  * (_pchip_interpolate_optimized): refined = mask ? median3x3( mask ? LUT(depth) : 0 ) : 0, where LUT is
@@ -333,6 +348,15 @@ const char *dd_refine_last_error(void);
 int dd_refine_fit(const float *points, int32_t n, const float *cam_from_world, const float *calibration, const void *depth,
                   int32_t depth_dtype, int32_t height, int32_t width, int32_t edge_margin, int32_t robust, float outlier_threshold,
                   int32_t half_precision_io, float *z_mono_out, float *z_metric_out, float *scratch, int32_t *meta_out, void *stream);
+/* dd_refine_fit for a streaming caller, everything of a view's fit enqueued by ONE call (round 6: the loop around the kernels is bound by
+ * the number of calls the host makes): the n sparse points are copied up from points_host ((n,3) float32, page-locked for the copy to
+ * be asynchronous), the fit runs as in dd_refine_fit with z_mono / z_metric / scratch inside `work` (device, 6 n floats: the points,
+ * then the three arrays), the number of masked pixels (mask != 0, or depth > 0 if mask is NULL; clamped to 2^31 - 1) goes to
+ * meta_dev[5], the eight result words are copied to meta_host (page-locked) and ready_event (a hipEvent_t or NULL) is recorded. */
+int dd_refine_fit_async(const float *points_host, int32_t n, const float *cam_from_world, const float *calibration, const void *depth,
+                        int32_t depth_dtype, int32_t height, int32_t width, int32_t edge_margin, int32_t robust, float outlier_threshold,
+                        int32_t half_precision_io, const uint8_t *mask, float *work, int32_t *meta_dev, int32_t *meta_host,
+                        void *ready_event, void *stream);
 /* The knots sorted by x (torch.argsort, :149-151), n <= 4096, one launch. */
 int dd_sort_knots(const float *x, const float *y, int32_t n, float *x_sorted, float *y_sorted, void *stream);
 

@@ -9,10 +9,8 @@ FAULT = 64                 # fault injection: an in-kernel scan gives up
 LIST_ORDER = 32            # rows in list order (no shift of the wave runs onto 128-byte lines)
 W32, W64 = 2 << 20, 3 << 20        # polling lanes of the decoupled look-back
 CLASSIC = 1 << 26          # the decoupled look-back of rounds 1-4 instead of the scan service
-BISECT, MEDIAN9 = 1 << 27, 1 << 28  # DD_REFINE: bisect all knots / one median per window
 
-_SWITCHES = ((FAULT, _lib.DD_LAB_FAULT_INJECT), (LIST_ORDER, _lib.DD_LAB_LIST_ORDER), (CLASSIC, _lib.DD_LAB_LOOKBACK),
-             (BISECT, _lib.DD_LAB_REFINE_BISECT), (MEDIAN9, _lib.DD_LAB_REFINE_MEDIAN9))
+_SWITCHES = ((FAULT, _lib.DD_LAB_FAULT_INJECT), (LIST_ORDER, _lib.DD_LAB_LIST_ORDER), (CLASSIC, _lib.DD_LAB_LOOKBACK))
 
 
 def split(word: int) -> tuple:

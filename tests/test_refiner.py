@@ -121,7 +121,8 @@ def test_gpu_fp16_default_mode(g, name):
 @pytest.mark.parametrize("shape", [(96, 128), (37, 53), (1, 1), (33, 65)])
 @pytest.mark.parametrize("with_mask", (True, False))
 def test_hip_apply_kernel_equals_tensor_path(shape, skip, with_mask):
-    """dd_refine_apply (csrc/ddrefine.hip) vs the tensor formulation evaluated on the CPU: bit-exact."""
+    """dd_refine_apply (csrc/ddrefine.hip) vs the tensor formulation evaluated on the CPU: bit-exact with the kernels' blend, two ulps
+    of t from the reference's."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from depthdensifier_amd.depth_refiner import DepthRefiner
@@ -142,8 +143,12 @@ def test_hip_apply_kernel_equals_tensor_path(shape, skip, with_mask):
     m_cpu = mask if mask is not None else depth > 0
     if int(m_cpu.sum()) < 4:
         pytest.skip("fewer than 4 masked pixels: the tensor path takes its own branch")
-    want = cpu._apply_curve(depth.clone(), m_cpu, x, y)
+    # bit-exact against the tensor formulation with the kernels' blend (t = (d - x0) * (1 / dx): round 6) ...
+    want = cpu._apply_curve(depth.clone(), m_cpu, x, y, reciprocal=True)
     assert torch.equal(got, want)
+    # ... and within two ulps of t -- 1.2e-7 of the interval's |dy| -- of the reference's quotient form (:160-176)
+    ref = cpu._apply_curve(depth.clone(), m_cpu, x, y)
+    assert float((got - ref).abs().max()) <= 3e-7 * float(y.abs().max())
 
 
 @pytest.mark.gpu
@@ -188,10 +193,12 @@ def test_hip_apply_kernel_random_against_the_tensor_path(seed):
     m_cpu = mask if mask is not None else depth > 0
     if int(m_cpu.sum()) < 4:
         pytest.skip("fewer than 4 masked pixels: the tensor path takes its own branch")
-    want = cpu._apply_curve(depth.clone(), m_cpu, x, y)
+    want = cpu._apply_curve(depth.clone(), m_cpu, x, y, reciprocal=True)      # the kernels' blend (round 6), bit for bit
     nan = torch.isnan(want)
     assert torch.equal(torch.isnan(got), nan)             # (a NaN is a NaN: the CPU's carries another payload)
     assert torch.equal(got[~nan].view(torch.int32), want[~nan].view(torch.int32))
+    ref = cpu._apply_curve(depth.clone(), m_cpu, x, y)    # the reference's quotient form: two ulps of t away at most
+    assert torch.equal(torch.isnan(ref), nan) and float((got[~nan] - ref[~nan]).abs().max()) <= 3e-7 * float(y.abs().max())
 
 
 def _tensor_fit_cpu(r, depth, pts, E, K):

@@ -11,7 +11,7 @@ import bench, depthdensifier_amd as dd
 from depthdensifier_amd.depth_refiner import DepthRefiner
 
 ap = argparse.ArgumentParser(); ap.add_argument("--views", type=int, default=64)
-ap.add_argument("--tuning", type=lambda x: int(x, 0), default=0, help="variant word of the fused batch (tests/lab_bits.py; bit 27: bisect all knots, bit 28: one median per window -- experiment switches of include/ddcore_lab.h)")
+ap.add_argument("--tuning", type=lambda x: int(x, 0), default=0, help="variant word of the fused batch (tests/lab_bits.py: a product tuning + experiment switches of include/ddcore_lab.h)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 cfg = dict(bench.WORKLOADS["garden185"]); cfg["V"] = a.views

@@ -8,7 +8,7 @@ sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import torch
 from scan_factory import make_scan
 from depthdensifier_amd import pipeline as P
-V = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+V = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 185
 JPG = "--jpg" in sys.argv      # photograph-like JPEG images (what real scans hold) instead of PNG files of noise
 with tempfile.TemporaryDirectory() as tmp:
     t0 = time.time()
@@ -29,8 +29,15 @@ with tempfile.TemporaryDirectory() as tmp:
         np.save(rgb_cache / f"{f.stem}_rgb.npy", np.array(PILImage.open(img).convert("RGB")))
     import os
     ncores = len(os.sched_getaffinity(0))
-    for stride, nio in ((32, 0), (32, 4), (32, 8), (4, 8), (1, 8), (1, max(2, min(16, ncores - 2)))):
-      for cache in ("moge_cache", "moge_cache_npy") + (("moge_cache_npy_rgb",) if stride == 1 or nio == 8 else ()):
+    MATRIX = "--matrix" in sys.argv       # round 3's sweep over strides / io threads / cache layouts; default: the two runs VERDICT r5 asks for
+    nio_default = max(2, min(16, ncores - 2))
+    if "--io" in sys.argv:
+        nio_default = int(sys.argv[sys.argv.index("--io") + 1])
+    STRIDES = [int(x) for x in sys.argv[sys.argv.index("--strides") + 1].split(",")] if "--strides" in sys.argv else [1, 32]
+    runs = ([(32, 0), (32, 4), (32, 8), (4, 8), (1, 8), (1, nio_default)] if MATRIX else [(st, nio_default) for st in STRIDES])
+    for stride, nio in runs:
+      for cache in (("moge_cache", "moge_cache_npy") + (("moge_cache_npy_rgb",) if stride == 1 or nio == 8 else ()) if MATRIX else ("moge_cache_npy_rgb",)):
+       for rep in range(1 if MATRIX else 3):        # (warm caches: the first run of a configuration pages the files in and pins the staging slots)
         cfg = P.ScriptConfig()
         cfg.paths = P.PathsConfig(recon_path=scan / "sparse" / "0", image_dir=scan / "images", output_model_dir=Path(tmp) / f"out_s{stride}")
         cfg.moge.cache_dir = scan / cache
@@ -40,8 +47,16 @@ with tempfile.TemporaryDirectory() as tmp:
         cfg.refiner.verbose = 0
         buf = io.StringIO()
         with contextlib.redirect_stdout(buf):
-            rep = P.main(cfg)
+            rep_ = P.main(cfg)
         torch.cuda.synchronize()
-        t = {k: round(v, 3) for k, v in rep["timings"].items()}
-        loop = sum(t[k] for k in ("image_decode", "depth_source", "refine", "densify"))
-        print(json.dumps({"stride": stride, "io_threads": nio, "loop_ms_per_view": round(loop / rep["views"] * 1e3, 2), "images": "jpg" if JPG else "png", "cache": "npy+rgb" if cache.endswith("rgb") else "npy" if cache.endswith("npy") else "npz", "views": rep["views"], "dense_points": rep["dense_points"], "removed": rep["removed"], "seconds": t}), flush=True)
+        t = {k: round(v, 3) for k, v in rep_["timings"].items()}
+        loop = sum(rep_["timings"][k] for k in ("image_decode", "depth_source", "refine", "densify"))
+        wait = rep_["loop_detail"].get("finish_refine_of_which_waiting_for_the_gpu", 0.0) + rep_["loop_detail"].get("wait_for_io_thread", 0.0)
+        line = {"stride": stride, "io_threads": nio, "run": rep, "views": rep_["views"],
+                "host_ms_per_view": round(loop / rep_["views"] * 1e3, 3),
+                "host_ms_per_view_without_waits": round((loop - wait) / rep_["views"] * 1e3, 3),
+                "loop_wall_ms_per_view": round(rep_["loop_seconds"] / rep_["views"] * 1e3, 3),
+                "images": "jpg" if JPG else "png", "cache": "npy+rgb" if cache.endswith("rgb") else "npy" if cache.endswith("npy") else "npz",
+                "dense_points": rep_["dense_points"], "removed": rep_["removed"], "seconds": t,
+                "loop_detail_us_per_view": {k: round(v / rep_["views"] * 1e6, 1) for k, v in rep_["loop_detail"].items()}}
+        print(json.dumps(line), flush=True)

@@ -19,7 +19,7 @@ soak)
       if grep -q -E "EADDRINUSE|Connection refused|Connection reset|Rendezvous|connectFullMesh" /tmp/soak.err && ! grep -q "Memory access fault" /tmp/soak.err; then echo "launch $i: rendezvous trouble, not counted" >> $out; continue; fi
       echo "launch $i (views $v): rc $rc after $done_ clean executions" | tee -a $out; grep -E "fault|Error|error|stage" /tmp/soak.err | tail -20 | tee -a $out; exit 1
     fi
-    [ $(grep -c ": ok," /tmp/soak.out) -eq 3 ] || { echo "launch $i: a rank did not report ok" | tee -a $out; exit 1; }
+    [ $(grep -o ": ok," /tmp/soak.out | wc -l) -eq 3 ] || { echo "launch $i: a rank did not report ok" | tee -a $out; cat /tmp/soak.out | tail -5 | tee -a $out; grep -v amdgpu.ids /tmp/soak.err | tail -12 | tee -a $out; exit 1; }
     done_=$((done_ + reps))
     [ $((i % 10)) -eq 0 ] && echo "$i launches, $done_ executions clean, $(( $(date +%s) - t0 )) s" | tee -a $out
   done
