@@ -41,6 +41,7 @@ EXPORTS = (
     "dd_scatter",
     "dd_unproject_compact",
     "dd_stream_fork",
+    "dd_stream_wait",
     "dd_streams_overlap",
     "dd_chain_workgroup_limit",
     "dd_floater_votes",
@@ -59,6 +60,11 @@ EXPORTS = (
     "dd_npy_read",
     "dd_upload_async",
     "dd_ingest_last_error",
+    "dd_prefetch_create",
+    "dd_prefetch_submit",
+    "dd_prefetch_wait",
+    "dd_prefetch_release",
+    "dd_prefetch_destroy",
     "dd_format_points3d",
     "dd_model_last_error",
     "dd_arena_create",
@@ -207,6 +213,8 @@ def _load() -> C.CDLL:
     ]
     lib.dd_stream_fork.restype = C.c_int
     lib.dd_stream_fork.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.dd_stream_wait.restype = C.c_int
+    lib.dd_stream_wait.argtypes = [C.c_void_p, C.c_void_p]
     lib.dd_streams_overlap.restype = C.c_int
     lib.dd_streams_overlap.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
     lib.dd_chain_workgroup_limit.restype = C.c_int32
@@ -249,6 +257,16 @@ def _load() -> C.CDLL:
     lib.dd_npy_read.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.c_void_p, C.c_int64]
     lib.dd_upload_async.restype = C.c_int
     lib.dd_upload_async.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]
+    lib.dd_prefetch_create.restype = C.c_int
+    lib.dd_prefetch_create.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]
+    lib.dd_prefetch_submit.restype = C.c_int64
+    lib.dd_prefetch_submit.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.dd_prefetch_wait.restype = C.c_int
+    lib.dd_prefetch_wait.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]
+    lib.dd_prefetch_release.restype = C.c_int
+    lib.dd_prefetch_release.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    lib.dd_prefetch_destroy.restype = C.c_int
+    lib.dd_prefetch_destroy.argtypes = [C.c_void_p]
     lib.dd_ingest_last_error.restype = C.c_char_p
     lib.dd_ingest_last_error.argtypes = []
     lib.dd_format_points3d.restype = C.c_int

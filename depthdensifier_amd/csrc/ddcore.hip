@@ -2248,6 +2248,12 @@ int dd_stream_fork(void *event, void *from_stream, void *to_stream) {
     return DD_OK;
 }
 
+int dd_stream_wait(void *stream, void *event) {
+    if (!event) return fail(DD_ERR_INVALID_ARG, "event is NULL");
+    if (hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0) != hipSuccess) { (void)hipGetLastError(); return fail(DD_ERR_LAUNCH, "hipStreamWaitEvent failed"); }
+    return DD_OK;
+}
+
 int dd_streams_overlap(void *stream_a, void *stream_b, int32_t *scratch_dev, int32_t *overlap_out) {
     if (!scratch_dev || !overlap_out) return fail(DD_ERR_INVALID_ARG, "scratch_dev / overlap_out is NULL");
     if (stream_a == stream_b) { *overlap_out = 0; return DD_OK; }

@@ -17,6 +17,12 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
 #include "ddcore.h"
 
 namespace {
@@ -92,11 +98,194 @@ int parse_npy(int fd, const char *path, NpyInfo &info) {
     return DD_OK;
 }
 
+// one .npy file into dst: validate, then pread until done.  expect_dtype < 0 = any of the four element types; the type found -> *found
+int read_npy_into(const char *path, int expect_dtype, int expect_ndim, const long long *expect_shape, void *dst, long long dst_bytes, int *found) {
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return ifail(DD_ERR_INVALID_ARG, "%s: %s", path, strerror(errno));
+    NpyInfo info;
+    int rc = parse_npy(fd, path, info);
+    if (rc == DD_OK) {
+        // (a bool map may be asked for as bytes and the other way round: both are one byte per element with values 0 / 1)
+        const bool bytes = info.dtype == DD_NPY_U8 || info.dtype == DD_NPY_BOOL;
+        const bool same = expect_dtype < 0 || info.dtype == expect_dtype || (bytes && (expect_dtype == DD_NPY_U8 || expect_dtype == DD_NPY_BOOL));
+        bool ok = same && info.ndim == expect_ndim;
+        for (int k = 0; ok && k < info.ndim; ++k) ok = info.shape[k] == expect_shape[k];
+        if (!ok) rc = ifail(DD_ERR_INVALID_ARG, "%s: element type or shape differs from what the view needs", path);
+        else if (info.nbytes > dst_bytes) rc = ifail(DD_ERR_WORKSPACE, "%s: destination buffer too small", path);
+    }
+    if (rc == DD_OK) {
+        if (found) *found = info.dtype;
+        char *out = reinterpret_cast<char *>(dst);
+        long long done = 0;
+        while (done < info.nbytes) {
+            const ssize_t got = pread(fd, out + done, (size_t)(info.nbytes - done), info.data_offset + done);
+            if (got < 0 && errno == EINTR) continue;
+            if (got <= 0) { rc = ifail(DD_ERR_INVALID_ARG, "%s: %s", path, got == 0 ? "file shorter than its header says" : strerror(errno)); break; }
+            done += got;
+        }
+    }
+    close(fd);
+    return rc;
+}
+
 }  // namespace
+
+// ==================================================================================================
+// The prefetcher: native threads that read the .npy files of the views to come into page-locked slots while the main thread enqueues
+// the current view -- the job of the pipeline's Python thread pool, without Python.  (Sixteen Python prefetch threads took the
+// interpreter lock whenever the main thread let go of it -- at every tensor or library call -- and the loop around the kernels spent
+// 0.6-1.3 ms per view waiting for its turn; with native threads nobody else wants the lock.)  Job t uses slot t mod slots; a slot is
+// refilled once its previous job has been released and the event given with the release (recorded by the caller behind its last
+// read of the slot, e.g. by dd_upload_async) has passed.  Page-locked memory is taken lazily, by the worker that first fills a slot.
+// ==================================================================================================
+struct DDPrefetcher {
+    struct File { std::string path; int dtype, ndim; long long shape[4]; long long offset; int found; };
+    struct Job {
+        long long ticket = -1;
+        int state = 0;                  // 0 free (released), 1 queued, 2 running, 3 done
+        int status = DD_OK;
+        std::string error;
+        std::vector<File> files;
+        void *release_event = nullptr;  // of the slot's PREVIOUS job, synchronised before the slot is written again
+    };
+    int device = 0;
+    int nslots = 0;
+    long long slot_bytes = 0;
+    std::vector<void *> slot_mem;
+    std::vector<Job> jobs;              // by slot
+    long long next_ticket = 0, next_to_run = 0;
+    bool stop = false;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::thread> workers;
+
+    void run() {
+        (void)hipSetDevice(device);
+        for (;;) {
+            long long t;
+            int slot;
+            void *ev;
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                cv.wait(lock, [&] { return stop || (next_to_run < next_ticket && jobs[next_to_run % nslots].ticket == next_to_run && jobs[next_to_run % nslots].state == 1); });
+                if (stop) return;
+                t = next_to_run++;
+                slot = (int)(t % nslots);
+                jobs[slot].state = 2;
+                ev = jobs[slot].release_event;
+                jobs[slot].release_event = nullptr;
+            }
+            int status = DD_OK;
+            std::string error;
+            if (ev && hipEventSynchronize((hipEvent_t)ev) != hipSuccess) (void)hipGetLastError();      // (an event of a dead stream: nothing reads the slot any more)
+            if (!slot_mem[slot]) {
+                void *mem = nullptr;
+                if (hipHostMalloc(&mem, (size_t)slot_bytes, hipHostMallocDefault) != hipSuccess) {
+                    (void)hipGetLastError();
+                    mem = malloc((size_t)slot_bytes);            // ordinary memory: still correct, the upload is then the driver's pageable copy
+                }
+                if (!mem) { status = DD_ERR_WORKSPACE; error = "out of host memory for a staging slot"; }
+                slot_mem[slot] = mem;
+            }
+            if (status == DD_OK) {
+                std::vector<File> &files = jobs[slot].files;      // (ours alone while the job is running)
+                for (File &f : files) {
+                    if (f.offset < 0 || f.offset > slot_bytes) { status = DD_ERR_INVALID_ARG; error = "file offset outside the slot"; break; }
+                    status = read_npy_into(f.path.c_str(), f.dtype, f.ndim, f.shape, reinterpret_cast<char *>(slot_mem[slot]) + f.offset, slot_bytes - f.offset, &f.found);
+                    if (status != DD_OK) { error = g_ierr; break; }
+                }
+            }
+            {
+                std::lock_guard<std::mutex> lock(mu);
+                jobs[slot].status = status;
+                jobs[slot].error = error;
+                jobs[slot].state = 3;
+            }
+            cv.notify_all();
+        }
+    }
+};
 
 extern "C" {
 
 const char *dd_ingest_last_error(void) { return g_ierr; }
+
+int dd_prefetch_create(int32_t threads, int32_t slots, int64_t slot_bytes, DDPrefetcher **out) {
+    if (!out) return ifail(DD_ERR_INVALID_ARG, "out is NULL");
+    if (threads < 1 || threads > 256 || slots < 1 || slots > 4096 || slot_bytes < 1) return ifail(DD_ERR_INVALID_ARG, "dd_prefetch_create: threads 1..256, slots 1..4096, slot_bytes >= 1");
+    DDPrefetcher *p = new DDPrefetcher();
+    if (hipGetDevice(&p->device) != hipSuccess) { (void)hipGetLastError(); p->device = 0; }
+    p->nslots = slots; p->slot_bytes = slot_bytes;
+    p->slot_mem.assign((size_t)slots, nullptr);
+    p->jobs.resize((size_t)slots);
+    for (int i = 0; i < threads; ++i) p->workers.emplace_back([p] { p->run(); });
+    *out = p;
+    return DD_OK;
+}
+
+int64_t dd_prefetch_submit(DDPrefetcher *p, int32_t n, const char *const *paths, const int32_t *expect_dtype, const int32_t *ndim,
+                           const int64_t *shapes, const int64_t *offsets) {
+    if (!p || n < 1 || n > 8 || !paths || !expect_dtype || !ndim || !shapes || !offsets) return ifail(DD_ERR_INVALID_ARG, "dd_prefetch_submit: NULL argument or n outside 1..8");
+    std::unique_lock<std::mutex> lock(p->mu);
+    const long long t = p->next_ticket;
+    DDPrefetcher::Job &job = p->jobs[t % p->nslots];
+    if (job.state != 0) return ifail(DD_ERR_WORKSPACE, "dd_prefetch_submit: every slot holds a job that has not been released (submit at most `slots` jobs ahead)");
+    job.files.clear();
+    for (int i = 0; i < n; ++i) {
+        if (!paths[i] || ndim[i] < 1 || ndim[i] > 4) return ifail(DD_ERR_INVALID_ARG, "dd_prefetch_submit: NULL path or ndim outside 1..4");
+        DDPrefetcher::File f;
+        f.path = paths[i]; f.dtype = expect_dtype[i]; f.ndim = ndim[i]; f.offset = offsets[i]; f.found = -1;
+        for (int k = 0; k < 4; ++k) f.shape[k] = k < ndim[i] ? shapes[4 * i + k] : 1;
+        job.files.push_back(f);
+    }
+    job.ticket = t; job.state = 1; job.status = DD_OK; job.error.clear();
+    p->next_ticket = t + 1;
+    lock.unlock();
+    p->cv.notify_all();
+    return t;
+}
+
+int dd_prefetch_wait(DDPrefetcher *p, int64_t ticket, void **base_out, int32_t *dtypes_out) {
+    if (!p) return ifail(DD_ERR_INVALID_ARG, "prefetcher is NULL");
+    std::unique_lock<std::mutex> lock(p->mu);
+    if (ticket < 0 || ticket >= p->next_ticket) return ifail(DD_ERR_INVALID_ARG, "dd_prefetch_wait: no such ticket");
+    DDPrefetcher::Job &job = p->jobs[ticket % p->nslots];
+    if (job.ticket != ticket) return ifail(DD_ERR_INVALID_ARG, "dd_prefetch_wait: the ticket's slot has been given to a later job");
+    p->cv.wait(lock, [&] { return job.state == 3 || job.state == 0 || p->stop; });
+    if (job.state != 3) return ifail(DD_ERR_INVALID_ARG, "dd_prefetch_wait: the job was released or the prefetcher is shutting down");
+    if (base_out) *base_out = p->slot_mem[ticket % p->nslots];
+    if (dtypes_out) for (size_t i = 0; i < job.files.size(); ++i) dtypes_out[i] = job.files[i].found;
+    if (job.status != DD_OK) snprintf(g_ierr, sizeof(g_ierr), "%s", job.error.c_str());
+    return job.status;
+}
+
+int dd_prefetch_release(DDPrefetcher *p, int64_t ticket, void *event) {
+    if (!p) return ifail(DD_ERR_INVALID_ARG, "prefetcher is NULL");
+    {
+        std::lock_guard<std::mutex> lock(p->mu);
+        if (ticket < 0 || ticket >= p->next_ticket) return ifail(DD_ERR_INVALID_ARG, "dd_prefetch_release: no such ticket");
+        DDPrefetcher::Job &job = p->jobs[ticket % p->nslots];
+        if (job.ticket != ticket || job.state != 3) return ifail(DD_ERR_INVALID_ARG, "dd_prefetch_release: the job is not finished (dd_prefetch_wait first) or was released already");
+        job.state = 0;
+        job.release_event = event;
+    }
+    p->cv.notify_all();
+    return DD_OK;
+}
+
+int dd_prefetch_destroy(DDPrefetcher *p) {
+    if (!p) return DD_OK;
+    {
+        std::lock_guard<std::mutex> lock(p->mu);
+        p->stop = true;
+    }
+    p->cv.notify_all();
+    for (std::thread &w : p->workers) w.join();
+    for (void *m : p->slot_mem)
+        if (m && hipHostFree(m) != hipSuccess) { (void)hipGetLastError(); free(m); }
+    delete p;
+    return DD_OK;
+}
 
 int dd_npy_header(const char *path, int32_t *dtype_out, int32_t *ndim_out, int64_t *shape_out, int64_t *data_offset_out) {
     if (!path) return ifail(DD_ERR_INVALID_ARG, "path is NULL");
@@ -115,30 +304,10 @@ int dd_npy_header(const char *path, int32_t *dtype_out, int32_t *ndim_out, int64
 
 int dd_npy_read(const char *path, int32_t expect_dtype, int32_t expect_ndim, const int64_t *expect_shape, void *dst, int64_t dst_bytes) {
     if (!path || !dst || !expect_shape) return ifail(DD_ERR_INVALID_ARG, "path / dst / expect_shape is NULL");
-    const int fd = open(path, O_RDONLY | O_CLOEXEC);
-    if (fd < 0) return ifail(DD_ERR_INVALID_ARG, "%s: %s", path, strerror(errno));
-    NpyInfo info;
-    int rc = parse_npy(fd, path, info);
-    if (rc == DD_OK) {
-        // (a bool map may be asked for as bytes and the other way round: both are one byte per element with values 0 / 1)
-        const bool same = info.dtype == expect_dtype || ((info.dtype == DD_NPY_U8 || info.dtype == DD_NPY_BOOL) && (expect_dtype == DD_NPY_U8 || expect_dtype == DD_NPY_BOOL));
-        bool ok = same && info.ndim == expect_ndim;
-        for (int k = 0; ok && k < info.ndim; ++k) ok = info.shape[k] == expect_shape[k];
-        if (!ok) rc = ifail(DD_ERR_INVALID_ARG, "%s: element type or shape differs from what the view needs", path);
-        else if (info.nbytes > dst_bytes) rc = ifail(DD_ERR_WORKSPACE, "%s: destination buffer too small", path);
-    }
-    if (rc == DD_OK) {
-        char *out = reinterpret_cast<char *>(dst);
-        long long done = 0;
-        while (done < info.nbytes) {
-            const ssize_t got = pread(fd, out + done, (size_t)(info.nbytes - done), info.data_offset + done);
-            if (got < 0 && errno == EINTR) continue;
-            if (got <= 0) { rc = ifail(DD_ERR_INVALID_ARG, "%s: %s", path, got == 0 ? "file shorter than its header says" : strerror(errno)); break; }
-            done += got;
-        }
-    }
-    close(fd);
-    return rc;
+    if (expect_ndim < 1 || expect_ndim > 4) return ifail(DD_ERR_INVALID_ARG, "expect_ndim outside 1..4");
+    long long shape[4] = {1, 1, 1, 1};
+    for (int k = 0; k < expect_ndim; ++k) shape[k] = expect_shape[k];
+    return read_npy_into(path, expect_dtype, expect_ndim, shape, dst, dst_bytes, nullptr);
 }
 
 int dd_upload_async(int32_t n, const void *const *src_host, void *const *dst_dev, const int64_t *nbytes, void *event, void *stream) {

@@ -177,8 +177,14 @@ class _PinnedRing:
             self._views[k][:arr.nbytes] = arr.view(np.uint8).reshape(-1)
             return self._ptrs[k], k
 
-    def staged_until(self, slot: int, event) -> None:
-        self._events[slot] = event
+    def staged_until(self, slot: int, stream) -> None:
+        """The stream operation that reads the slot has been enqueued on ``stream``: the slot is free once the stream has passed here.
+        (An event of the slot's own -- never one the caller re-records for something later: a reuse of the slot would wait for THAT.)"""
+        ev = self._slot_events[slot]
+        if ev is None:
+            ev = self._slot_events[slot] = torch.cuda.Event()
+        ev.record(stream)
+        self._events[slot] = ev
 
     def _allocate(self) -> None:
         # one page-locked block for all slots (a pinned allocation costs ~0.3 ms whatever its size)
@@ -187,6 +193,7 @@ class _PinnedRing:
         self._views = [b.numpy() for b in self._bufs]
         self._ptrs = [b.data_ptr() for b in self._bufs]
         self._events = [None] * self.slots
+        self._slot_events = [None] * self.slots
 
     def _upload(self, arr: np.ndarray, device: torch.device) -> torch.Tensor:
         if not self._bufs:

@@ -82,6 +82,14 @@ class DepthRefiner:
             print(f"[DepthRefiner] Using {self.device.type.upper()} backend with "
                   f"{'FP16' if self.dtype == torch.float16 else 'FP32'}")
 
+    trace: Optional[dict] = None           # a caller's dict: host seconds per step of begin_refine (the pipeline's loop report)
+
+    def _lap(self, key: str, t0: float) -> float:
+        now = time.perf_counter()
+        if self.trace is not None:
+            self.trace[key] = self.trace.get(key, 0.0) + now - t0
+        return now
+
     # ---- pieces -----------------------------------------------------------------------
     def _to(self, x: ArrayLike, dtype=None) -> torch.Tensor:
         t = torch.from_numpy(x) if isinstance(x, np.ndarray) else x
@@ -119,7 +127,7 @@ class DepthRefiner:
         """Piecewise-linear transfer curve through the sorted knots ``(x, y)`` (``depth_refiner.py:141-178``);
         clamped at the end knots, floored at 1e-3.  ``reciprocal``: ``t = (d - x0) * (1 / dx)`` instead of the reference's
         ``(d - x0) / dx`` -- what the HIP kernels compute since round 6 (the reciprocal is a property of the interval,
-        ``csrc/ddrefine_math.h``; at most two ulps of ``t`` apart): the tests' exact oracle for them."""
+        ``csrc/ddrefine_math.h``; at most two ulps of ``t`` apart): what the tests compare the kernels with, bit for bit."""
         if len(d) < 4:
             return d * torch.median(y / (d + 1e-6))
         order = torch.argsort(x)
@@ -165,9 +173,11 @@ class DepthRefiner:
             raise DDCoreError(rc, lib.dd_refine_last_error().decode())
         return out
 
-    def _apply_curve(self, depth: torch.Tensor, mask: torch.Tensor, x: torch.Tensor, y: torch.Tensor, reciprocal: bool = False) -> torch.Tensor:
-        """``depth_refiner.py:180-205``: curve on masked pixels, 3x3 median, zeros outside the mask."""
-        if depth.is_cuda and len(x) >= 2 and int(mask.sum().item()) >= 4:       # (:143-145, 153-154 keep the tensor path)
+    def _apply_curve(self, depth: torch.Tensor, mask: torch.Tensor, x: torch.Tensor, y: torch.Tensor, reciprocal: bool = False,
+                     n_masked: Optional[int] = None) -> torch.Tensor:
+        """``depth_refiner.py:180-205``: curve on masked pixels, 3x3 median, zeros outside the mask.  ``n_masked``: the number of set
+        mask pixels if the caller knows it (the fit counts them: no host synchronisation here then)."""
+        if depth.is_cuda and len(x) >= 2 and (n_masked if n_masked is not None else int(mask.sum().item())) >= 4:       # (:143-145, 153-154 keep the tensor path)
             return self._apply_curve_hip(depth, mask, x, y)
         out = torch.zeros_like(depth)
         if mask.any():
@@ -203,14 +213,17 @@ class DepthRefiner:
             host, ready = torch.empty(8, dtype=torch.int32, pin_memory=True), torch.cuda.Event()
             ready.record(stream)                      # (creates the underlying event: its handle goes to the native call)
         staged = None
+        t_ = time.perf_counter()
         if isinstance(points3D, np.ndarray):
             from .densify import _small
             staged = _small.stage(np.ascontiguousarray(points3D, dtype=np.float32).reshape(-1, 3))
+        t_ = self._lap("fit_launch.stage_points", t_)
         if staged is not None and isinstance(mask_or_count, (torch.Tensor, type(None))) and (mask_or_count is None or mask_or_count.dtype in (torch.bool, torch.uint8)):
             # ONE native call: points up, fit, masked-pixel count, result words down, event (dd_refine_fit_async) -- the calls the host
             # makes per view are what bounds the loop around the kernels (profiles/r06_bench_pipeline.txt)
             n = int(np.asarray(points3D).reshape(-1, 3).shape[0])
             work = torch.empty(6 * max(n, 1) + 8, dtype=torch.float32, device=self.device)
+            t_ = self._lap("fit_launch.empty_work", t_)
             m = mask_or_count
             rc = lib.dd_refine_fit_async(staged[0], n, (C.c_float * 12)(*E.tolist()), (C.c_float * 6)(*Kq.tolist()), d.data_ptr(),
                                          DD_F16 if d.dtype == torch.float16 else DD_F32, d.shape[0], d.shape[1], int(self.edge_margin),
@@ -219,7 +232,8 @@ class DepthRefiner:
                                          ready.cuda_event, stream.cuda_stream)
             if rc < 0:
                 raise DDCoreError(rc, lib.dd_refine_last_error().decode())
-            _small.staged_until(staged[1], ready)
+            self._lap("fit_launch.native_call", t_)
+            _small.staged_until(staged[1], stream)
             nn = max(n, 1)
             return {"work": work, "n": nn, "host": host, "ready": ready, "keep": (d, m)}
         if isinstance(points3D, np.ndarray):
@@ -291,7 +305,9 @@ class DepthRefiner:
         if self.verbose > 1:
             print(f"[DepthRefiner] Input depth shape: {tuple(depth_map.shape)}")
             print(f"[DepthRefiner] COLMAP points: {len(points3D)}")
+        t_ = time.perf_counter()
         depth = self._to(depth_map)
+        t_ = self._lap("begin_refine.depth_to_working_precision", t_)
         gpu_fit = depth.is_cuda and depth.dim() == 2 and min(depth.shape) >= 2
         # (on the GPU path a missing mask stays None -- the kernels test depth > 0 themselves -- and is only made when a tensor branch asks)
         m = self._to(mask, torch.bool) if mask is not None else (None if gpu_fit else depth > 0)
@@ -300,7 +316,9 @@ class DepthRefiner:
         if gpu_fit:
             # GPU: the whole correspondence half is one hand-written kernel (the number of masked pixels, needed later to
             # choose the apply path, is counted beside it and read in the fit's own synchronisation)
+            t_ = self._lap("begin_refine.mask", t_)
             h["fit"] = self._fit_launch(depth, points3D, cam_from_world, K, mask_or_count=m.contiguous() if m is not None else None)
+            self._lap("begin_refine.fit_launch", t_)
         return h
 
     def finish_refine(self, h: dict) -> dict[str, Any]:
@@ -344,10 +362,12 @@ class DepthRefiner:
                     # float(result["scale_factor"]) gives the number in either case
                     return {"refined_depth": None, "curve": (kx, ky, bool(self.skip_smoothing)), "raw_depth": depth,
                             "num_correspondences": n_corr, "outliers_removed": removed, "scale_factor": scale}
-            scale = float(scale)
+            if not (return_tensor and self.verbose <= 0):
+                scale = float(scale)                             # (a device scalar after the adaptive subsample: reading it synchronises -- a
+                                                                 # caller that keeps the map on the device gets the scalar as it is, see fit_only)
             if m is None:
                 m = depth > 0                                    # depth_refiner.py:241
-            refined = self._apply_curve(depth, m, z_mono, z_metric)
+            refined = self._apply_curve(depth, m, z_mono, z_metric, n_masked=n_masked)
             if self.verbose > 0:
                 print(f"[DepthRefiner] Refined using {n_corr} correspondences")
                 if removed > 0:

@@ -39,6 +39,7 @@ class StagingSlot:
     def __init__(self):
         self._bufs: dict = {}
         self._free: Optional[torch.cuda.Event] = None
+        self._ev: Optional[torch.cuda.Event] = None      # the slot's own event, recorded natively by dd_upload_async (event_handle)
 
     def array(self, key: str, shape, dtype) -> np.ndarray:
         tdt = torch.from_numpy(np.empty(0, dtype=dtype)).dtype
@@ -73,6 +74,20 @@ class StagingSlot:
         ev = torch.cuda.Event()
         ev.record(stream)
         self._free = ev
+
+    def event_handle(self, stream) -> int:
+        """The raw handle of the slot's own event for a native call that records it behind the uploads (``dd_upload_async``); the
+        caller then calls ``released_natively()``."""
+        if self._ev is None:
+            self._ev = torch.cuda.Event()
+            self._ev.record(stream)                  # (creates the underlying event)
+        return self._ev.cuda_event
+
+    def released_natively(self) -> None:
+        self._free = self._ev
+
+
+_TORCH_OF = {"float32": torch.float32, "float16": torch.float16, "uint8": torch.uint8, "bool": torch.bool, "float64": torch.float64}
 
 
 class DepthSource:
@@ -208,6 +223,37 @@ class CachedSource(DepthSource):
             raise ValueError(f"{f}: depth is {maps['depth'].shape}, image at processing resolution is {(h, w)}")
         return maps
 
+    def upload_staged(self, maps: dict, rgb_u8: np.ndarray, slot: StagingSlot, device: torch.device, copy_stream=None, fork_event=None):
+        """The maps ``prepare(..., staging=slot)`` left in the slot and the image (``slot.put("rgb", ...)``) to the device with ONE native
+        call (``dd_upload_async``: the copies and the event that frees the slot) -> (``infer``'s dictionary, the image on the device).
+        ``copy_stream`` (with ``fork_event``, an event of the caller's): the copies run on that stream -- beside the kernels of the
+        views before, not in line with them (41 MB per 1080p view: 0.76 ms of PCIe against 0.03 ms of kernels) -- ordered behind what the
+        current stream has enqueued so far (the destination blocks may have had readers there) and in front of what it enqueues next."""
+        import ctypes as C
+        from ._lib import lib
+        keys = [k for k in ("depth", "mask", "normal") if k in maps]
+        out = {k: torch.empty(maps[k].shape, dtype=_TORCH_OF[maps[k].dtype.name], device=device) for k in keys}
+        rgb_dev = torch.empty(rgb_u8.shape, dtype=torch.uint8, device=device)
+        n = len(keys) + 1
+        src = (C.c_void_p * n)(*[slot.pointer(k) for k in keys], slot.pointer("rgb"))
+        dst = (C.c_void_p * n)(*[out[k].data_ptr() for k in keys], rgb_dev.data_ptr())
+        size = (C.c_int64 * n)(*[maps[k].nbytes for k in keys], rgb_u8.nbytes)
+        stream = torch.cuda.current_stream(device)
+        ev = slot.event_handle(stream)
+        if copy_stream is not None:
+            lib.dd_stream_fork(fork_event.cuda_event, stream.cuda_stream, copy_stream.cuda_stream)
+        if lib.dd_upload_async(n, src, dst, size, ev, (copy_stream or stream).cuda_stream) < 0:
+            raise RuntimeError(f"libddcore: {lib.dd_ingest_last_error().decode('utf-8', 'replace')}")
+        if copy_stream is not None:
+            lib.dd_stream_wait(stream.cuda_stream, ev)
+        slot.released_natively()
+        h, w = rgb_u8.shape[:2]
+        mask = out.get("mask")
+        if mask is not None and mask.dtype != torch.bool:
+            mask = mask.bool()
+        return {"depth": out["depth"], "normal": out.get("normal"),
+                "mask": mask if mask is not None else torch.ones((h, w), dtype=torch.bool, device=device)}, rgb_dev
+
     def infer(self, image_name, rgb_u8, device, prepared=None):
         maps = prepared if prepared is not None else self.prepare(image_name, rgb_u8)
         h, w = rgb_u8.shape[:2]
@@ -215,6 +261,155 @@ class CachedSource(DepthSource):
         mask = g("mask")
         return {"depth": g("depth"), "normal": g("normal"),
                 "mask": mask.bool() if mask is not None else torch.ones((h, w), dtype=torch.bool, device=device)}
+
+
+_PREFETCHERS: dict = {}              # (threads, slots) -> (handle, slot bytes, the slots' events)
+_PREFETCHERS_LOCK = threading.Lock()
+
+
+class _Staged:
+    """What ``upload_staged`` needs to know of an array that lies in a staging slot: shape, element type, bytes."""
+    __slots__ = ("shape", "dtype", "nbytes")
+
+    def __init__(self, shape, dtype):
+        self.shape, self.dtype = tuple(shape), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+
+
+class _NativeSlot:
+    """One job of the native prefetcher as the pipeline's staging slot: addresses of the view's arrays, the event that frees it."""
+
+    def __init__(self, feeder: "NativeFeeder", ticket: int, base: int, offsets: dict):
+        self.feeder, self.ticket, self.base, self.offsets = feeder, ticket, base, offsets
+        self._bufs = offsets                       # (the keys the slot holds, as StagingSlot has them)
+
+    def pointer(self, key: str) -> int:
+        return self.base + self.offsets[key]
+
+    def event_handle(self, stream) -> int:
+        return self.feeder.event_handle(self.ticket, stream)
+
+    def released_natively(self) -> None:
+        self.feeder.release(self.ticket)
+
+
+class NativeFeeder:
+    """The views' cached ``.npy`` files read ahead by native threads (``dd_prefetch_*``, csrc/ddingest.hip) instead of a Python thread
+    pool: with no second Python thread nobody competes with the main thread for the interpreter lock (16 prefetch threads cost the
+    loop 0.6-1.3 ms per view in waiting for it: profiles/r06_bench_pipeline.txt).  ``get(k)`` -> what ``fetch`` returns."""
+
+    KEYS = ("depth", "mask", "normal", "rgb")
+    CODES = {"depth": -1, "mask": 3, "normal": 0, "rgb": 2}      # DD_NPY_*: the depth may be float32 or float16
+    DTYPES = {0: np.float32, 1: np.float16, 2: np.uint8, 3: np.bool_}
+
+    def __init__(self, source: "CachedSource", names, sizes: dict, threads: int, ahead: int):
+        import ctypes as C
+        from ._lib import lib
+        self._C, self._lib = C, lib
+        self.source, self.names, self.sizes = source, list(names), sizes
+        first = source._stem(self.names[0])
+        self.keys = [k for k in self.KEYS if (source.dir / f"{first}_{k}.npy").exists()]
+        if "depth" not in self.keys or "rgb" not in self.keys:
+            raise FileNotFoundError("the cache holds no <stem>_depth.npy / <stem>_rgb.npy")
+        w0, h0 = sizes[self.names[0]]
+        for key in self.keys:                        # the first view's files must be what its size says (an image cached at another size: not this path)
+            dt, nd, shape = C.c_int32(), C.c_int32(), (C.c_int64 * 4)()
+            if lib.dd_npy_header(str(source.dir / f"{first}_{key}.npy").encode(), C.byref(dt), C.byref(nd), shape, None) < 0 \
+                    or (int(shape[0]), int(shape[1])) != (h0, w0) or (self.CODES[key] >= 0 and int(dt.value) not in ((2, 3) if key == "mask" else (self.CODES[key],))):
+                raise FileNotFoundError(f"{first}_{key}.npy is not the {key} of a {w0} x {h0} view")
+        self.ahead = max(1, int(ahead))
+        self.nslots = self.ahead + 2
+        self.slot_bytes = max(sum(self._bytes(k, sizes[n]) for k in self.keys) + 64 * len(self.keys) for n in self.names)
+        # one prefetcher per process and shape of use, kept across scans (scripts/run_batch.py runs scan after scan): its slots are
+        # page-locked memory, and locking 1.4 GB of it again for every scan costs more than reading the scan
+        key = (int(threads), self.nslots)
+        with _PREFETCHERS_LOCK:
+            have = _PREFETCHERS.get(key)
+            if have is not None and have[1] < self.slot_bytes:
+                lib.dd_prefetch_destroy(have[0])
+                have = None
+            if have is None:
+                h = C.c_void_p()
+                if lib.dd_prefetch_create(int(threads), self.nslots, self.slot_bytes, C.byref(h)) < 0:
+                    raise RuntimeError(lib.dd_ingest_last_error().decode("utf-8", "replace"))
+                have = _PREFETCHERS[key] = (h, self.slot_bytes, [None] * self.nslots)
+        self._h, _, self._events = have
+        self._submitted = 0
+        self._tickets: dict = {}          # view index -> ticket (tickets count on over the scans of a process)
+        self._offsets: dict = {}
+        for _ in range(min(self.ahead, len(self.names))):
+            self._submit()
+
+    @staticmethod
+    def _bytes(key: str, size) -> int:
+        w, h = size
+        return h * w * {"depth": 4, "mask": 1, "normal": 12, "rgb": 3}[key]
+
+    def _submit(self) -> None:
+        C, k = self._C, self._submitted
+        if k >= len(self.names):
+            return
+        name = self.names[k]
+        w, h = self.sizes[name]
+        stem = self.source._stem(name)
+        n = len(self.keys)
+        offs, at = {}, 0
+        for key in self.keys:
+            offs[key], at = at, at + ((self._bytes(key, (w, h)) + 63) & ~63)
+        paths = (C.c_char_p * n)(*[str(self.source.dir / f"{stem}_{key}.npy").encode() for key in self.keys])
+        codes = (C.c_int32 * n)(*[self.CODES[key] for key in self.keys])
+        nds = (C.c_int32 * n)(*[3 if key in ("normal", "rgb") else 2 for key in self.keys])
+        shapes = (C.c_int64 * (4 * n))(*[x for key in self.keys for x in ((h, w, 3, 1) if key in ("normal", "rgb") else (h, w, 1, 1))])
+        t = self._lib.dd_prefetch_submit(self._h, n, paths, codes, nds, shapes, (C.c_int64 * n)(*[offs[key] for key in self.keys]))
+        if t < 0:
+            raise RuntimeError(f"prefetcher: {self._lib.dd_ingest_last_error().decode('utf-8', 'replace')}")
+        self._tickets[k], self._offsets[k] = int(t), offs
+        self._submitted += 1
+
+    def get(self, k: int):
+        C = self._C
+        base, found = C.c_void_p(), (C.c_int32 * 8)()
+        t = self._tickets.pop(k)
+        if self._lib.dd_prefetch_wait(self._h, t, C.byref(base), found) < 0:
+            why = self._lib.dd_ingest_last_error().decode("utf-8", "replace")
+            self._offsets.pop(k, None)
+            self._lib.dd_prefetch_release(self._h, t, None)      # (the slot goes on; the caller reads this view its other way)
+            self._submit()
+            raise OSError(f"libddcore: {why}")
+        w, h = self.sizes[self.names[k]]
+        maps = {}
+        for i, key in enumerate(self.keys):
+            if key != "rgb":
+                maps[key] = _Staged((h, w, 3) if key == "normal" else (h, w), self.DTYPES[int(found[i])])
+        return _Staged((h, w, 3), np.uint8), maps, _NativeSlot(self, t, int(base.value), self._offsets.pop(k))
+
+    def event_handle(self, ticket: int, stream) -> int:
+        s = ticket % self.nslots
+        if self._events[s] is None:
+            self._events[s] = torch.cuda.Event()
+            self._events[s].record(stream)           # (creates the underlying event)
+        return self._events[s].cuda_event
+
+    def release(self, ticket: int) -> None:
+        ev = self._events[ticket % self.nslots]
+        if self._lib.dd_prefetch_release(self._h, ticket, None if ev is None else ev.cuda_event) < 0:
+            raise RuntimeError(self._lib.dd_ingest_last_error().decode("utf-8", "replace"))
+        self._submit()                               # the slot is spoken for again: the next view to come
+
+    def close(self) -> None:
+        """Jobs that were read ahead and never taken are waited for and given back: the prefetcher goes on to the next scan."""
+        if self._h is not None:
+            for k, t in sorted(self._tickets.items()):
+                self._lib.dd_prefetch_wait(self._h, t, None, None)
+                self._lib.dd_prefetch_release(self._h, t, None)
+            self._tickets.clear()
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001
+            pass
 
 
 def dump_cache(source: DepthSource, image_dir: Path, cache_dir: Path, device: torch.device, factor: int = 1,

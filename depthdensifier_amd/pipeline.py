@@ -231,6 +231,8 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
     clock = time.perf_counter
     detail: dict = {}                                                          # finer: seconds per step of the loop (report["loop_detail"])
 
+    refiner.trace = detail
+
     def lap(key: str, t_from: float) -> float:
         now = clock()
         detail[key] = detail.get(key, 0.0) + (now - t_from)
@@ -260,8 +262,22 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
     # decode / cache reads run `ahead` views in front of the GPU on a small pool; order of consumption is unchanged.
     # Each view in flight owns a slot of pinned staging buffers (ahead + 1 of them, round-robin): the maps are uploaded by
     # asynchronous DMA instead of the driver's pageable copy on this thread.
-    pool = ThreadPoolExecutor(max_workers=config.processing.io_threads) if config.processing.io_threads > 0 else None
     ahead = 2 * config.processing.io_threads
+    # a cache that holds every map AND the decoded image as .npy files is read ahead by NATIVE threads (depth_source.NativeFeeder): no
+    # second Python thread, nobody to share the interpreter lock with.  Anything else (images to decode, .npz archives): Python threads.
+    feeder = None
+    if config.processing.io_threads > 0 and mine and hasattr(source, "upload_staged") and os.environ.get("DD_NATIVE_PREFETCH", "1") == "1":
+        try:
+            from .depth_source import NativeFeeder
+            feeder = NativeFeeder(source, [im.name for im in mine], sizes, config.processing.io_threads, ahead)
+        except (FileNotFoundError, OSError, RuntimeError):
+            feeder = None
+    pool = ThreadPoolExecutor(max_workers=config.processing.io_threads) if config.processing.io_threads > 0 and feeder is None else None
+    # the uploads of staged views run on a stream of their own, beside the kernels of the views before them
+    copy_stream, fork_event = None, None
+    if config.processing.io_threads > 0 and hasattr(source, "upload_staged") and os.environ.get("DD_COPY_STREAM", "1") == "1":
+        copy_stream, fork_event = torch.cuda.Stream(device), torch.cuda.Event()
+        fork_event.record(torch.cuda.current_stream(device))                   # (creates the underlying event)
     from .depth_source import StagingSlot
     slots = [StagingSlot() for _ in range(ahead + 2)] if pool else []
     pending: deque = deque(pool.submit(fetch, im, slots[j % len(slots)]) for j, im in enumerate(mine[:ahead])) if pool else deque()
@@ -272,7 +288,12 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
         t0_ = clock()
         pts_world = rec.xyz_of(image.observed_point3D_ids())                    # :139
         t1 = lap("sparse_points", t0_)
-        if pool:
+        if feeder is not None:
+            try:
+                rgb, prepared, slot = feeder.get(k)
+            except OSError:                                                     # this view's files are not what its size says: read it the other way
+                rgb, prepared, slot = fetch(image)
+        elif pool:
             rgb, prepared, slot = pending.popleft().result()
             if k + ahead < len(mine):                                           # its slot was released two views ago at the latest
                 pending.append(pool.submit(fetch, mine[k + ahead], slots[(k + ahead) % len(slots)]))
@@ -280,12 +301,18 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
             rgb, prepared, slot = fetch(image)
         new_h, new_w = rgb.shape[:2]
         t2 = lap("wait_for_io_thread", t1)
-        maps = source.infer(image.name, rgb, device, prepared=prepared)         # :161-168, stays on device
-        tx = lap("upload_maps", t2)
-        rgb_dev = torch.from_numpy(rgb).to(device, non_blocking=True)           # :215 the colours, uploaded with the maps
-        if slot is not None:
-            slot.release(torch.cuda.current_stream(device))                     # every upload from the slot is enqueued by now
-        t3 = lap("upload_rgb_release_slot", tx)
+        staged = slot is not None and prepared is not None and hasattr(source, "upload_staged") and "rgb" in slot._bufs and rgb is not None \
+            and all(a.dtype.name in ("float32", "float16", "uint8", "bool") for a in prepared.values())
+        if staged:
+            maps, rgb_dev = source.upload_staged(prepared, rgb, slot, device, copy_stream, fork_event)    # :161-168 + :215: maps and colours up, slot freed
+            tx = t3 = lap("upload_maps", t2)
+        else:
+            maps = source.infer(image.name, rgb, device, prepared=prepared)         # :161-168, stays on device
+            tx = lap("upload_maps", t2)
+            rgb_dev = torch.from_numpy(rgb).to(device, non_blocking=True)           # :215 the colours, uploaded with the maps
+            if slot is not None:
+                slot.release(torch.cuda.current_stream(device))                     # every upload from the slot is enqueued by now
+            t3 = lap("upload_rgb_release_slot", tx)
         camera = rec.cameras[image.camera_id]
         camera.rescale(new_width=new_w, new_height=new_h)                       # :172-173 (in place, like the reference)
         E = image.cam_from_world().matrix()[:3, :]                              # :177
@@ -370,6 +397,9 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
         finish(inflight.popleft())
     if pool:
         pool.shutdown(wait=False, cancel_futures=True)
+    if feeder is not None:
+        torch.cuda.current_stream(device).synchronize()                         # (no upload still reads a slot)
+        feeder.close()
     say(f"-> Image processing loop finished in {time.time() - t_loop:.2f}s.")
 
     report = {"views": num_views, "dense_points": 0, "removed": 0, "timings": stage, "loop_detail": detail, "loop_seconds": time.time() - t_loop}

@@ -220,6 +220,8 @@ int dd_unproject_compact(const DDViewBatch *batch, const DDCloudOut *out,
  * nothing is enqueued: a chain of small calls on resident maps then carries no barrier packet at all. */
 int dd_stream_fork(void *event, void *from_stream, void *to_stream);
 
+/* `stream` waits (on the device) for `event`, a hipEvent_t recorded elsewhere -- e.g. by dd_upload_async on a copy stream. */
+int dd_stream_wait(void *stream, void *event);
 /* ABI 13: do kernels of `stream_a` and `stream_b` run side by side?  The HIP runtime deals streams to a few hardware queues, and two
  * streams that share one run strictly in order -- calls chained across them (DDViewBatch.chain) would then be SLOWER than on one
  * stream.  A one-thread kernel on `stream_a` waits (at most 1 ms) for a flag that a kernel launched behind it on `stream_b` raises;
@@ -323,6 +325,19 @@ int dd_npy_read(const char *path, int32_t expect_dtype, int32_t expect_ndim, con
 /* n host -> device copies on `stream` and, behind them, `event` (a hipEvent_t or NULL) -- one call instead of n + 1. */
 int dd_upload_async(int32_t n, const void *const *src_host, void *const *dst_dev, const int64_t *nbytes, void *event, void *stream);
 const char *dd_ingest_last_error(void);
+/* The prefetcher: `threads` native threads read the .npy files of views to come into `slots` page-locked staging slots of slot_bytes
+ * each (taken lazily).  dd_prefetch_submit queues a job of n <= 8 files -- file i, expected as in dd_npy_read (expect_dtype < 0: any of
+ * the four types), goes to byte offset offsets[i] of the job's slot -- and returns its ticket (0, 1, 2 ...; job t uses slot t mod
+ * slots).  dd_prefetch_wait blocks until the job is done and returns its status, the slot's address and the element types found;
+ * dd_prefetch_release gives the slot back: it is refilled once `event` (a hipEvent_t the caller recorded behind its last read of the
+ * slot, e.g. through dd_upload_async; NULL = at once) has passed.  Jobs are released by their owner, at most `slots` in flight. */
+typedef struct DDPrefetcher DDPrefetcher;
+int dd_prefetch_create(int32_t threads, int32_t slots, int64_t slot_bytes, DDPrefetcher **out);
+int64_t dd_prefetch_submit(DDPrefetcher *p, int32_t n, const char *const *paths, const int32_t *expect_dtype, const int32_t *ndim,
+                           const int64_t *shapes /* n x 4 */, const int64_t *offsets);
+int dd_prefetch_wait(DDPrefetcher *p, int64_t ticket, void **base_out, int32_t *dtypes_out);
+int dd_prefetch_release(DDPrefetcher *p, int64_t ticket, void *event);
+int dd_prefetch_destroy(DDPrefetcher *p);
 
 /* ---------------------------------------------------------------------------------------------
  * the per-pixel half of DepthRefiner as one kernel --

@@ -333,3 +333,71 @@ def test_arena_layout_planning(tmp_path):
                     "-o", str(exe), str(ROOT / "tests" / "c_client" / "arena_plan_test.cpp")], check=True, timeout=120)
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0 and "plan OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_native_npy_reader_and_prefetcher(libmod, tmp_path):
+    """csrc/ddingest.hip on the host: .npy headers and arrays read without the interpreter (element type and shape checked against what
+    the view needs), and the prefetcher -- native threads filling staging slots ahead of the consumer, a slot refilled only after its
+    release -- against np.load.  (No GPU here: the slots are ordinary memory and events are NULL; the GPU twin is the pipeline itself.)"""
+    import numpy as np
+    L = libmod.lib
+    rng = np.random.default_rng(3)
+    H, W, V = 12, 20, 9
+    want = []
+    for v in range(V):
+        maps = {"depth": rng.uniform(0.5, 5, (H, W)).astype(np.float16 if v % 2 else np.float32), "mask": rng.uniform(size=(H, W)) < 0.7,
+                "normal": rng.normal(size=(H, W, 3)).astype(np.float32), "rgb": rng.integers(0, 256, (H, W, 3), dtype=np.uint8)}
+        for k, a in maps.items():
+            np.save(tmp_path / f"v{v}_{k}.npy", a)
+        want.append(maps)
+    np.save(tmp_path / "f64.npy", np.zeros((2, 2)))
+    np.save(tmp_path / "fortran.npy", np.asfortranarray(np.zeros((3, 4), np.float32)))
+    dt, nd, shape, off = C.c_int32(), C.c_int32(), (C.c_int64 * 4)(), C.c_int64()
+    assert L.dd_npy_header(str(tmp_path / "v1_depth.npy").encode(), C.byref(dt), C.byref(nd), shape, C.byref(off)) == 0
+    assert (dt.value, nd.value, list(shape)[:2]) == (libmod.DD_NPY_F16, 2, [H, W]) and off.value % 64 == 0
+    assert L.dd_npy_header(str(tmp_path / "f64.npy").encode(), C.byref(dt), C.byref(nd), shape, None) == -4 and b"element type" in L.dd_ingest_last_error()
+    assert L.dd_npy_header(str(tmp_path / "fortran.npy").encode(), C.byref(dt), C.byref(nd), shape, None) == -4
+    assert L.dd_npy_header(str(tmp_path / "nothing.npy").encode(), C.byref(dt), C.byref(nd), shape, None) == -1 and b"No such file" in L.dd_ingest_last_error()
+    out = np.empty((H, W, 3), np.float32)
+    ok = lambda name, code, shp: L.dd_npy_read(str(tmp_path / name).encode(), code, len(shp), (C.c_int64 * 4)(*shp), out.ctypes.data, out.nbytes)
+    assert ok("v0_normal.npy", libmod.DD_NPY_F32, (H, W, 3)) == 0 and np.array_equal(out, want[0]["normal"])
+    assert ok("v0_normal.npy", libmod.DD_NPY_F32, (H, W + 1, 3)) == -1 and ok("v0_normal.npy", libmod.DD_NPY_F16, (H, W, 3)) == -1
+    assert ok("v0_mask.npy", libmod.DD_NPY_U8, (H, W)) == 0                       # bool files read as bytes
+    # the prefetcher: 4 slots, 3 threads, 3 jobs ahead
+    sizes = {"depth": H * W * 4, "mask": H * W, "normal": H * W * 12, "rgb": H * W * 3}
+    offs, at = {}, 0
+    for k, n in sizes.items():
+        offs[k], at = at, at + ((n + 63) & ~63)
+    handle = C.c_void_p()
+    assert L.dd_prefetch_create(3, 4, at, C.byref(handle)) == 0
+    keys = list(sizes)
+
+    def submit(v):
+        paths = (C.c_char_p * 4)(*[str(tmp_path / f"v{v}_{k}.npy").encode() for k in keys])
+        codes = (C.c_int32 * 4)(-1, libmod.DD_NPY_BOOL, libmod.DD_NPY_F32, libmod.DD_NPY_U8)
+        nds = (C.c_int32 * 4)(2, 2, 3, 3)
+        shp = (C.c_int64 * 16)(H, W, 1, 1, H, W, 1, 1, H, W, 3, 1, H, W, 3, 1)
+        return L.dd_prefetch_submit(handle, 4, paths, codes, nds, shp, (C.c_int64 * 4)(*[offs[k] for k in keys]))
+
+    tickets = [submit(v) for v in range(3)]
+    assert tickets == [0, 1, 2]
+    for v in range(V):
+        base, found = C.c_void_p(), (C.c_int32 * 8)()
+        assert L.dd_prefetch_wait(handle, tickets[v], C.byref(base), found) == 0, L.dd_ingest_last_error()
+        assert found[0] == (libmod.DD_NPY_F16 if v % 2 else libmod.DD_NPY_F32)
+        for i, k in enumerate(keys):
+            a = want[v][k]
+            got = np.frombuffer((C.c_char * a.nbytes).from_address(base.value + offs[k]), dtype=a.dtype).reshape(a.shape)
+            assert np.array_equal(got, a), (v, k)
+        assert L.dd_prefetch_release(handle, tickets[v], None) == 0
+        assert L.dd_prefetch_release(handle, tickets[v], None) == -1                   # once
+        if v + 3 < V:
+            tickets.append(submit(v + 3))
+    # a job whose file is missing reports it at the wait; more jobs than slots without a release is refused
+    paths = (C.c_char_p * 1)(str(tmp_path / "gone.npy").encode())
+    t = L.dd_prefetch_submit(handle, 1, paths, (C.c_int32 * 1)(-1), (C.c_int32 * 1)(2), (C.c_int64 * 4)(H, W, 1, 1), (C.c_int64 * 1)(0))
+    assert t == V and L.dd_prefetch_wait(handle, t, None, None) == -1 and b"gone.npy" in L.dd_ingest_last_error()
+    for _ in range(3):
+        assert submit(0) >= 0
+    assert submit(0) == -3 and b"released" in L.dd_ingest_last_error()
+    assert L.dd_prefetch_destroy(handle) == 0
