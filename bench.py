@@ -518,6 +518,9 @@ def fused_refine_record(dd, cfg, scene, params, E, builder, device) -> dict:
     for _ in range(5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(device)
+        # the launch's duration, not the host's way to it: an untimed launch keeps the GPU busy while the timed one is enqueued behind
+        # it (round 5 recorded e0 on an idle stream: the ~0.2 ms the host needs to reach the launch were counted as kernel time)
+        builder.reset(); builder.append(fused)
         builder.reset(); e0.record(); builder.append(fused); e1.record()
         torch.cuda.synchronize(device)
         ts.append(e0.elapsed_time(e1))
@@ -539,7 +542,7 @@ def fused_refine_record(dd, cfg, scene, params, E, builder, device) -> dict:
             and (got.normals is None or torch.equal(got.normals, want.normals)) and (got.colors is None or torch.equal(got.colors, want.colors)))
     return {"what": "raw depth -> points in ONE kernel (DD_REFINE: transfer curve + 3x3 median fused into the densify kernel; refined map written for the filter "
                     "cache), the whole workload in one batch, 500 knots", "ms": round(med, 4), "us_per_view": round(1e3 * med / V, 2), "points": int(n),
-            "algorithmic_bytes": int(alg), "frac": round(alg / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "bound": "valu (235 vector instructions per pixel; plain kernel: 86)",
+            "algorithmic_bytes": int(alg), "frac": round(alg / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "bound": "hbm + valu (profiles/r06_fused_refine.txt: the look-ups cost 1.7 us of 17 per view, the windows 0.9, the refined map's write 1.4)",
             "equals_refine_apply_then_plain": bool(same), "views_compared": k}
 
 

@@ -1244,23 +1244,34 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
         // row up and down); replicate padding = clamped coordinates, so nothing outside the view is ever needed
         float *const s_val = reinterpret_cast<float *>(s_raw);
         const unsigned Wd = (unsigned)a.W, Hd = (unsigned)a.H;
+#ifdef DD_X_NO_HALO      // experiment (tools/bench_fused_refine.py --variants): what the halo's look-ups cost (wrong medians at the tile's ends)
         const unsigned lo = q0 > Wd + 1u ? q0 - (Wd + 1u) : 0u;
         const unsigned hi = (q0 + (unsigned)LT + Wd + 1u) < a.P ? (q0 + (unsigned)LT + Wd + 1u) : a.P;
+        const unsigned lo_eval = q0, hi_eval = (q0 + (unsigned)LT) < a.P ? q0 + (unsigned)LT : a.P;
+#else
+        const unsigned lo = q0 > Wd + 1u ? q0 - (Wd + 1u) : 0u;
+        const unsigned hi = (q0 + (unsigned)LT + Wd + 1u) < a.P ? (q0 + (unsigned)LT + Wd + 1u) : a.P;
+        const unsigned lo_eval = lo, hi_eval = hi;
+#endif
         // Rounds 5-6: this stage is bound by the vector ALU, not by memory (24 us per 1080p view where the plain kernel takes 14).  The
         // curve's interval is found through a grid of buckets (the knots that share the depth's bucket: ~1), the blend reads both knots
         // with one LDS access and multiplies by the interval's reciprocal width instead of dividing (ddrefine_math.h), four values per
         // lane and step with their bisections in lock step; four consecutive windows share their sorted columns (median9x4).
+#ifdef DD_X_NO_BUILD     // experiment (with DD_X_NO_LUT): what building the curve per tile costs
+        ddmath::Curve curve; curve.kxy = s_kxy; curve.inv = s_inv; curve.grid = s_grid; curve.n = nk; curve.x0 = 0.0f; curve.scale = 0.0f;
+#else
         const ddmath::Curve curve = ddmath::curve_build(s_kxy, s_inv, s_grid, vp->knots_x, vp->knots_y, nk, tid, BT);
+#endif
         // (tried in round 2: batches of 7 pixels per lane with their loads issued together and a fixed-trip lockstep search --
         // 6 % SLOWER on the same box; the other waves of the CU already hide these latencies and the early-exit search does less work)
         bool any_nan = false;
         {
             // four consecutive values per lane and step: one wide load of the depth, one of the mask, four look-ups in lock step.
             // Scalar bases + 32-bit byte offsets (the window is < 2^16 values): no 64-bit address arithmetic per lane.
-            const unsigned cnt = hi - lo;
+            const unsigned cnt = hi_eval - lo;
             const unsigned char *const dbase = reinterpret_cast<const unsigned char *>(a.depth) + (vbase + lo) * (a.raw_f16 ? 2 : 4);
             const unsigned char *const mbase = a.mask ? a.mask + vbase + lo : nullptr;
-            for (unsigned e4 = (unsigned)tid * 4u; e4 < cnt; e4 += (unsigned)BT * 4u) {
+            for (unsigned e4 = (unsigned)tid * 4u + ((lo_eval - lo) & ~3u); e4 < cnt; e4 += (unsigned)BT * 4u) {
                 float raw[4], val[4];
                 bool mk[4];
                 const bool whole = e4 + 4u <= cnt;
@@ -1285,7 +1296,12 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
                         mk[k] = in && (mbase ? (mbase[e] != 0) : (raw[k] > 0.0f));
                     }
                 }
+#ifdef DD_X_NO_LUT       // experiment: what the look-ups cost
+#pragma unroll
+                for (int k = 0; k < 4; ++k) val[k] = mk[k] ? raw[k] : 0.0f;
+#else
                 ddmath::curve_eval4(curve, raw, mk, val);                                     // :185-191
+#endif
                 any_nan |= (val[0] != val[0]) | (val[1] != val[1]) | (val[2] != val[2]) | (val[3] != val[3]);
                 if (whole) *reinterpret_cast<float4 *>(s_val + e4) = make_float4(val[0], val[1], val[2], val[3]);
                 else {
@@ -1295,7 +1311,11 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
             }
         }
         const bool tile_nan = __syncthreads_or((int)any_nan) != 0;            // (a NaN anywhere in the tile or its halo: the windows take the careful path)
+#ifdef DD_X_NO_MEDIAN    // experiment: what the windows cost
+        const bool smooth = false;
+#else
         const bool smooth = vp->skip_smoothing == 0;
+#endif
         float ref[CH][VEC];
         unsigned y0g = 0u, x0g = 0u;
 #pragma unroll
@@ -1306,16 +1326,24 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
             else { x0g += (unsigned)CSPAN; while (x0g >= Wd) { x0g -= Wd; ++y0g; } }
             y = y0g; x = x0g;
             unsigned b = 0;
-            // four windows of one image row, none at the left or right border, no NaN in the tile: their columns are sorted once
-            const bool fast = smooth && !tile_nan && VEC == 4 && qb + 4u <= a.P && x >= 1u && x + 5u <= Wd;
+            // four windows of one image row, no NaN in the tile: their six columns are sorted once.  At the row's ends the outer
+            // columns are the replicate padding (clamped coordinates) -- no separate path for them: a wave holds half a row or more,
+            // so nearly every wave has a lane at a row's end, and a divergent slow path would be executed by all of them (round 6)
+            const bool fast = smooth && !tile_nan && VEC == 4 && qb + 4u <= a.P && x + 4u <= Wd;
             if (fast) {
                 const unsigned ym = y ? y - 1u : 0u, yp = y + 1u < Hd ? y + 1u : Hd - 1u;
-                const float *const r1 = s_val + (y * Wd + x - 1u - lo);
+                const unsigned c0 = x ? x - 1u : 0u, c5 = x + 4u < Wd ? x + 4u : Wd - 1u;
+                float v0[6], v1[6], v2[6];
+                const unsigned b0 = ym * Wd - lo, b1 = y * Wd - lo, b2 = yp * Wd - lo;      // (mod 2^32: a row may start in front of the window, the sums below never do)
+                v0[0] = s_val[b0 + c0]; v1[0] = s_val[b1 + c0]; v2[0] = s_val[b2 + c0];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { v0[k + 1] = s_val[b0 + x + (unsigned)k]; v1[k + 1] = s_val[b1 + x + (unsigned)k]; v2[k + 1] = s_val[b2 + x + (unsigned)k]; }
+                v0[5] = s_val[b0 + c5]; v1[5] = s_val[b1 + c5]; v2[5] = s_val[b2 + c5];
                 float m4[4];
-                ddmath::median9x4(s_val + (ym * Wd + x - 1u - lo), r1, s_val + (yp * Wd + x - 1u - lo), m4);
+                ddmath::median9x4(v0, v1, v2, m4);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float r = (r1[k + 1] != 0.0f) ? m4[k] : 0.0f;       // :203
+                    const float r = (v1[k + 1] != 0.0f) ? m4[k] : 0.0f;       // :203
                     if (r > 0.0f) b |= 1u << k;
                     ref[ch][k] = r;
                 }
@@ -1346,9 +1374,14 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
             bits[ch] = b;
             d[ch].x = __float_as_uint(ref[ch][0]); d[ch].y = __float_as_uint(ref[ch][1]);
             d[ch].z = __float_as_uint(ref[ch][2]); d[ch].w = __float_as_uint(ref[ch][3]);
+#ifdef DD_X_NO_REFOUT
+            if (false) {
+#else
             if (a.refined_out) {                       // the filter's cache (scripts/test.py:197-201)
+#endif
                 float *o = a.refined_out + vbase + qb;
-                if (qb + (unsigned)VEC <= a.P && ((vbase + qb) & 3) == 0) *reinterpret_cast<uint4 *>(o) = d[ch];
+                // (written once, read by the filter much later: past the L2 -- 17.7 -> 17.0 us per 1080p view, profiles/r06_fused_refine.txt)
+                if (qb + (unsigned)VEC <= a.P && ((vbase + qb) & 3) == 0) __builtin_nontemporal_store(u32x4{d[ch].x, d[ch].y, d[ch].z, d[ch].w}, reinterpret_cast<u32x4 *>(o));
                 else {
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) if (qb + (unsigned)k < a.P) o[k] = ref[ch][k];

@@ -166,7 +166,8 @@ __device__ __forceinline__ float median9(float (&v)[9]) {
 // columns they share are sorted once (min3 / med3 / max3), every window is the med3 of (max of its three column minima, med of the
 // medians, min of the maxima).  r0 / r1 / r2: the three rows, six values each (columns x-1 .. x+4).  Selects inputs like median9:
 // the same bits (no -0 can occur: a value is 0, >= 1e-3 or NaN).
-__device__ __forceinline__ void median9x4(const float *r0, const float *r1, const float *r2, float (&out)[4]) {
+template <typename Row>
+__device__ __forceinline__ void median9x4(const Row &r0, const Row &r1, const Row &r2, float (&out)[4]) {
     float lo[6], mid[6], hi[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {

@@ -12,6 +12,8 @@ from depthdensifier_amd.depth_refiner import DepthRefiner
 
 ap = argparse.ArgumentParser(); ap.add_argument("--views", type=int, default=64)
 ap.add_argument("--tuning", type=lambda x: int(x, 0), default=0, help="variant word of the fused batch (tests/lab_bits.py: a product tuning + experiment switches of include/ddcore_lab.h)")
+ap.add_argument("--variants", nargs="*", default=[], help="experiment builds of csrc/ddcore.hip timed on the fused batch, interleaved with the product library: tag:-Dflag,-Dflag (tools/ab_builds.build); tags that start with x_ may compute something else")
+ap.add_argument("--rounds", type=int, default=7)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 cfg = dict(bench.WORKLOADS["garden185"]); cfg["V"] = a.views
@@ -56,3 +58,37 @@ pix = V * H * W
 rho = n / pix
 print(f"bytes per pixel by the model: unfused {5 + 4 + 5 + rho * 42:.1f} (refine 5 r + 4 w, densify 5 r + rho 42), fused {5 + 4 + rho * 42:.1f} "
       f"(5 r + 4 w for the filter cache + rho 42); rho = {rho:.3f}")
+
+if a.variants:
+    import ctypes as C
+    sys.path.insert(0, str(ROOT / "tools"))
+    import ab_builds
+    from depthdensifier_amd import _lib
+    libs = [("product", _lib.lib)]
+    for spec in a.variants:
+        tag, _, fl = spec.partition(":")
+        libs.append((tag, ab_builds.build(tag, [f for f in fl.split(",") if f])))
+    cb, out = fused_batch.c_struct(), b._out_struct()
+    cb.tuning |= _lib.DD_TUNE_BY_INDEX
+    ws = torch.zeros(4 * fused_batch.workspace_bytes() + 4096, dtype=torch.uint8, device=dev)
+    offs = torch.empty(V + 1, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    times = {tag: [] for tag, _ in libs}
+    ref = None
+    for r in range(a.rounds + 1):
+        for tag, lib in libs:
+            b.cursor.zero_()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = lib.dd_unproject_compact(C.byref(cb), C.byref(out), offs.data_ptr(), b.cursor.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+            e1.record(); torch.cuda.synchronize()
+            assert rc == 0, (tag, rc)
+            if r == 0:
+                chk = (int(b.cursor.item()), float(b.xyz[: int(b.cursor.item())].double().sum()))
+                ref = ref or chk
+                assert chk == ref or tag.startswith("x_"), f"variant {tag} computes something else: {chk} vs {ref}"
+            else:
+                times[tag].append(e0.elapsed_time(e1))
+    for tag, _ in libs:
+        t = sorted(times[tag])
+        print(f"{tag:<28s} median {t[len(t) // 2] / V * 1e3:6.2f} us per view   min {t[0] / V * 1e3:6.2f}   ({V} views, kernel alone through the C ABI)")
