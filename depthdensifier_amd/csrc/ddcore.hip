@@ -468,6 +468,9 @@ __global__ __launch_bounds__(BLOCK) void compact_generic(const KArgs a) {
 #ifndef DD_LEAN_WGS
 #define DD_LEAN_WGS 6
 #endif
+#ifndef DD_REFINE_EV
+#define DD_REFINE_EV 4
+#endif
 constexpr int L_PXT = DD_L_PXT;              // pixels per lane per tile
 constexpr int L_WSPAN = 64 * L_PXT;          // 1024 pixels per wave
 constexpr int L_TILE = WAVES * L_WSPAN;      // 4096
@@ -1245,12 +1248,15 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
         float *const s_val = reinterpret_cast<float *>(s_raw);
         const unsigned Wd = (unsigned)a.W, Hd = (unsigned)a.H;
 #ifdef DD_X_NO_HALO      // experiment (tools/bench_fused_refine.py --variants): what the halo's look-ups cost (wrong medians at the tile's ends)
-        const unsigned lo = q0 > Wd + 1u ? q0 - (Wd + 1u) : 0u;
+        const unsigned lo = (q0 > Wd + 1u ? q0 - (Wd + 1u) : 0u) & ~3u;
         const unsigned hi = (q0 + (unsigned)LT + Wd + 1u) < a.P ? (q0 + (unsigned)LT + Wd + 1u) : a.P;
         const unsigned lo_eval = q0, hi_eval = (q0 + (unsigned)LT) < a.P ? q0 + (unsigned)LT : a.P;
 #else
-        const unsigned lo = q0 > Wd + 1u ? q0 - (Wd + 1u) : 0u;
         const unsigned hi = (q0 + (unsigned)LT + Wd + 1u) < a.P ? (q0 + (unsigned)LT + Wd + 1u) : a.P;
+        // (the window starts on a multiple of four values where that fits the LDS -- it always does below 3070 columns: a lane's four
+        //  pixels then sit on a 16-byte boundary of s_val whenever the width is a multiple of four, and are read with one LDS access)
+        const unsigned lo_raw = q0 > Wd + 1u ? q0 - (Wd + 1u) : 0u;
+        const unsigned lo = hi - (lo_raw & ~3u) <= (unsigned)(LT * 6 / 4) ? (lo_raw & ~3u) : lo_raw;
         const unsigned lo_eval = lo, hi_eval = hi;
 #endif
         // Rounds 5-6: this stage is bound by the vector ALU, not by memory (24 us per 1080p view where the plain kernel takes 14).  The
@@ -1271,42 +1277,50 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
             const unsigned cnt = hi_eval - lo;
             const unsigned char *const dbase = reinterpret_cast<const unsigned char *>(a.depth) + (vbase + lo) * (a.raw_f16 ? 2 : 4);
             const unsigned char *const mbase = a.mask ? a.mask + vbase + lo : nullptr;
-            for (unsigned e4 = (unsigned)tid * 4u + ((lo_eval - lo) & ~3u); e4 < cnt; e4 += (unsigned)BT * 4u) {
-                float raw[4], val[4];
-                bool mk[4];
-                const bool whole = e4 + 4u <= cnt;
-                if (whole) {
-                    if (a.raw_f16) {
-                        const u32x2 w = *reinterpret_cast<const u32x2_unaligned *>(dbase + e4 * 2u);
-                        raw[0] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w.x & 0xffffu)); raw[1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w.x >> 16));
-                        raw[2] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w.y & 0xffffu)); raw[3] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w.y >> 16));
+            constexpr int EV = DD_REFINE_EV;             // values per lane and step (4, or 8: two wide loads and eight look-ups in lock step)
+            for (unsigned e0 = (unsigned)tid * (unsigned)EV + ((lo_eval - lo) & ~3u); e0 < cnt; e0 += (unsigned)BT * (unsigned)EV) {
+                float raw[EV], val[EV];
+                bool mk[EV];
+#pragma unroll
+                for (int g = 0; g < EV; g += 4) {
+                    const unsigned e4 = e0 + (unsigned)g;
+                    if (e4 + 4u <= cnt) {
+                        if (a.raw_f16) {
+                            const u32x2 w = *reinterpret_cast<const u32x2_unaligned *>(dbase + e4 * 2u);
+                            raw[g + 0] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w.x & 0xffffu)); raw[g + 1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w.x >> 16));
+                            raw[g + 2] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w.y & 0xffffu)); raw[g + 3] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w.y >> 16));
+                        } else {
+                            const u32x4 w = *reinterpret_cast<const u32x4_unaligned *>(dbase + e4 * 4u);
+                            raw[g + 0] = __uint_as_float(w.x); raw[g + 1] = __uint_as_float(w.y); raw[g + 2] = __uint_as_float(w.z); raw[g + 3] = __uint_as_float(w.w);
+                        }
+                        const unsigned m4 = mbase ? *reinterpret_cast<const u32_unaligned *>(mbase + e4) : 0u;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) mk[g + k] = mbase ? ((m4 >> (8 * k)) & 0xffu) != 0u : (raw[g + k] > 0.0f);      // depth_refiner.py:238-241
                     } else {
-                        const u32x4 w = *reinterpret_cast<const u32x4_unaligned *>(dbase + e4 * 4u);
-                        raw[0] = __uint_as_float(w.x); raw[1] = __uint_as_float(w.y); raw[2] = __uint_as_float(w.z); raw[3] = __uint_as_float(w.w);
-                    }
-                    const unsigned m4 = mbase ? *reinterpret_cast<const u32_unaligned *>(mbase + e4) : 0u;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) mk[k] = mbase ? ((m4 >> (8 * k)) & 0xffu) != 0u : (raw[k] > 0.0f);      // depth_refiner.py:238-241
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const bool in = e4 + (unsigned)k < cnt;
-                        const unsigned e = e4 + (in ? (unsigned)k : 0u);
-                        raw[k] = a.raw_f16 ? (float)*reinterpret_cast<const _Float16 *>(dbase + e * 2u) : *reinterpret_cast<const float *>(dbase + e * 4u);
-                        mk[k] = in && (mbase ? (mbase[e] != 0) : (raw[k] > 0.0f));
+                        for (int k = 0; k < 4; ++k) {
+                            const bool in = e4 + (unsigned)k < cnt;
+                            const unsigned e = in ? e4 + (unsigned)k : 0u;
+                            raw[g + k] = a.raw_f16 ? (float)*reinterpret_cast<const _Float16 *>(dbase + e * 2u) : *reinterpret_cast<const float *>(dbase + e * 4u);
+                            mk[g + k] = in && (mbase ? (mbase[e] != 0) : (raw[g + k] > 0.0f));
+                        }
                     }
                 }
 #ifdef DD_X_NO_LUT       // experiment: what the look-ups cost
 #pragma unroll
-                for (int k = 0; k < 4; ++k) val[k] = mk[k] ? raw[k] : 0.0f;
+                for (int k = 0; k < EV; ++k) val[k] = mk[k] ? raw[k] : 0.0f;
 #else
-                ddmath::curve_eval4(curve, raw, mk, val);                                     // :185-191
+                ddmath::curve_evalN<EV>(curve, raw, mk, val);                                 // :185-191
 #endif
-                any_nan |= (val[0] != val[0]) | (val[1] != val[1]) | (val[2] != val[2]) | (val[3] != val[3]);
-                if (whole) *reinterpret_cast<float4 *>(s_val + e4) = make_float4(val[0], val[1], val[2], val[3]);
-                else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) if (e4 + (unsigned)k < cnt) s_val[e4 + k] = val[k];
+                for (int g = 0; g < EV; g += 4) {
+                    const unsigned e4 = e0 + (unsigned)g;
+                    any_nan |= (val[g] != val[g]) | (val[g + 1] != val[g + 1]) | (val[g + 2] != val[g + 2]) | (val[g + 3] != val[g + 3]);
+                    if (e4 + 4u <= cnt) *reinterpret_cast<float4 *>(s_val + e4) = make_float4(val[g], val[g + 1], val[g + 2], val[g + 3]);
+                    else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (e4 + (unsigned)k < cnt) s_val[e4 + k] = val[g + k];
+                    }
                 }
             }
         }
@@ -1317,6 +1331,7 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
         const bool smooth = vp->skip_smoothing == 0;
 #endif
         float ref[CH][VEC];
+        const bool quads = (lo & 3u) == 0u && (Wd & 3u) == 0u;      // wave-uniform: every lane's four pixels are one image row's, 16-byte aligned in s_val
         unsigned y0g = 0u, x0g = 0u;
 #pragma unroll
         for (int ch = 0; ch < CH; ++ch) {
@@ -1335,10 +1350,36 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
                 const unsigned c0 = x ? x - 1u : 0u, c5 = x + 4u < Wd ? x + 4u : Wd - 1u;
                 float v0[6], v1[6], v2[6];
                 const unsigned b0 = ym * Wd - lo, b1 = y * Wd - lo, b2 = yp * Wd - lo;      // (mod 2^32: a row may start in front of the window, the sums below never do)
-                v0[0] = s_val[b0 + c0]; v1[0] = s_val[b1 + c0]; v2[0] = s_val[b2 + c0];
+                if (quads) {
+                    // the four own columns of each row with ONE 16-byte LDS read (dword reads at a lane stride of four collide four ways in
+                    // the banks); the outer two columns are the neighbouring lanes' -- a wave shift -- and come from the LDS only at the
+                    // wave's two ends; at a row's ends they are the replicate padding, i.e. the lane's own outer columns
+                    const float4 q0v = *reinterpret_cast<const float4 *>(s_val + (b0 + x)), q1v = *reinterpret_cast<const float4 *>(s_val + (b1 + x)),
+                                 q2v = *reinterpret_cast<const float4 *>(s_val + (b2 + x));
+                    v0[1] = q0v.x; v0[2] = q0v.y; v0[3] = q0v.z; v0[4] = q0v.w;
+                    v1[1] = q1v.x; v1[2] = q1v.y; v1[3] = q1v.z; v1[4] = q1v.w;
+                    v2[1] = q2v.x; v2[2] = q2v.y; v2[3] = q2v.z; v2[4] = q2v.w;
+                    auto from_left = [&](float mine, unsigned at) {     // column x - 1: lane - 1 holds it as its fourth column
+                        float v = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine), 0x138, 0xF, 0xF, false));     // wave_shr:1
+                        if (lane == 0) v = s_val[at];
+                        return v;
+                    };
+                    auto from_right = [&](float mine, unsigned at) {    // column x + 4: lane + 1 holds it as its first column
+                        float v = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine), 0x130, 0xF, 0xF, false));     // wave_shl:1
+                        if (lane == 63) v = s_val[at];
+                        return v;
+                    };
+                    const bool first = x == 0u, last = x + 4u == Wd;
+                    const float l0 = from_left(v0[4], b0 + c0), l1 = from_left(v1[4], b1 + c0), l2 = from_left(v2[4], b2 + c0);
+                    const float r0 = from_right(v0[1], b0 + c5), r1 = from_right(v1[1], b1 + c5), r2 = from_right(v2[1], b2 + c5);
+                    v0[0] = first ? v0[1] : l0; v1[0] = first ? v1[1] : l1; v2[0] = first ? v2[1] : l2;
+                    v0[5] = last ? v0[4] : r0; v1[5] = last ? v1[4] : r1; v2[5] = last ? v2[4] : r2;
+                } else {
+                    v0[0] = s_val[b0 + c0]; v1[0] = s_val[b1 + c0]; v2[0] = s_val[b2 + c0];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { v0[k + 1] = s_val[b0 + x + (unsigned)k]; v1[k + 1] = s_val[b1 + x + (unsigned)k]; v2[k + 1] = s_val[b2 + x + (unsigned)k]; }
-                v0[5] = s_val[b0 + c5]; v1[5] = s_val[b1 + c5]; v2[5] = s_val[b2 + c5];
+                    for (int k = 0; k < 4; ++k) { v0[k + 1] = s_val[b0 + x + (unsigned)k]; v1[k + 1] = s_val[b1 + x + (unsigned)k]; v2[k + 1] = s_val[b2 + x + (unsigned)k]; }
+                    v0[5] = s_val[b0 + c5]; v1[5] = s_val[b1 + c5]; v2[5] = s_val[b2 + c5];
+                }
                 float m4[4];
                 ddmath::median9x4(v0, v1, v2, m4);
 #pragma unroll

@@ -97,27 +97,33 @@ __device__ __forceinline__ float curve_blend(const Curve &c, float d, int lo) {
 }
 // Four values at once, their (short) bisections in lock step: the four chains of dependent LDS reads overlap, and the trip count is
 // what the slowest lane of the wave needs.  out[k] = 0 where !mk[k]; a NaN depth comes back as it is.
-__device__ __forceinline__ void curve_eval4(const Curve &c, const float (&d)[4], const bool (&mk)[4], float (&out)[4]) {
-    int base[4], len[4];
+template <int N>
+__device__ __forceinline__ void curve_evalN(const Curve &c, const float (&d)[N], const bool (&mk)[N], float (&out)[N]) {
+    int base[N], len[N];
+    int any = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < N; ++k) {
         const int b = curve_bucket(d[k], c.x0, c.scale);
         base[k] = c.grid[b];
         len[k] = (int)c.grid[b + 1] - base[k];
         if (!mk[k] || d[k] != d[k]) len[k] = 0;
+        any |= len[k];
     }
-    while (__any((len[0] | len[1] | len[2] | len[3]) > 0)) {
+    while (__any(any > 0)) {
+        any = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {                  // lower_bound of d[k] in [base, base + len]
+        for (int k = 0; k < N; ++k) {                  // lower_bound of d[k] in [base, base + len]
             const int half = len[k] >> 1;
             const bool right = len[k] > 0 && c.kxy[base[k] + half].x < d[k];
             base[k] = right ? base[k] + half + 1 : base[k];
             len[k] = right ? len[k] - half - 1 : half;
+            any |= len[k];
         }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) out[k] = !mk[k] ? 0.0f : (d[k] != d[k]) ? d[k] : curve_blend(c, d[k], base[k]);
+    for (int k = 0; k < N; ++k) out[k] = !mk[k] ? 0.0f : (d[k] != d[k]) ? d[k] : curve_blend(c, d[k], base[k]);
 }
+__device__ __forceinline__ void curve_eval4(const Curve &c, const float (&d)[4], const bool (&mk)[4], float (&out)[4]) { curve_evalN<4>(c, d, mk, out); }
 __device__ __forceinline__ float curve_eval(const Curve &c, float d) {      // one value (ragged ends)
     if (d != d) return d;
     const int b = curve_bucket(d, c.x0, c.scale);

@@ -3,6 +3,8 @@
 #   soak <launches> <reps>  the three-rank rehearsal (torchrun, gloo, p2p, views 2 / 4 in turn), <reps> executions per launch
 #   bench [bench args]      python3 bench.py ... -> gpurun_out/r06_bench.json
 #   py <script> [args]      python3 <script> ... -> gpurun_out/r06_<script name>.log
+#   pmc_refine              SQ counters (two passes) of the fused refine kernel beside the plain kernel -> gpurun_out/r06_refine_pmc.json
+#   prof <tag> <cmd...>     rocprofv3 --kernel-trace --stats of a python3 command -> gpurun_out/r06_prof_<tag>_*.csv
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; what=$1; shift
 case "$what" in
 suite)
@@ -30,5 +32,42 @@ bench)
 py)
   s=$1; shift; timeout -k 10 ${PY_SECONDS:-600} python3 $s "$@" > gpurun_out/r06_$(basename $s .py).log 2>&1; rc=$?
   tail -n ${TAIL:-40} gpurun_out/r06_$(basename $s .py).log; exit $rc ;;
+pmc_refine)
+  export TMPDIR=/tmp DD_EXCLUSIVE_GPU=1
+  i=0
+  for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" \
+             "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM"; do
+    i=$((i+1)); rm -rf /tmp/rp_$i
+    (cd /tmp && timeout -k 10 300 rocprofv3 --pmc $set --kernel-include-regex "compact_lean" --kernel-trace --output-format csv -d /tmp/rp_$i -- python3 "$GRAFT_REPO_ROOT/tools/bench_fused_refine.py" --views 185 > "$GRAFT_REPO_ROOT/gpurun_out/r06_refine_pmc_$i.log" 2>&1) || { echo "set $i failed"; tail -5 gpurun_out/r06_refine_pmc_$i.log; exit 1; }
+  done
+  python3 - <<'P'
+import csv, glob, json
+from collections import defaultdict
+acc = defaultdict(lambda: defaultdict(list))
+for i in (1, 2):
+    for f in glob.glob(f"/tmp/rp_{i}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if "compact_lean" not in k: continue
+            tag = "fused_refine" if ("true, 16>" in k or "ELb1ELi16" in k) else "plain"
+            acc[tag][r["Counter_Name"]].append(float(r["Counter_Value"]))
+res = {t: {c: sum(v) / len(v) for c, v in d.items()} for t, d in acc.items()}
+for t, d in res.items():
+    wc = d.get("SQ_WAVE_CYCLES", 0)
+    if wc:
+        d["share_wait_any"] = round(d["SQ_WAIT_ANY"] / wc, 3); d["share_wait_inst"] = round(d["SQ_WAIT_INST_ANY"] / wc, 3); d["share_active"] = round(d["SQ_ACTIVE_INST_ANY"] / wc, 3)
+    if d.get("SQ_BUSY_CYCLES"):
+        d["valu_busy_per_simd"] = round(d.get("SQ_ACTIVE_INST_VALU", 0) * 4 / (d["SQ_BUSY_CYCLES"] / 32 * 1024), 3)
+    d["valu_per_pixel"] = round(d.get("SQ_INSTS_VALU", 0) * 64 / (185 * 1080 * 1920), 1)
+json.dump(res, open("gpurun_out/r06_refine_pmc.json", "w"), indent=1)
+print(json.dumps(res, indent=1))
+P
+  ;;
+prof)
+  tag=$1; shift; export TMPDIR=/tmp; rm -rf /tmp/prof_$tag
+  (cd /tmp && timeout -k 10 ${PROF_SECONDS:-600} rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python3 "$@" > "$GRAFT_REPO_ROOT/gpurun_out/r06_prof_$tag.out" 2> "$GRAFT_REPO_ROOT/gpurun_out/r06_prof_$tag.err"); rc=$?
+  for f in $(find /tmp/prof_$tag -name "*_kernel_stats.csv" 2>/dev/null); do cp "$f" "gpurun_out/r06_prof_${tag}_kernel_stats.csv"; done
+  python3 tools/kernel_trace_groups.py /tmp/prof_$tag "gpurun_out/r06_prof_${tag}_kernel_groups.csv" "$tag: python3 $*" 2>/dev/null | tail -n 12
+  exit $rc ;;
 *) echo "unknown job $what"; exit 2 ;;
 esac
