@@ -47,6 +47,10 @@ WORKLOADS = {
     "mip360conf": dict(V=232, H=1080, W=1920, depth="float32", mask=True, normal=True, rgb=True, rho=0.85, conf=0.5,
                        note="BASELINE configs[3], one GPU's share as ONE batch: 232 = 1626 / 7 views of the Mip-NeRF 360 set "
                             "(synthetic stand-ins), mask AND conf > 0.5; use --views to change"),
+    "mip360conf_smooth": dict(V=232, H=1080, W=1920, depth="float32", mask=True, normal=True, rgb=True, rho=0.85, conf=0.5, conf_kind="smooth",
+                              note="the same share with a spatially COHERENT confidence map (blobs: what a network's confidence looks like) -- the "
+                                   "per-pixel noise of mip360conf keeps a survivor on every 128-byte line of the normal / colour maps, so its gathers "
+                                   "fetch the whole maps (traffic 1.26x the algorithmic bytes: line granularity, not kernel quality)"),
     "mip360x7": dict(V=1626, H=1080, W=1920, depth="float32", mask=True, normal=True, rgb=True, rho=0.85, conf=0.5,
                      scenes=[("bicycle", 194), ("bonsai", 292), ("counter", 240), ("garden", 185), ("kitchen", 279),
                              ("room", 311), ("stump", 125)],
@@ -546,6 +550,86 @@ def fused_refine_record(dd, cfg, scene, params, E, builder, device) -> dict:
             "equals_refine_apply_then_plain": bool(same), "views_compared": k}
 
 
+def pipeline_record(device, views: int = 48) -> dict:
+    """The path as the drop-in drives it (scripts/run_batch.py:57-91 -> scripts/test.py:131-251 -> depthdensifier_amd/pipeline.py): the
+    image loop of one synthetic 1080p scan with every cache warm (maps and decoded image as .npy files), at full density -- host
+    milliseconds per view, how much of that is waiting (for the GPU: 41 MB of maps per view come over PCIe; for the prefetcher), the
+    loop's wall clock and the densify kernel's share of it.  The scan is written to a temporary directory first (not timed); the
+    loop runs three times, the last one is reported.  profiles/r06_bench_pipeline.txt has the 185-view runs at densities 1 and 32."""
+    import contextlib, io, tempfile
+    from PIL import Image as PILImage
+    from depthdensifier_amd import pipeline as P
+    from depthdensifier_amd.colmap_io import Camera, Image, Reconstruction
+    H, W, V = 1080, 1920, int(views)
+    g = torch.Generator(device=device).manual_seed(11)
+    with tempfile.TemporaryDirectory() as tmp:
+        scan = Path(tmp) / "scan"
+        (scan / "images").mkdir(parents=True); (scan / "sparse" / "0").mkdir(parents=True); (scan / "cache").mkdir()
+        rec = Reconstruction()
+        fx = 0.9 * W
+        rec.cameras[1] = Camera(1, 1, W, H, np.array([fx, fx, W / 2.0, H / 2.0]))
+        us = torch.arange(W, device=device, dtype=torch.float32)[None, :]; vs = torch.arange(H, device=device, dtype=torch.float32)[:, None]
+        flat = PILImage.fromarray(np.full((H, W, 3), 128, np.uint8))
+        ids, xyz, next_id = [], [], 1
+        rng = np.random.default_rng(11)
+        for v in range(V):
+            a = -0.5 + v / max(V - 1, 1)
+            c = np.array([3.0 * np.sin(a), -2.0, -3.0 * np.cos(a)])                       # a camera above the plane y = 0, looking at the origin
+            zax = -c / np.linalg.norm(c); xax = np.cross([0, 1.0, 0], zax); xax /= np.linalg.norm(xax); yax = np.cross(zax, xax)
+            R = np.stack([xax, yax, zax]); t = -R @ c
+            Rt = torch.tensor(R, device=device, dtype=torch.float32)
+            ry = ((us - W / 2.0) / fx) * Rt[0, 1] + ((vs - H / 2.0) / fx) * Rt[1, 1] + Rt[2, 1]     # y of R^T r
+            tt = -float(c[1]) / ry
+            depth_true = torch.where((tt > 0) & torch.isfinite(tt), tt, torch.zeros_like(tt))
+            mask = (depth_true > 0) & (depth_true < 12) & (torch.rand((H, W), device=device, generator=g) < 0.97)
+            mono = 0.5 * depth_true.clamp(min=1e-3) ** 1.1
+            stem = f"img_{v:03d}"
+            np.save(scan / "cache" / f"{stem}_depth.npy", mono.cpu().numpy())
+            np.save(scan / "cache" / f"{stem}_mask.npy", mask.cpu().numpy())
+            np.save(scan / "cache" / f"{stem}_normal.npy", np.tile((np.array([0.0, -1.0, 0.0]) @ R.T).astype(np.float32), (H, W, 1)))
+            np.save(scan / "cache" / f"{stem}_rgb.npy", torch.randint(0, 256, (H, W, 3), device=device, generator=g, dtype=torch.uint8).cpu().numpy())
+            flat.save(scan / "images" / f"{stem}.png")
+            pu = rng.uniform(12, W - 13, 300); pv = rng.uniform(12, H - 13, 300)
+            d = depth_true[torch.as_tensor(pv.astype(int), device=device), torch.as_tensor(pu.astype(int), device=device)].cpu().numpy().astype(np.float64)
+            ok = (d > 0) & (d < 12)
+            pu, pv, d = pu[ok], pv[ok], d[ok]
+            cam = np.stack([(np.floor(pu) - W / 2.0) / fx * d, (np.floor(pv) - H / 2.0) / fx * d, d], -1)
+            world = (cam - t) @ R
+            pid = np.arange(next_id, next_id + len(world)); next_id += len(world)
+            ids.append(pid); xyz.append(world)
+            w4 = np.sqrt(max(0.0, 1 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
+            q = np.array([w4, (R[2, 1] - R[1, 2]) / (4 * w4), (R[0, 2] - R[2, 0]) / (4 * w4), (R[1, 0] - R[0, 1]) / (4 * w4)])
+            rec.images[v + 1] = Image(v + 1, q, t, 1, f"{stem}.png", np.stack([np.floor(pu), np.floor(pv)], -1), pid.astype(np.int64))
+        rec.point_ids = np.concatenate(ids).astype(np.uint64); rec.point_xyz = np.concatenate(xyz)
+        rec.point_rgb = np.full((len(rec.point_ids), 3), 200, np.uint8); rec.point_error = np.zeros(len(rec.point_ids))
+        rec._tracks = [np.zeros((0, 2), np.int32)] * len(rec.point_ids)
+        rec.write_binary(scan / "sparse" / "0")
+        cfg = P.ScriptConfig()
+        cfg.paths = P.PathsConfig(recon_path=scan / "sparse" / "0", image_dir=scan / "images", output_model_dir=Path(tmp) / "out")
+        cfg.moge.cache_dir = scan / "cache"
+        cfg.processing.downsample_density = 1
+        cfg.refiner.verbose = 0
+        rep = None
+        for _ in range(3):
+            with contextlib.redirect_stdout(io.StringIO()):
+                rep = P.main(cfg, _loop_only=True)
+            torch.cuda.synchronize(device)
+    tm, det, n = rep["timings"], rep["loop_detail"], rep["views"]
+    host = sum(tm[k] for k in ("image_decode", "depth_source", "refine", "densify"))
+    waits = det.get("finish_refine_of_which_waiting_for_the_gpu", 0.0) + det.get("wait_for_io_thread", 0.0)
+    wall = rep["loop_seconds"]
+    kernel_us = 17.0                       # the fused refine launch per 1080p view (this line's garden185.fused_refine.us_per_view)
+    return {"what": "pipeline.main's image loop on a synthetic scan, caches warm (maps + decoded image as .npy), downsample_density 1, "
+                    f"{cfg.processing.io_threads} native prefetch threads, {cfg.processing.views_per_launch} views per launch",
+            "views": n, "dense_points": int(rep["dense_points"]),
+            "host_ms_per_view": round(1e3 * host / n, 3), "host_ms_per_view_without_waits": round(1e3 * (host - waits) / n, 3),
+            "waiting_ms_per_view": round(1e3 * waits / n, 3), "loop_wall_ms_per_view": round(1e3 * wall / n, 3),
+            "upload_bytes_per_view": int(H * W * (4 + 1 + 12 + 3)), "pcie_floor_ms_per_view": round(H * W * 20 / 54e9 * 1e3, 3),
+            "densify_share_of_loop": round(kernel_us * 1e-6 * n / wall, 4),
+            "loop_detail_us_per_view": {k: round(1e6 * v / n, 1) for k, v in det.items() if 1e6 * v / n >= 5},
+            "r03": {"host_ms_per_view": 2.04}}
+
+
 def _cpu_worker(job):
     """One process of the all-cores courtesy baseline: the oracle over this worker's views (arrays staged as .npy in
     shared memory by the parent; only the oracle calls are timed)."""
@@ -817,7 +901,7 @@ def main() -> None:
         the oracle, the kernel re-timed on fresh allocations.  Returns (the line rank 0 would print for it, what is still resident)."""
         cfg = dict(WORKLOADS[workload])
         cfg["mask_kind"] = args.mask_kind
-        cfg["conf_kind"] = args.conf_kind
+        cfg["conf_kind"] = cfg.get("conf_kind", args.conf_kind)      # (a workload may fix its kind of confidence map: mip360conf_smooth)
         strong = workload == "scene2000"
         multi = "scenes" in cfg                          # whole scenes back to back, dealt to the ranks
         if views_override:
@@ -1071,7 +1155,7 @@ def main() -> None:
             traffic, traffic_source = None, None
             tfile = ROOT / "profiles" / "traffic.json"
             if tfile.exists():
-                tkey = ("mip360conf" if multi else workload) + (":bernoulli" if args.mask_kind == "bernoulli" else "") + (":smooth" if cfg.get("conf") and args.conf_kind == "smooth" else "") + ("" if single_pass and not speculative else ":two-pass")      # (the speculative call runs the two-pass scatter kernel)
+                tkey = ("mip360conf" if multi or workload == "mip360conf_smooth" else workload) + (":bernoulli" if args.mask_kind == "bernoulli" else "") + (":smooth" if cfg.get("conf") and cfg["conf_kind"] == "smooth" else "") + ("" if single_pass and not speculative else ":two-pass")      # (the speculative call runs the two-pass scatter kernel)
                 # (mip360x7 runs the mip360conf kernel scene after scene on the same kind of maps: its bytes per view)
                 rec = json.loads(tfile.read_text()).get(tkey)
                 if rec:     # PMC bytes were collected on the full workload; a launch over fewer views moves proportionally fewer
@@ -1093,7 +1177,7 @@ def main() -> None:
                 "mpoints_per_s": round(n_total / (elapsed / steps) / 1e6, 1),
                 "config": {"workload": workload, "note": cfg["note"], "views_total": total_views, "views_per_gpu": V,
                            "height": H, "width": W, "downsample_density": 1, "valid_fraction": round(n_local / (V * H * W), 4), "mask_kind": args.mask_kind,
-                           "conf_kind": args.conf_kind if cfg.get("conf") else None,
+                           "conf_kind": cfg["conf_kind"] if cfg.get("conf") else None,
                            "poses": poses_from,
                            "inputs": "+".join(k for k in ("depth", "mask", "conf", "normal", "rgb") if scene[k] is not None),
                            "outputs": "xyz f32" + (" + normal f32" if cfg["normal"] else "") + (" + rgb u8" if cfg["rgb"] else "")
@@ -1242,7 +1326,7 @@ def main() -> None:
     # one-GPU workload; the driver's N > 1 runs measure the scaling curve of the main workload)
     subs = []
     if args.sub == "auto":
-        subs = ["garden185", "roofline12mp", "mip360conf"] if (world == 1 and not explicit and not use_dist) else []
+        subs = ["garden185", "roofline12mp", "mip360conf", "mip360conf_smooth"] if (world == 1 and not explicit and not use_dist) else []
     elif args.sub != "none":
         subs = [x for x in args.sub.split(",") if x.strip()]
     for name in subs:
@@ -1276,6 +1360,13 @@ def main() -> None:
                 failed = failed or not fr["equals_refine_apply_then_plain"]
                 if rank == 0:
                     rec["fused_refine"] = fr
+                try:
+                    pr = pipeline_record(device)
+                    pr["densify_share_of_loop"] = round(fr["us_per_view"] * 1e-6 / (pr["loop_wall_ms_per_view"] * 1e-3), 4)
+                except Exception as e:      # noqa: BLE001  (no writable temporary directory ...: the line goes on without it)
+                    pr = {"error": f"{type(e).__name__}: {e}"[:300]}
+                if rank == 0:
+                    line["pipeline"] = pr
             sst.clear()
             del sst
             gc.collect()

@@ -64,10 +64,11 @@ class ProcessingConfig:
     io_threads: int = field(default_factory=lambda: _default_io_threads())
     """Host threads that decode images / read cached maps ahead of the GPU (0 = inline, like the reference).  Default: the
     cores this process may use minus two, between 2 and 16 -- image decoding is what bounds a scan once the maps are cached."""
-    views_per_launch: int = 8
+    views_per_launch: int = 16
     """Consecutive equally sized views densified by ONE kernel launch at full density (downsample_density = 1): their fits are
     enqueued back to back and read in one go, their maps stacked on the device, one ViewBatch / dd_unproject_compact with a
-    transfer curve per view.  1 = a launch per view (rounds 1-2).  Same model either way."""
+    transfer curve per view.  1 = a launch per view (rounds 1-2).  Same model either way.  (16: a launch of 2700 tiles fills the
+    256 CUs five times over -- 0.72 of the roofline in a chain of such calls where 8 views reach 0.68, profiles/r05_streaming_*.txt.)"""
     exclusive_gpu: Optional[bool] = None
     """This process's densify stream has its GPU to itself -- the reference is ONE process that owns its GPU, and scripts/run_batch.py
     under torchrun is one process per GPU: the single-pass kernel then takes its tiles by workgroup index and small appends are
@@ -165,8 +166,9 @@ def _votes_single(cloud, cached, depth_threshold):
     return votes
 
 
-def main(config: ScriptConfig) -> dict:
-    """Densify one COLMAP scan; returns a small report (counts, timings).
+def main(config: ScriptConfig, _loop_only: bool = False) -> dict:
+    """Densify one COLMAP scan; returns a small report (counts, timings).  (``_loop_only``: stop behind the image loop and the
+    fused cloud -- no filter, no model written: what ``bench.py`` times as the path's own share of a scan.)
 
     Under ``torchrun`` (one process per GPU) with ``processing.shard_views`` the scan's views are sharded
     contiguously over the ranks (``distributed.shard_views``): every rank refines and densifies its views into
@@ -180,12 +182,12 @@ def main(config: ScriptConfig) -> dict:
     device = torch.device("cuda", torch.cuda.current_device())
     say = print if ranks.rank == 0 else (lambda *a, **k: None)
     try:
-        return _run(config, ranks, device, say, t_total)
+        return _run(config, ranks, device, say, t_total, _loop_only)
     finally:
         ranks.close()
 
 
-def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> dict:
+def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float, loop_only: bool = False) -> dict:
     t0 = time.time()
     say(f"Loading depth source ({config.moge.cache_dir or config.moge.checkpoint})...")
     source = make_depth_source(config.moge.checkpoint, config.moge.cache_dir, device)
@@ -409,6 +411,9 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float) -> di
     cloud = builder.finish()
     n_before = ranks.total(len(cloud), device)
     say(f"number of dense points: {n_before}")                                  # :244-245
+    if loop_only:
+        report["dense_points"] = n_before
+        return report
     if n_before == 0:
         say("No dense points were generated. Skipping save.")
         return report
