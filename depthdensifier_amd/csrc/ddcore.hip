@@ -1156,7 +1156,8 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
     constexpr int VEC = 16 / (int)sizeof(DepthT), CH = PXT / VEC, CSPAN = 64 * VEC;
     // rows written past the L2 (non-temporal) in the small-batch instantiation: what a kernel leaves dirty in the L2s is written
     // back at its end, and a chain of small calls pays that once per call (1 us of 27 per one-view call, profiles/r05_streaming_*.txt)
-    constexpr bool NT_ROWS = DD_NT_STORE != 0 || PXT != L_PXT;
+    // (... and in the fused refine instantiation, whose L2 also serves the halo's re-reads: 17.1 -> 17.0 us per view, profiles/r06_fused_refine.txt)
+    constexpr bool NT_ROWS = DD_NT_STORE != 0 || PXT != L_PXT || REFINE;
     // the point list: depth (float) + 16-bit pixel per listed point.  One raw block, because the fused refine stage uses
     // the same bytes, BEFORE the list exists, for the transformed values of the tile and its halo (up to LT*6/4 floats)
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[LT * 6];
@@ -1691,6 +1692,9 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
         prep(0, pa);
     }
     set_row_bases();
+#ifdef DD_X_PRIO      // experiment: the row phase's waves issue in front of the co-resident workgroup's compute phases
+    if constexpr (REFINE) __builtin_amdgcn_s_setprio(DD_X_PRIO);
+#endif
     if (a.align_runs) hrot = (int)((0ll - excl) & 31ll);
 #if DD_GATHER_DEPTH == 3
     // the gathers of TWO sweeps in flight behind the sweep that is being stored (three point sets taking turns)
