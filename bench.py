@@ -367,7 +367,14 @@ def strong_scaling_record(args, dd, D, dist, use_dist, rank, world, device, fenc
         if need > 0.9 * free:
             rec[key] = {"skipped": f"replicated cloud of {need / 1e9:.1f} GB does not fit the free HBM ({free / 1e9:.1f} GB)"}
             continue
-        if record == "rows":
+        placed_report = None
+        if record == "rows" and os.environ.get("DD_FUSE_PLACEMENT") == "probed":
+            # the global arrays RCCL receives into, placed by the zone arena (classes of HBM) instead of as the allocator returns them:
+            # what distributed.fuse_replicated's comment says should work and no one-GPU box could show (tools/run_multi_gpu.sh runs it)
+            from depthdensifier_amd import placement as _plf
+            p_xyz, p_nrm, p_rgb, placed_report = _plf.place_outputs(n_total, colors=True, normals=True, device=device, mode="probed")
+            bufs = {"points": p_xyz, "normals": p_nrm, "colors": p_rgb}
+        elif record == "rows":
             bufs = {"points": torch.empty((n_total, 3), dtype=torch.float32, device=device),
                     "normals": torch.empty((n_total, 3), dtype=torch.float32, device=device),
                     "colors": torch.empty((n_total, 3), dtype=torch.uint8, device=device)}
@@ -401,6 +408,8 @@ def strong_scaling_record(args, dd, D, dist, use_dist, rank, world, device, fenc
                     "what": "count pass + count all-gather + fused kernel writing at final global rows, per-chunk grouped send/recv "
                             "in place overlapped with the next chunk's kernel" if world > 1 else
                             "N = 1: count pass + fused kernel per chunk (no wire)"}
+        if placed_report is not None:
+            rec[key]["buffers_placement"] = placed_report.mode
         del bufs
         torch.cuda.empty_cache()
     return rec

@@ -324,9 +324,14 @@ def fuse_replicated(batch, num_views_total: int, *, normals: bool = True, colors
     base = 0 if receives else own_lo                                   # a pure sender holds only its own rows
     cap = total if receives else own_hi - own_lo
     rows = record == "rows"
+    # Where the global arrays live.  RCCL's send / recv copy between the user's buffer and RCCL's own (IPC-shared) FIFO buffers with
+    # kernels of the local GPU, so a user buffer needs no export of its own -- arrays placed by the zone arena (virtual-memory API,
+    # exportable as shareable handles but not through hipIpcGetMemHandle: profiles/r05_ubench_vmm_export.txt) should do.  That could
+    # not be run on this build's one-GPU boxes (RCCL refuses two ranks on one device), so the default stays the plain allocation that
+    # is known to work; DD_FUSE_PLACEMENT=probed places them (tools/run_multi_gpu.sh times both on the first multi-GPU box).
     builder = CloudBuilder(cap, points=rows, normals=normals and rows, colors=colors and rows, pixel_index=pixel_index,
                            view_index=view_index, packed=not rows, buffers=buffers, start=own_lo - base, device=batch.device,
-                           placement="first")      # these arrays go over RCCL: plain allocations (arena memory is not IPC-exportable)
+                           placement=os.environ.get("DD_FUSE_PLACEMENT", "first"))
     # the counts are KNOWN here (plan_fuse): nothing to guess -- and a guess that missed would scatter rows beyond this rank's
     # [own_lo, own_hi) into regions of the shared buffers that RCCL is receiving the peers' rows into
     builder.speculate_dense = False

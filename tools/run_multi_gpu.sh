@@ -60,6 +60,7 @@ N1=$(python3 -c "import json; print(json.load(open('$OUT/${TAG}_scale_n1.json'))
 NS=""; for n in 2 4 8; do [ "$n" -le "$NGPU" ] && NS="$NS $n"; done
 for n in $NS; do
   line "n${n}_default" "$n" -- --n1-strong-mpix "$N1" $SMALL
+  line "n${n}_placed" "$n" "DD_FUSE_PLACEMENT=probed" -- --n1-strong-mpix "$N1" --steps 5 --warmup 2 --alloc-rounds 0 $SMALL     # the gathered legs with arena-placed global arrays
   for chunks in 1 5 10; do for ag in p2p broadcast; do for dst in all 0; do
     [ "$ag" = broadcast ] && [ "$dst" = 0 ] && continue        # the broadcast flavour replicates by construction
     line "n${n}_c${chunks}_${ag}_dst${dst}" "$n" "DD_ALLGATHERV=$ag" -- --steps 5 --warmup 2 --chunks "$chunks" --gather-dst "$dst" --n1-strong-mpix "$N1" --alloc-rounds 0 $SMALL
