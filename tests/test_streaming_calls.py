@@ -463,3 +463,27 @@ def test_random_chains_of_appends_write_the_one_batch_cloud(dd, seed):
                 b.join()
         _equal(b.finish(), want)
     assert b.healed == 0 and b.dense_misses == 0
+
+
+def test_the_ungated_chain_limit_follows_the_device(dd):
+    """how many workgroups a chained call may have before a gate kernel precedes it is three quarters of the slots the
+    device offers that kernel (occupancy x compute units, from the runtime) -- not a constant: 384 on a whole MI355X, and a call one
+    tile larger is gated (dd_debug_plan), one at the limit is not."""
+    import ctypes as C
+    import torch
+    from depthdensifier_amd import _lib
+    limit = _lib.lib.dd_chain_workgroup_limit()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert limit > 0 and limit % 3 == 0 and limit * 4 // 3 % cus == 0, (limit, cus)          # 3/4 of (a whole number of workgroups per CU) x CUs
+    if cus == 256:
+        assert limit == 384
+    out = (C.c_int32 * 8)()
+    word = torch.zeros(1, dtype=torch.int64, device="cuda")
+
+    def gate(tiles):                                  # a one-view batch of `tiles` 6144-pixel tiles, chained
+        px = tiles * 6144
+        b = _lib.DDViewBatch(num_views=1, height=1, width=px, stride=1, depth=0x1000, params=0x2000, depth_dtype=_lib.DD_F32,
+                             flags=_lib.DD_VALID_DEPTH_POSITIVE, chain=word.data_ptr(), chain_seq=0)
+        assert _lib.lib.dd_debug_plan(C.byref(b), out) == 0
+        return out[6]
+    assert gate(limit - 1) == 0 and gate(limit) == 1           # (+ 1 workgroup: the scan)

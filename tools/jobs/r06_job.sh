@@ -3,6 +3,7 @@
 #   soak <launches> <reps>  the three-rank rehearsal (torchrun, gloo, p2p, views 2 / 4 in turn), <reps> executions per launch
 #   bench [bench args]      python3 bench.py ... -> gpurun_out/r06_bench.json
 #   py <script> [args]      python3 <script> ... -> gpurun_out/r06_<script name>.log
+#   sweeps                  the seeded parity sweeps at soak sizes -> gpurun_out/r06_soak.txt
 #   pmc_refine              SQ counters (two passes) of the fused refine kernel beside the plain kernel -> gpurun_out/r06_refine_pmc.json
 #   prof <tag> <cmd...>     rocprofv3 --kernel-trace --stats of a python3 command -> gpurun_out/r06_prof_<tag>_*.csv
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; what=$1; shift
@@ -32,6 +33,16 @@ bench)
 py)
   s=$1; shift; timeout -k 10 ${PY_SECONDS:-600} python3 $s "$@" > gpurun_out/r06_$(basename $s .py).log 2>&1; rc=$?
   tail -n ${TAIL:-40} gpurun_out/r06_$(basename $s .py).log; exit $rc ;;
+sweeps)
+  out=gpurun_out/r06_soak.txt; : > $out
+  run() { local envs="$1"; shift; local t0=$(date +%s); env $envs timeout -k 10 900 python3 -m pytest "$@" -x -q -m gpu > /tmp/sweep.log 2>&1; local rc=$?
+          printf "%-44s %s: %s\n" "$envs" "$*" "$(tail -n 1 /tmp/sweep.log)" | tee -a $out; [ $rc -eq 0 ] || { tail -n 30 /tmp/sweep.log; exit 1; }; }
+  run "DD_APPLY_SEEDS=1500 DD_REFINE_SEEDS=3000" tests/test_refiner.py
+  run "DD_RANDOM_SEEDS=12000" tests/test_gpu_random.py
+  run "DD_RANDOM_SEEDS=1500 DD_RANDOM_SCALE=6" tests/test_gpu_random.py
+  run "DD_STREAM_SEEDS=2000" tests/test_streaming_calls.py -k random_chains
+  run "DD_VOTE_SEEDS=400" tests/test_filter.py
+  ;;
 pmc_refine)
   export TMPDIR=/tmp DD_EXCLUSIVE_GPU=1
   i=0
