@@ -223,7 +223,7 @@ class CachedSource(DepthSource):
             raise ValueError(f"{f}: depth is {maps['depth'].shape}, image at processing resolution is {(h, w)}")
         return maps
 
-    def upload_staged(self, maps: dict, rgb_u8: np.ndarray, slot: StagingSlot, device: torch.device, copy_stream=None, fork_event=None):
+    def upload_staged(self, maps: dict, rgb_u8: np.ndarray, slot: StagingSlot, device: torch.device, copy_stream=None, fork_event=None, timing=None):
         """The maps ``prepare(..., staging=slot)`` left in the slot and the image (``slot.put("rgb", ...)``) to the device with ONE native
         call (``dd_upload_async``: the copies and the event that frees the slot) -> (``infer``'s dictionary, the image on the device).
         ``copy_stream`` (with ``fork_event``, an event of the caller's): the copies run on that stream -- beside the kernels of the
@@ -242,8 +242,14 @@ class CachedSource(DepthSource):
         ev = slot.event_handle(stream)
         if copy_stream is not None:
             lib.dd_stream_fork(fork_event.cuda_event, stream.cuda_stream, copy_stream.cuda_stream)
+        if timing is not None:                        # (a measurement run: how long the copies themselves take on their stream)
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record(copy_stream or stream)
         if lib.dd_upload_async(n, src, dst, size, ev, (copy_stream or stream).cuda_stream) < 0:
             raise RuntimeError(f"libddcore: {lib.dd_ingest_last_error().decode('utf-8', 'replace')}")
+        if timing is not None:
+            t1.record(copy_stream or stream)
+            timing.append((t0, t1))
         if copy_stream is not None:
             lib.dd_stream_wait(stream.cuda_stream, ev)
         slot.released_natively()

@@ -277,6 +277,7 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float, loop_
     pool = ThreadPoolExecutor(max_workers=config.processing.io_threads) if config.processing.io_threads > 0 and feeder is None else None
     # the uploads of staged views run on a stream of their own, beside the kernels of the views before them
     copy_stream, fork_event = None, None
+    upload_events = [] if os.environ.get("DD_PIPELINE_TRACE") == "1" else None      # measurement runs: the copies timed on their stream
     if config.processing.io_threads > 0 and hasattr(source, "upload_staged") and os.environ.get("DD_COPY_STREAM", "1") == "1":
         copy_stream, fork_event = torch.cuda.Stream(device), torch.cuda.Event()
         fork_event.record(torch.cuda.current_stream(device))                   # (creates the underlying event)
@@ -306,7 +307,7 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float, loop_
         staged = slot is not None and prepared is not None and hasattr(source, "upload_staged") and "rgb" in slot._bufs and rgb is not None \
             and all(a.dtype.name in ("float32", "float16", "uint8", "bool") for a in prepared.values())
         if staged:
-            maps, rgb_dev = source.upload_staged(prepared, rgb, slot, device, copy_stream, fork_event)    # :161-168 + :215: maps and colours up, slot freed
+            maps, rgb_dev = source.upload_staged(prepared, rgb, slot, device, copy_stream, fork_event, upload_events)    # :161-168 + :215: maps and colours up, slot freed
             tx = t3 = lap("upload_maps", t2)
         else:
             maps = source.infer(image.name, rgb, device, prepared=prepared)         # :161-168, stays on device
@@ -411,6 +412,9 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float, loop_
     cloud = builder.finish()
     n_before = ranks.total(len(cloud), device)
     say(f"number of dense points: {n_before}")                                  # :244-245
+    if upload_events:
+        torch.cuda.synchronize(device)
+        report["upload_seconds_on_the_copy_stream"] = sum(a.elapsed_time(b) for a, b in upload_events) * 1e-3
     if loop_only:
         report["dense_points"] = n_before
         return report

@@ -58,5 +58,7 @@ with tempfile.TemporaryDirectory() as tmp:
                 "loop_wall_ms_per_view": round(rep_["loop_seconds"] / rep_["views"] * 1e3, 3),
                 "images": "jpg" if JPG else "png", "cache": "npy+rgb" if cache.endswith("rgb") else "npy" if cache.endswith("npy") else "npz",
                 "dense_points": rep_["dense_points"], "removed": rep_["removed"], "seconds": t,
+                "upload_ms_per_view_on_the_copy_stream": None if "upload_seconds_on_the_copy_stream" not in rep_ else round(rep_["upload_seconds_on_the_copy_stream"] / rep_["views"] * 1e3, 3),
+                "copy_engine_busy_fraction_of_the_loop": None if "upload_seconds_on_the_copy_stream" not in rep_ else round(rep_["upload_seconds_on_the_copy_stream"] / rep_["loop_seconds"], 3),
                 "loop_detail_us_per_view": {k: round(v / rep_["views"] * 1e6, 1) for k, v in rep_["loop_detail"].items()}}
         print(json.dumps(line), flush=True)
