@@ -1199,6 +1199,18 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
             t -= 1u;
         }
         if (t >= a.num_tiles) return;          // (never: the grid is num_tiles workgroups)
+#ifdef DD_REFINE_XCD_RUN
+        // experiment: runs of DD_REFINE_XCD_RUN consecutive tiles on one XCD (workgroup b runs on XCD b mod 8), so that the halo rows two
+        // neighbouring tiles both read come out of that XCD's L2 the second time (profiles/r06_fused_refine.txt: the halo's re-reads
+        // reach the HBM today, 1.6 B/px).  A tile then waits for up to 8 (R - 1) workgroups dispatched behind it.
+        if constexpr (REFINE) {
+            constexpr unsigned R = DD_REFINE_XCD_RUN, BLK = 8u * R;
+            if (a.static_tiles && a.scan_service && t < a.num_tiles - a.num_tiles % BLK) {
+                const unsigned blk = t / BLK, j = t % BLK, x = (j + 1u) & 7u, i = j >> 3;      // (tile workgroups start at blockIdx 1: XCD (j + 1) mod 8)
+                t = blk * BLK + x * R + i;
+            }
+        }
+#endif
     } else {
 #if DD_XCD_SWIZZLE
         {   // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous range of tiles

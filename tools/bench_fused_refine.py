@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser(); ap.add_argument("--views", type=int, default=64)
 ap.add_argument("--tuning", type=lambda x: int(x, 0), default=0, help="variant word of the fused batch (tests/lab_bits.py: a product tuning + experiment switches of include/ddcore_lab.h)")
 ap.add_argument("--variants", nargs="*", default=[], help="experiment builds of csrc/ddcore.hip timed on the fused batch, interleaved with the product library: tag:-Dflag,-Dflag (tools/ab_builds.build); tags that start with x_ may compute something else")
 ap.add_argument("--rounds", type=int, default=7)
+ap.add_argument("--refined-placements", action="store_true", help="time the fused launch with the refined map (the filter's cache) allocated plainly and through the zone arena, rotated from class 0 / 1 / 2")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 cfg = dict(bench.WORKLOADS["garden185"]); cfg["V"] = a.views
@@ -92,3 +93,24 @@ if a.variants:
     for tag, _ in libs:
         t = sorted(times[tag])
         print(f"{tag:<28s} median {t[len(t) // 2] / V * 1e3:6.2f} us per view   min {t[0] / V * 1e3:6.2f}   ({V} views, kernel alone through the C ABI)")
+
+if a.refined_placements:
+    from depthdensifier_amd import placement as PL
+    print("placement of the cloud:", None if b.placement is None else (b.placement.mode, b.placement.classes))
+    outs = {"plain": torch.empty((V, H, W), dtype=torch.float32, device=dev)}
+    for ph in (0, 1, 2):
+        t, rep = PL.place_arrays({"refined": ((V, H, W), torch.float32, PL.rotated(ph))}, dev, "probed")
+        outs[f"rotated({ph})"] = t["refined"]
+        print(f"rotated({ph}):", rep.mode, rep.classes)
+    batches = {k: dd.ViewBatch(scene["depth"], params, E, mask=scene["mask"], normal=scene["normal"], rgb=scene["rgb"], device=dev,
+                               refine=[(kx, ky, False)] * V, refined_out=o) for k, o in outs.items()}
+    times = {k: [] for k in batches}
+    for r in range(a.rounds + 1):
+        for k, fb in batches.items():
+            b.reset(); b.append(fb)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            b.reset(); e0.record(); b.append(fb); e1.record(); torch.cuda.synchronize()
+            if r: times[k].append(e0.elapsed_time(e1))
+    for k, t in times.items():
+        t = sorted(t)
+        print(f"refined map {k:<12s} median {t[len(t) // 2] / V * 1e3:6.2f} us per view   min {t[0] / V * 1e3:6.2f}")

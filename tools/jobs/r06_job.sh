@@ -4,6 +4,8 @@
 #   bench [bench args]      python3 bench.py ... -> gpurun_out/r06_bench.json
 #   py <script> [args]      python3 <script> ... -> gpurun_out/r06_<script name>.log
 #   sweeps                  the seeded parity sweeps at soak sizes -> gpurun_out/r06_soak.txt
+#   driver_cmd [runs]       the driver's bench command under rocprofv3 --kernel-trace --stats in fresh processes -> gpurun_out/r06_driver_cmd/
+#   traffic_refine          FETCH_SIZE / WRITE_SIZE (separate passes) of the fused refine kernel -> gpurun_out/r06_traffic_refine.json
 #   pmc_refine              SQ counters (two passes) of the fused refine kernel beside the plain kernel -> gpurun_out/r06_refine_pmc.json
 #   prof <tag> <cmd...>     rocprofv3 --kernel-trace --stats of a python3 command -> gpurun_out/r06_prof_<tag>_*.csv
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; what=$1; shift
@@ -42,6 +44,35 @@ sweeps)
   run "DD_RANDOM_SEEDS=1500 DD_RANDOM_SCALE=6" tests/test_gpu_random.py
   run "DD_STREAM_SEEDS=2000" tests/test_streaming_calls.py -k random_chains
   run "DD_VOTE_SEEDS=400" tests/test_filter.py
+  ;;
+driver_cmd)
+  bash tools/profile_driver_cmd.sh gpurun_out/r06_driver_cmd r06_driver_cmd ${1:-2} ;;
+traffic_refine)
+  export TMPDIR=/tmp DD_EXCLUSIVE_GPU=1
+  for c in FETCH_SIZE WRITE_SIZE; do rm -rf /tmp/tr_$c
+    (cd /tmp && timeout -k 10 300 rocprofv3 --pmc $c --kernel-include-regex "compact_lean" --kernel-trace --output-format csv -d /tmp/tr_$c -- python3 "$GRAFT_REPO_ROOT/tools/bench_fused_refine.py" --views 185 > "$GRAFT_REPO_ROOT/gpurun_out/r06_traffic_refine_$c.log" 2>&1) || { echo "$c failed"; tail -5 gpurun_out/r06_traffic_refine_$c.log; exit 1; }
+  done
+  python3 - <<'P'
+import csv, glob, json
+from collections import defaultdict
+acc = defaultdict(lambda: defaultdict(list))
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(f"/tmp/tr_{c}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if "compact_lean" not in k: continue
+            tag = "fused_refine" if ("true, 16>" in k or "ELb1ELi16" in k) else "plain"
+            acc[tag][r["Counter_Name"]].append(float(r["Counter_Value"]))
+res = {}
+px = 185 * 1080 * 1920
+for t, d in acc.items():
+    fetch = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]); write = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
+    rd, wr = fetch * 1024 * 2, write * 1024          # gfx950: FETCH_SIZE tallies 128-B read requests at 64 B (MI355X_MICROARCH.md; verified on count_lean in round 1)
+    res[t] = {"FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "read_bytes_corrected": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr,
+              "bytes_per_pixel": round((rd + wr) / px, 2), "read_per_pixel": round(rd / px, 2), "write_per_pixel": round(wr / px, 2), "dispatches": [len(d["FETCH_SIZE"]), len(d["WRITE_SIZE"])]}
+json.dump(res, open("gpurun_out/r06_traffic_refine.json", "w"), indent=1)
+print(json.dumps(res, indent=1))
+P
   ;;
 pmc_refine)
   export TMPDIR=/tmp DD_EXCLUSIVE_GPU=1
