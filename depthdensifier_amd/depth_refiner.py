@@ -299,14 +299,20 @@ class DepthRefiner:
     def begin_refine(self, depth_map: ArrayLike, normal_map: Optional[ArrayLike], points3D: ArrayLike,
                      cam_from_world: ArrayLike, K: ArrayLike, mask: Optional[ArrayLike] = None,
                      return_tensor: bool = False, generator: Optional[torch.Generator] = None, fit_only: bool = False,
-                     **kwargs) -> dict:
+                     working_out: Optional[torch.Tensor] = None, **kwargs) -> dict:
         """First half of ``refine_depth``: inputs to the device and, on a GPU, the correspondence fit enqueued (no host
-        synchronisation).  Returns the handle ``finish_refine`` takes."""
+        synchronisation).  Returns the handle ``finish_refine`` takes.  ``working_out``: a device tensor of the depth map's shape in the
+        refiner's working precision (``self.dtype``) to hold the map in that precision (the pipeline's resident stacks: the
+        conversion then writes where the densify kernel will read, nothing is allocated or stacked later)."""
         if self.verbose > 1:
             print(f"[DepthRefiner] Input depth shape: {tuple(depth_map.shape)}")
             print(f"[DepthRefiner] COLMAP points: {len(points3D)}")
         t_ = time.perf_counter()
-        depth = self._to(depth_map)
+        if working_out is not None and isinstance(depth_map, torch.Tensor) and depth_map.is_cuda and working_out.dtype == self.dtype \
+                and tuple(working_out.shape) == tuple(depth_map.shape):
+            depth = working_out if working_out.data_ptr() == depth_map.data_ptr() else working_out.copy_(depth_map)
+        else:
+            depth = self._to(depth_map)
         t_ = self._lap("begin_refine.depth_to_working_precision", t_)
         gpu_fit = depth.is_cuda and depth.dim() == 2 and min(depth.shape) >= 2
         # (on the GPU path a missing mask stays None -- the kernels test depth > 0 themselves -- and is only made when a tensor branch asks)

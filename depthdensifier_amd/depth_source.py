@@ -223,24 +223,31 @@ class CachedSource(DepthSource):
             raise ValueError(f"{f}: depth is {maps['depth'].shape}, image at processing resolution is {(h, w)}")
         return maps
 
-    def upload_staged(self, maps: dict, rgb_u8: np.ndarray, slot: StagingSlot, device: torch.device, copy_stream=None, fork_event=None, timing=None):
+    def upload_staged(self, maps: dict, rgb_u8: np.ndarray, slot: StagingSlot, device: torch.device, copy_stream=None, fork_event=None, timing=None,
+                      dest: Optional[dict] = None):
         """The maps ``prepare(..., staging=slot)`` left in the slot and the image (``slot.put("rgb", ...)``) to the device with ONE native
         call (``dd_upload_async``: the copies and the event that frees the slot) -> (``infer``'s dictionary, the image on the device).
         ``copy_stream`` (with ``fork_event``, an event of the caller's): the copies run on that stream -- beside the kernels of the
         views before, not in line with them (41 MB per 1080p view: 0.76 ms of PCIe against 0.03 ms of kernels) -- ordered behind what the
-        current stream has enqueued so far (the destination blocks may have had readers there) and in front of what it enqueues next."""
+        current stream has enqueued so far (the destination blocks may have had readers there) and in front of what it enqueues next.
+        ``dest``: device tensors of the caller's to copy INTO (keys as ``maps`` + ``"rgb"``; the pipeline's resident group stacks) --
+        nothing is allocated, and with ``fork_event=None`` the copy stream waits for nothing: ordering against earlier readers of
+        those tensors is the caller's."""
         import ctypes as C
         from ._lib import lib
         keys = [k for k in ("depth", "mask", "normal") if k in maps]
-        out = {k: torch.empty(maps[k].shape, dtype=_TORCH_OF[maps[k].dtype.name], device=device) for k in keys}
-        rgb_dev = torch.empty(rgb_u8.shape, dtype=torch.uint8, device=device)
+        if dest is not None:
+            out, rgb_dev = {k: dest[k] for k in keys}, dest["rgb"]
+        else:
+            out = {k: torch.empty(maps[k].shape, dtype=_TORCH_OF[maps[k].dtype.name], device=device) for k in keys}
+            rgb_dev = torch.empty(rgb_u8.shape, dtype=torch.uint8, device=device)
         n = len(keys) + 1
         src = (C.c_void_p * n)(*[slot.pointer(k) for k in keys], slot.pointer("rgb"))
         dst = (C.c_void_p * n)(*[out[k].data_ptr() for k in keys], rgb_dev.data_ptr())
         size = (C.c_int64 * n)(*[maps[k].nbytes for k in keys], rgb_u8.nbytes)
         stream = torch.cuda.current_stream(device)
         ev = slot.event_handle(stream)
-        if copy_stream is not None:
+        if copy_stream is not None and fork_event is not None:
             lib.dd_stream_fork(fork_event.cuda_event, stream.cuda_stream, copy_stream.cuda_stream)
         if timing is not None:                        # (a measurement run: how long the copies themselves take on their stream)
             t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

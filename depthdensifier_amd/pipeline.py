@@ -142,6 +142,42 @@ class _Ranks:
             dist.destroy_process_group()
 
 
+class _GroupRing:
+    """Device-resident stacks for the views of ``R`` launch groups of ``K`` views each (round 6): a view's maps are uploaded -- on the copy
+    stream, waiting for nothing but the densify launch that last read the stack -- straight to where the group's ONE ViewBatch will read
+    them: no per-view allocations, no torch.stack of 41 MB per view, and no fork of the copy stream behind every view's fit (which put
+    0.4 ms of gaps between the copies of consecutive views: profiles/r06_bench_pipeline.txt).  The masks and the refined maps (the
+    filter's cache, scripts/test.py:197-201) live in two arrays of their own for the whole scan."""
+
+    def __init__(self, n_views: int, K: int, H: int, W: int, device, work_dtype, R: int = 3):
+        self.K, self.R, self.H, self.W, self.device, self.work_dtype = K, R, H, W, device, work_dtype
+        self.depth: list = [None] * R                # (K,H,W) in the cache's dtype, allocated when the first view says which
+        self.work: list = [None] * R                 # (K,H,W) in the refiner's working precision (the same tensor when the dtypes agree)
+        self.normal = [torch.empty((K, H, W, 3), dtype=torch.float32, device=device) for _ in range(R)]
+        self.rgb = [torch.empty((K, H, W, 3), dtype=torch.uint8, device=device) for _ in range(R)]
+        self.mask_all = torch.empty((n_views, H, W), dtype=torch.bool, device=device)
+        self.refined_all = torch.empty((n_views, H, W), dtype=torch.float32, device=device)
+        self.events: list = [None] * R               # behind the densify launch that last read stack r (compute stream)
+        self.checks: list = [None] * R               # the builder's check behind it: what it covers is final, its maps may be overwritten
+
+    def place(self, k: int, prepared: dict, rgb) -> Optional[dict]:
+        """Where view ``k``'s arrays go, or None if they are not what the ring holds (another size or element type: the caller's other way)."""
+        g, j = divmod(k, self.K)
+        r = g % self.R
+        d = prepared.get("depth")
+        if d is None or tuple(d.shape) != (self.H, self.W) or tuple(rgb.shape) != (self.H, self.W, 3) or "normal" not in prepared or "mask" not in prepared:
+            return None
+        dt = torch.float16 if d.dtype.name == "float16" else torch.float32 if d.dtype.name == "float32" else None
+        if dt is None or prepared["mask"].dtype.name not in ("bool", "uint8") or prepared["normal"].dtype.name != "float32":
+            return None
+        if self.depth[r] is None:
+            self.depth[r] = torch.empty((self.K, self.H, self.W), dtype=dt, device=self.device)
+            self.work[r] = self.depth[r] if dt == self.work_dtype else torch.empty((self.K, self.H, self.W), dtype=self.work_dtype, device=self.device)
+        if self.depth[r].dtype != dt:
+            return None
+        return dict(r=r, j=j, depth=self.depth[r][j], work=self.work[r][j], mask=self.mask_all[k], normal=self.normal[r][j], rgb=self.rgb[r][j])
+
+
 def _exclusive_gpu(processing: "ProcessingConfig") -> bool:
     """``ProcessingConfig.exclusive_gpu`` resolved: an explicit choice stands; otherwise on, unless the environment says
     ``DD_EXCLUSIVE_GPU=0`` or more local ranks than GPUs were started (they share a card)."""
@@ -281,6 +317,13 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float, loop_
     if config.processing.io_threads > 0 and hasattr(source, "upload_staged") and os.environ.get("DD_COPY_STREAM", "1") == "1":
         copy_stream, fork_event = torch.cuda.Stream(device), torch.cuda.Event()
         fork_event.record(torch.cuda.current_stream(device))                   # (creates the underlying event)
+    # Full density, every view of one size, staged uploads: the views' maps go straight into resident stacks (one per launch group)
+    K_LAUNCH = 1 if verbose else max(1, int(config.processing.views_per_launch))
+    ring = None
+    if copy_stream is not None and s == 1 and not verbose and mine and len(set(sizes.values())) == 1 and os.environ.get("DD_GROUP_RING", "1") == "1":
+        pw0, ph0 = next(iter(sizes.values()))
+        if pw0 <= 3071:
+            ring = _GroupRing(len(mine), K_LAUNCH, ph0, pw0, device, refiner.dtype)
     from .depth_source import StagingSlot
     slots = [StagingSlot() for _ in range(ahead + 2)] if pool else []
     pending: deque = deque(pool.submit(fetch, im, slots[j % len(slots)]) for j, im in enumerate(mine[:ahead])) if pool else deque()
@@ -306,7 +349,19 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float, loop_
         t2 = lap("wait_for_io_thread", t1)
         staged = slot is not None and prepared is not None and hasattr(source, "upload_staged") and "rgb" in slot._bufs and rgb is not None \
             and all(a.dtype.name in ("float32", "float16", "uint8", "bool") for a in prepared.values())
-        if staged:
+        spot = ring.place(k, prepared, rgb) if (ring is not None and staged) else None
+        if spot is not None:
+            r_ = spot["r"]
+            if spot["j"] == 0:                                                  # the first view of a group: the stack's last readers
+                if ring.checks[r_] is not None:
+                    ring.checks[r_].result()                                    # (long done: the batches that read the stack are final and released)
+                    ring.checks[r_] = None
+                if ring.events[r_] is not None:
+                    from ._lib import lib as _l
+                    _l.dd_stream_wait(copy_stream.cuda_stream, ring.events[r_].cuda_event)
+            maps, rgb_dev = source.upload_staged(prepared, rgb, slot, device, copy_stream, None, upload_events, dest=spot)    # :161-168 + :215
+            tx = t3 = lap("upload_maps", t2)
+        elif staged:
             maps, rgb_dev = source.upload_staged(prepared, rgb, slot, device, copy_stream, fork_event, upload_events)    # :161-168 + :215: maps and colours up, slot freed
             tx = t3 = lap("upload_maps", t2)
         else:
@@ -328,23 +383,38 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float, loop_
         fuse = s == 1 and new_w <= 3071          # full density: the densify kernel applies the transfer curve itself
         tc = lap("camera", t3)
         handle = refiner.begin_refine(depth_map=maps["depth"], normal_map=normal, points3D=pts_world, cam_from_world=E, K=K,
-                                      mask=maps["mask"], return_tensor=True, fit_only=fuse)   # :179-186, first half
+                                      mask=maps["mask"], return_tensor=True, fit_only=fuse,
+                                      working_out=None if spot is None else spot["work"])   # :179-186, first half
         t4 = lap("begin_refine", tc)
         stage["image_decode"] += t2 - t1; stage["depth_source"] += t3 - t2; stage["refine"] += t4 - t3
         # (the camera may be rescaled again by the next view before this one is finished: its intrinsics are taken now)
-        return dict(rgb=rgb_dev, maps=maps, normal=normal, E=E, K=K, pinhole=camera.pinhole_params().copy(), handle=handle)
+        return dict(rgb=rgb_dev, maps=maps, normal=normal, E=E, K=K, pinhole=camera.pinhole_params().copy(), handle=handle,
+                    spot=None if spot is None else (spot["r"], spot["j"], k))
 
     def densify_run(run: list) -> None:
         """Consecutive views whose transfer curves the kernel applies itself, all of one size: ONE ViewBatch, one launch.
         :194 "refined_depth[~moge_mask] = 0" is the kernels' validity rule (mask AND depth > 0); :203-240 densify + append.
         Raw depth -> LUT + 3x3 median -> validity -> unprojection in one kernel; the refined maps it writes on the way are the
         filter's cache (:197-201).  Same bits as dd_refine_apply followed by the plain densify call, view by view."""
-        st = (lambda key: torch.stack([v[key] for v in run])) if len(run) > 1 else (lambda key: run[0][key][None])
-        masks = st("mask")
-        batch = ViewBatch(st("raw"), np.stack([v["pinhole"] for v in run]), np.stack([v["E"] for v in run]), mask=masks, normal=st("normal"),
-                          rgb=st("rgb"), stride=s, view_index_base=lo + len(cached), device=device,
-                          refine=[v["curve"] for v in run], refined_out=True)
-        builder.append(batch)
+        spots = [v.get("spot") for v in run]
+        in_ring = ring is not None and all(sp is not None for sp in spots) and all(
+            spots[i][0] == spots[0][0] and spots[i][1] == spots[0][1] + i and spots[i][2] == spots[0][2] + i for i in range(len(run))) \
+            and all(v["raw"].data_ptr() == ring.work[spots[0][0]][sp[1]].data_ptr() for v, sp in zip(run, spots))
+        if in_ring:                                   # consecutive views of one resident stack: slices, nothing is copied
+            r_, j0, k0 = spots[0]
+            n_ = len(run)
+            masks = ring.mask_all[k0:k0 + n_]
+            batch = ViewBatch(ring.work[r_][j0:j0 + n_], np.stack([v["pinhole"] for v in run]), np.stack([v["E"] for v in run]), mask=masks,
+                              normal=ring.normal[r_][j0:j0 + n_], rgb=ring.rgb[r_][j0:j0 + n_], stride=s, view_index_base=lo + len(cached), device=device,
+                              refine=[v["curve"] for v in run], refined_out=ring.refined_all[k0:k0 + n_])
+            builder.append(batch)
+        else:
+            st = (lambda key: torch.stack([v[key] for v in run])) if len(run) > 1 else (lambda key: run[0][key][None])
+            masks = st("mask")
+            batch = ViewBatch(st("raw"), np.stack([v["pinhole"] for v in run]), np.stack([v["E"] for v in run]), mask=masks, normal=st("normal"),
+                              rgb=st("rgb"), stride=s, view_index_base=lo + len(cached), device=device,
+                              refine=[v["curve"] for v in run], refined_out=True)
+            builder.append(batch)
         for i, v in enumerate(run):
             cached.append(dict(depth=batch.refined[i], mask=masks[i], K=v["K"], E=v["E"]))         # :197-201
 
@@ -362,7 +432,7 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float, loop_
             maps = v["maps"]
             if res["refined_depth"] is None:
                 item = dict(raw=res["raw_depth"], curve=res["curve"], mask=maps["mask"], normal=v["normal"], rgb=v["rgb"], pinhole=v["pinhole"],
-                            E=v["E"], K=v["K"])
+                            E=v["E"], K=v["K"], spot=v.get("spot"))
                 if run and (tuple(run[0]["raw"].shape) != tuple(item["raw"].shape) or run[0]["raw"].dtype != item["raw"].dtype or len(run) >= max(1, K_LAUNCH)):
                     densify_run(run); run = []
                 run.append(item)
@@ -378,13 +448,19 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float, loop_
             cached.append(dict(depth=refined, mask=maps["mask"], K=v["K"], E=v["E"]))         # :197-201
         if run:
             densify_run(run)
+        used = {v["spot"][0] for v in group if v.get("spot") is not None}
+        for r_ in used:                                   # (a group's views share one resident stack)
+            if ring.events[r_] is None:
+                ring.events[r_] = torch.cuda.Event()
+            builder.join()
+            ring.events[r_].record(torch.cuda.current_stream(device))       # the stack may be overwritten once this has passed ...
+            ring.checks[r_] = builder.check_async()                         # ... and what read it is final (its batches released) once this is read
         t5 = lap("densify_launch", t4)
         stage["refine"] += t4 - t3; stage["densify"] += t5 - t4
 
     # Groups of `views_per_launch` views, one group of lag: while the GPU runs group g's uploads and fits, the host starts
     # group g + 1; by the time it asks for group g's fits the answers are there.  (With refiner messages on: view by view, no
     # lag, so that the log keeps its order.)
-    K_LAUNCH = 1 if verbose else max(1, int(config.processing.views_per_launch))
     lag = 0 if verbose else 1
     inflight: deque = deque()
     group: list = []
