@@ -156,9 +156,16 @@ class _GroupRing:
         self.normal = [torch.empty((K, H, W, 3), dtype=torch.float32, device=device) for _ in range(R)]
         self.rgb = [torch.empty((K, H, W, 3), dtype=torch.uint8, device=device) for _ in range(R)]
         self.mask_all = torch.empty((n_views, H, W), dtype=torch.bool, device=device)
-        self.refined_all = torch.empty((n_views, H, W), dtype=torch.float32, device=device)
+        self.n_views = n_views
+        self._refined_all = None                     # (n_views,H,W) float32, made when the first fused launch asks for it
         self.events: list = [None] * R               # behind the densify launch that last read stack r (compute stream)
         self.checks: list = [None] * R               # the builder's check behind it: what it covers is final, its maps may be overwritten
+
+    @property
+    def refined_all(self) -> torch.Tensor:
+        if self._refined_all is None:
+            self._refined_all = torch.empty((self.n_views, self.H, self.W), dtype=torch.float32, device=self.device)
+        return self._refined_all
 
     def place(self, k: int, prepared: dict, rgb) -> Optional[dict]:
         """Where view ``k``'s arrays go, or None if they are not what the ring holds (another size or element type: the caller's other way)."""
@@ -317,13 +324,12 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float, loop_
     if config.processing.io_threads > 0 and hasattr(source, "upload_staged") and os.environ.get("DD_COPY_STREAM", "1") == "1":
         copy_stream, fork_event = torch.cuda.Stream(device), torch.cuda.Event()
         fork_event.record(torch.cuda.current_stream(device))                   # (creates the underlying event)
-    # Full density, every view of one size, staged uploads: the views' maps go straight into resident stacks (one per launch group)
+    # Every view of one size, staged uploads: the views' maps go straight into resident stacks (one per launch group)
     K_LAUNCH = 1 if verbose else max(1, int(config.processing.views_per_launch))
     ring = None
-    if copy_stream is not None and s == 1 and not verbose and mine and len(set(sizes.values())) == 1 and os.environ.get("DD_GROUP_RING", "1") == "1":
+    if copy_stream is not None and not verbose and mine and len(set(sizes.values())) == 1 and os.environ.get("DD_GROUP_RING", "1") == "1":
         pw0, ph0 = next(iter(sizes.values()))
-        if pw0 <= 3071:
-            ring = _GroupRing(len(mine), K_LAUNCH, ph0, pw0, device, refiner.dtype)
+        ring = _GroupRing(len(mine), K_LAUNCH, ph0, pw0, device, refiner.dtype)
     from .depth_source import StagingSlot
     slots = [StagingSlot() for _ in range(ahead + 2)] if pool else []
     pending: deque = deque(pool.submit(fetch, im, slots[j % len(slots)]) for j, im in enumerate(mine[:ahead])) if pool else deque()
