@@ -448,6 +448,11 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float, loop_
             refined = res["refined_depth"]
             refined = refined if isinstance(refined, torch.Tensor) else torch.as_tensor(refined, device=device)
             refined = refined.float()
+            if v.get("spot") is not None:                 # an early exit of the refiner hands the INPUT map back (depth_refiner.py:259 ...): here a
+                r_ = v["spot"][0]                         # view of a resident stack, which the views of three groups on overwrite -- the filter's
+                stacks = {t.untyped_storage().data_ptr() for t in (ring.depth[r_], ring.work[r_]) if t is not None}      # cache keeps a copy
+                if refined.untyped_storage().data_ptr() in stacks:
+                    refined = refined.clone()
             batch = ViewBatch(refined, v["pinhole"][None], v["E"][None], mask=maps["mask"], normal=v["normal"], rgb=v["rgb"],
                               stride=s, view_index_base=lo + len(cached), device=device)
             builder.append(batch)

@@ -459,3 +459,44 @@ def test_cached_image_gives_the_same_model(tmp_path):
         P.main(cfg)
         outs.append((tmp_path / f"out_{with_rgb}" / "points3D.bin").read_bytes())
     assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 1000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("early_exit", (False, True))
+@pytest.mark.parametrize("density", (1, 4))
+def test_resident_stacks_give_the_same_model(tmp_path, monkeypatch, early_exit, density):
+    """Round 6: the views' maps are uploaded straight into resident group stacks that are reused every third launch group
+    (``pipeline._GroupRing``).  Ten views in groups of two -- the stacks wrap around -- must give the model of the run without them, byte
+    for byte: with the fused launch (density 1), the per-view launches (density 4), and with every view an early exit of the refiner
+    (the refiner hands its INPUT map back, a view of a stack: the filter's cache must keep a copy, not the view)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from PIL import Image as PILImage
+    from scan_factory import make_scan
+    from depthdensifier_amd import pipeline as P
+    scan, cache, _ = make_scan(tmp_path, "s", V=10, H=72, W=96, seed=9)
+    npy = scan / "cache_npy"
+    npy.mkdir()
+    for f in sorted(cache.glob("*.npz")):
+        with np.load(f) as z:
+            for k in z.files:
+                np.save(npy / f"{f.stem}_{k}.npy", z[k])
+    for img in sorted((scan / "images").iterdir()):
+        np.save(npy / f"{img.stem}_rgb.npy", np.array(PILImage.open(img).convert("RGB")))
+    outs = []
+    for ring in ("1", "0"):
+        monkeypatch.setenv("DD_GROUP_RING", ring)
+        cfg = P.ScriptConfig()
+        cfg.paths = P.PathsConfig(recon_path=scan / "sparse" / "0", image_dir=scan / "images", output_model_dir=tmp_path / f"out_{ring}")
+        cfg.moge.cache_dir = npy
+        cfg.processing.downsample_density = density
+        cfg.processing.views_per_launch = 2
+        cfg.refiner.verbose = 0
+        cfg.refiner.adaptive_correspondences = False
+        if early_exit:
+            cfg.refiner.min_correspondences = 10 ** 6          # "Too few correspondences": every view comes back unrefined
+        rep = P.main(cfg)
+        assert rep["views"] == 10
+        outs.append((tmp_path / f"out_{ring}" / "points3D.bin").read_bytes())
+    assert outs[0] == outs[1] and len(outs[0]) > 1000
