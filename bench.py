@@ -1188,6 +1188,9 @@ def main() -> None:
                            "height": H, "width": W, "downsample_density": 1, "valid_fraction": round(n_local / (V * H * W), 4), "mask_kind": args.mask_kind,
                            "conf_kind": cfg["conf_kind"] if cfg.get("conf") else None,
                            "poses": poses_from,
+                           "tiles": ("by workgroup index: exclusive_gpu, one process per GPU -- the default of the drop-in pipeline (ProcessingConfig) since round 6; "
+                                     "roofline.frac_shared_gpu_mode has the figure with tickets, the library's default for a GPU that may be shared")
+                                    if os.environ.get("DD_EXCLUSIVE_GPU") == "1" else "by ticket (a GPU that may be shared)",
                            "inputs": "+".join(k for k in ("depth", "mask", "conf", "normal", "rgb") if scene[k] is not None),
                            "outputs": "xyz f32" + (" + normal f32" if cfg["normal"] else "") + (" + rgb u8" if cfg["rgb"] else "")
                                       + (" + pixel_index i32" if args.pixel_index else ""),
