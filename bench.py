@@ -812,7 +812,7 @@ def main() -> None:
                          "the same line: garden185 (configs[1]) with its streaming chains, roofline12mp (configs[4]), mip360conf (configs[3])")
     ap.add_argument("--sub", default="auto", help="sub-records of the default line: auto (all, at N = 1 with the default workload), none, or a comma list")
     ap.add_argument("--sub-steps", type=int, default=10, help="timed steps of a sub-record (its warm-up: 3)")
-    ap.add_argument("--streaming", default="1,2,4,8", help="views per call of the streaming chains timed on garden185 ('' = skip)")
+    ap.add_argument("--streaming", default="1,2,4,8,16", help="views per call of the streaming chains timed on garden185 (16 = the pipeline's launch size; '' = skip)")
     ap.add_argument("--no-bernoulli", action="store_true", help="skip the per-pixel Bernoulli leg of the strong2000 record")
     ap.add_argument("--placement", default="probed", choices=("probed", "first"),
                     help="probed: the cloud's points / normals / colours built from different classes of HBM address ranges (the arena of "

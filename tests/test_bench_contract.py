@@ -67,7 +67,7 @@ def test_single_gpu_line():
         assert sub["value"] > 0 and 0 < sub["roofline"]["frac"] < 1 and 0 < sub["roofline"]["whole_step_frac"] < 1, sub
         assert sub["verified"]["all_ranks_ok"] and sub["roofline"]["redone"] == {"healed": 0, "dense_misses": 0}, sub
     st = line["garden185"]["streaming"]
-    assert st["all_ok"] and set(st["per_call"]) == {"1", "2", "4", "8"} and st["dependent_launch_floor_us"] > 0
+    assert st["all_ok"] and set(st["per_call"]) == {"1", "2", "4", "8", "16"} and st["dependent_launch_floor_us"] > 0
     for k, item in st["per_call"].items():
         assert item["calls"] == -(-6 // int(k)) and 0 < item["frac"] < 1 and item["verified"]["points"] > 0 and item["hip_graph_rows_equal"], item
     fr = line["garden185"]["fused_refine"]          # the pipeline's own call (raw depth -> points in one kernel), bit-equal to refine + plain call
@@ -79,7 +79,7 @@ def test_an_explicit_workload_prints_that_workload_only():
                  "--cpu-seconds", "0", "--alloc-rounds", "0"])
     _check(line, 1, 2, 1)
     assert line["scaling"] == "weak" and line["config"]["workload"] == "garden185" and "roofline12mp" not in line and "strong2000" not in line
-    assert set(line["streaming"]["per_call"]) == {"1", "2", "4", "8"} and line["fused_refine"]["equals_refine_apply_then_plain"]
+    assert set(line["streaming"]["per_call"]) == {"1", "2", "4", "8", "16"} and line["fused_refine"]["equals_refine_apply_then_plain"]
 
 
 def test_two_ranks_sharing_the_gpu():
