@@ -2249,7 +2249,7 @@ int enqueue_plan(const Plan &p, const KArgs &a, hipStream_t s) {
 }  // namespace
 
 // (for the library's other translation units: dd_refine_apply reads its two switches here)
-uint32_t dd_lab_word() { return g_lab; }
+__attribute__((visibility("hidden"))) uint32_t dd_lab_word() { return g_lab; }
 
 extern "C" {
 

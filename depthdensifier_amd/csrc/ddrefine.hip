@@ -17,7 +17,7 @@
 #include "ddcore_lab.h"
 #include "ddrefine_math.h"
 
-uint32_t dd_lab_word();      // ddcore.hip: this thread's experiment switches
+__attribute__((visibility("hidden"))) uint32_t dd_lab_word();      // ddcore.hip: this thread's experiment switches (not exported)
 
 namespace {
 

@@ -31,6 +31,13 @@ def test_header_symbols_are_exported(libmod):
     for sym in declared:
         assert getattr(handle, sym) is not None
     assert libmod.lib.dd_abi_version() == libmod.DD_ABI_VERSION
+    import shutil
+    import subprocess
+    nm = shutil.which("nm")
+    if nm:                      # ... and nothing else called dd_* leaves the library: helpers shared between its translation units stay hidden
+        out = subprocess.run([nm, "-D", "--defined-only", str(libmod.LIB_PATH)], capture_output=True, text=True).stdout
+        exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("dd_")}
+        assert exported == declared, exported ^ declared
 
 
 def test_tuning_holds_only_what_a_caller_chooses(libmod):
