@@ -553,7 +553,15 @@ def fused_refine_record(dd, cfg, scene, params, E, builder, device) -> dict:
     b3.append(plain); want = b3.finish()
     same = (len(got) == len(want) and torch.equal(got.points, want.points) and torch.equal(small.refined.view(torch.int32), refined.view(torch.int32))
             and (got.normals is None or torch.equal(got.normals, want.normals)) and (got.colors is None or torch.equal(got.colors, want.colors)))
-    return {"what": "raw depth -> points in ONE kernel (DD_REFINE: transfer curve + 3x3 median fused into the densify kernel; refined map written for the filter "
+    traffic = None
+    tfile = ROOT / "profiles" / "traffic.json"
+    if tfile.exists():
+        trec = json.loads(tfile.read_text()).get("garden185:fused_refine")
+        if trec:
+            traffic = int(trec["hbm_bytes_per_launch"] * V / trec["views"])
+    return {"traffic": traffic, "traffic_frac": None if traffic is None else round(traffic / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "traffic_source": "profiles/traffic.json[garden185:fused_refine]: PMC FETCH_SIZE / WRITE_SIZE of this kernel, separate profiling runs -- NOT measured in this run",
+            "what": "raw depth -> points in ONE kernel (DD_REFINE: transfer curve + 3x3 median fused into the densify kernel; refined map written for the filter "
                     "cache), the whole workload in one batch, 500 knots", "ms": round(med, 4), "us_per_view": round(1e3 * med / V, 2), "points": int(n),
             "algorithmic_bytes": int(alg), "frac": round(alg / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "bound": "hbm + valu (profiles/r06_fused_refine.txt: the look-ups cost 1.7 us of 17 per view, the windows 0.9, the refined map's write 1.4)",
             "equals_refine_apply_then_plain": bool(same), "views_compared": k}
