@@ -44,6 +44,11 @@ sweeps)
   run "DD_RANDOM_SEEDS=1500 DD_RANDOM_SCALE=6" tests/test_gpu_random.py
   run "DD_STREAM_SEEDS=2000" tests/test_streaming_calls.py -k random_chains
   run "DD_VOTE_SEEDS=400" tests/test_filter.py
+  if [ "${LONG:-0}" = 1 ]; then      # the protocols that depend on timing (scan service, chained calls), at length
+    run "DD_STREAM_SEEDS=6000" tests/test_streaming_calls.py -k random_chains
+    run "DD_RANDOM_SEEDS=60000" tests/test_gpu_random.py
+    run "DD_RANDOM_SEEDS=3000 DD_RANDOM_SCALE=6" tests/test_gpu_random.py
+  fi
   ;;
 driver_cmd)
   bash tools/profile_driver_cmd.sh gpurun_out/r06_driver_cmd r06_driver_cmd ${1:-2} ;;
