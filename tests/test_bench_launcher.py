@@ -62,3 +62,35 @@ def test_plain_launch_without_a_gpu_reports_the_ranks_failure():
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and r.stdout.strip() == ""
     assert "needs an MI355X" in r.stderr and "must be launched with" not in r.stderr
+
+
+def test_a_signal_to_the_launcher_reaches_every_rank(tmp_path):
+    """The driver ends a run that overstays with SIGTERM to the process it started: the ranks must go with it."""
+    import os
+    import signal
+    prog = tmp_path / "rank_program.py"
+    prog.write_text("import os, sys, time\n"
+                    "open(f'{sys.argv[1]}/pid{os.environ[\"RANK\"]}', 'w').write(str(os.getpid()))\n"
+                    "time.sleep(300)\n")
+    code = (f"import sys; sys.path.insert(0, {str(ROOT)!r}); import bench; "
+            f"sys.exit(bench.launch_ranks(2, [{str(prog)!r}, {str(tmp_path)!r}], grace_s=1.0))")
+    p = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    deadline = time.monotonic() + 60
+    while time.monotonic() < deadline and not all((tmp_path / f"pid{k}").exists() and (tmp_path / f"pid{k}").read_text() for k in range(2)):
+        time.sleep(0.1)
+    pids = [int((tmp_path / f"pid{k}").read_text()) for k in range(2)]
+    p.send_signal(signal.SIGTERM)
+    try:
+        p.communicate(timeout=60)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        raise
+    assert p.returncode != 0
+    time.sleep(0.5)
+    for pid in pids:                       # gone (a zombie of another parent would still answer kill -0: the launcher reaped them)
+        try:
+            os.kill(pid, 0)
+            alive = True
+        except ProcessLookupError:
+            alive = False
+        assert not alive, pid
