@@ -152,6 +152,7 @@ struct DDPrefetcher {
     int nslots = 0;
     long long slot_bytes = 0;
     std::vector<void *> slot_mem;
+    std::vector<char> slot_pinned;     // 1 = from hipHostMalloc (freed with hipHostFree), 0 = from malloc
     std::vector<Job> jobs;              // by slot
     long long next_ticket = 0, next_to_run = 0;
     bool stop = false;
@@ -180,9 +181,11 @@ struct DDPrefetcher {
             if (ev && hipEventSynchronize((hipEvent_t)ev) != hipSuccess) (void)hipGetLastError();      // (an event of a dead stream: nothing reads the slot any more)
             if (!slot_mem[slot]) {
                 void *mem = nullptr;
+                slot_pinned[slot] = 1;
                 if (hipHostMalloc(&mem, (size_t)slot_bytes, hipHostMallocDefault) != hipSuccess) {
                     (void)hipGetLastError();
                     mem = malloc((size_t)slot_bytes);            // ordinary memory: still correct, the upload is then the driver's pageable copy
+                    slot_pinned[slot] = 0;
                 }
                 if (!mem) { status = DD_ERR_WORKSPACE; error = "out of host memory for a staging slot"; }
                 slot_mem[slot] = mem;
@@ -217,6 +220,7 @@ int dd_prefetch_create(int32_t threads, int32_t slots, int64_t slot_bytes, DDPre
     if (hipGetDevice(&p->device) != hipSuccess) { (void)hipGetLastError(); p->device = 0; }
     p->nslots = slots; p->slot_bytes = slot_bytes;
     p->slot_mem.assign((size_t)slots, nullptr);
+    p->slot_pinned.assign((size_t)slots, 0);
     p->jobs.resize((size_t)slots);
     for (int i = 0; i < threads; ++i) p->workers.emplace_back([p] { p->run(); });
     *out = p;
@@ -251,8 +255,8 @@ int dd_prefetch_wait(DDPrefetcher *p, int64_t ticket, void **base_out, int32_t *
     if (ticket < 0 || ticket >= p->next_ticket) return ifail(DD_ERR_INVALID_ARG, "dd_prefetch_wait: no such ticket");
     DDPrefetcher::Job &job = p->jobs[ticket % p->nslots];
     if (job.ticket != ticket) return ifail(DD_ERR_INVALID_ARG, "dd_prefetch_wait: the ticket's slot has been given to a later job");
-    p->cv.wait(lock, [&] { return job.state == 3 || job.state == 0 || p->stop; });
-    if (job.state != 3) return ifail(DD_ERR_INVALID_ARG, "dd_prefetch_wait: the job was released or the prefetcher is shutting down");
+    p->cv.wait(lock, [&] { return job.ticket != ticket || job.state == 3 || job.state == 0 || p->stop; });
+    if (job.state != 3 || job.ticket != ticket) return ifail(DD_ERR_INVALID_ARG, "dd_prefetch_wait: the job was released or the prefetcher is shutting down");
     if (base_out) *base_out = p->slot_mem[ticket % p->nslots];
     if (dtypes_out) for (size_t i = 0; i < job.files.size(); ++i) dtypes_out[i] = job.files[i].found;
     if (job.status != DD_OK) snprintf(g_ierr, sizeof(g_ierr), "%s", job.error.c_str());
@@ -281,8 +285,12 @@ int dd_prefetch_destroy(DDPrefetcher *p) {
     }
     p->cv.notify_all();
     for (std::thread &w : p->workers) w.join();
-    for (void *m : p->slot_mem)
-        if (m && hipHostFree(m) != hipSuccess) { (void)hipGetLastError(); free(m); }
+    for (size_t i = 0; i < p->slot_mem.size(); ++i) {
+        void *m = p->slot_mem[i];
+        if (!m) continue;
+        if (!p->slot_pinned[i]) free(m);
+        else if (hipHostFree(m) != hipSuccess) (void)hipGetLastError();      // (a runtime that is shutting down: the memory goes with the process)
+    }
     delete p;
     return DD_OK;
 }

@@ -276,7 +276,7 @@ class CachedSource(DepthSource):
                 "mask": mask.bool() if mask is not None else torch.ones((h, w), dtype=torch.bool, device=device)}
 
 
-_PREFETCHERS: dict = {}              # (threads, slots) -> (handle, slot bytes, the slots' events)
+_PREFETCHERS: dict = {}              # (threads, slots) -> [handle, slot bytes, the slots' events, weak reference to the feeder using it]
 _PREFETCHERS_LOCK = threading.Lock()
 
 
@@ -335,18 +335,28 @@ class NativeFeeder:
         self.slot_bytes = max(sum(self._bytes(k, sizes[n]) for k in self.keys) + 64 * len(self.keys) for n in self.names)
         # one prefetcher per process and shape of use, kept across scans (scripts/run_batch.py runs scan after scan): its slots are
         # page-locked memory, and locking 1.4 GB of it again for every scan costs more than reading the scan
+        import weakref
         key = (int(threads), self.nslots)
+        self._h = None
         with _PREFETCHERS_LOCK:
             have = _PREFETCHERS.get(key)
-            if have is not None and have[1] < self.slot_bytes:
-                lib.dd_prefetch_destroy(have[0])
-                have = None
+            if have is not None:
+                # a scan that ended in an exception may have left its feeder open, with jobs read ahead in the slots: they are given
+                # back before this scan queues its own (scans of a process run one after the other; two at a time are not supported)
+                before = have[3]() if have[3] is not None else None
+                if before is not None:
+                    before.close()
+                if have[1] < self.slot_bytes:
+                    lib.dd_prefetch_destroy(have[0])
+                    del _PREFETCHERS[key]
+                    have = None
             if have is None:
                 h = C.c_void_p()
                 if lib.dd_prefetch_create(int(threads), self.nslots, self.slot_bytes, C.byref(h)) < 0:
                     raise RuntimeError(lib.dd_ingest_last_error().decode("utf-8", "replace"))
-                have = _PREFETCHERS[key] = (h, self.slot_bytes, [None] * self.nslots)
-        self._h, _, self._events = have
+                have = _PREFETCHERS[key] = [h, self.slot_bytes, [None] * self.nslots, None]
+            have[3] = weakref.ref(self)
+        self._h, _, self._events, _ = have
         self._submitted = 0
         self._tickets: dict = {}          # view index -> ticket (tickets count on over the scans of a process)
         self._offsets: dict = {}

@@ -475,21 +475,23 @@ def _run(config: ScriptConfig, ranks: _Ranks, device, say, t_total: float, loop_
     lag = 0 if verbose else 1
     inflight: deque = deque()
     group: list = []
-    for k, image in enumerate(mine):
-        group.append(begin(k, image))
-        if len(group) >= K_LAUNCH:
-            inflight.append(group); group = []
-            if len(inflight) > lag:
-                finish(inflight.popleft())
-    if group:
-        inflight.append(group)
-    while inflight:
-        finish(inflight.popleft())
-    if pool:
-        pool.shutdown(wait=False, cancel_futures=True)
-    if feeder is not None:
-        torch.cuda.current_stream(device).synchronize()                         # (no upload still reads a slot)
-        feeder.close()
+    try:
+        for k, image in enumerate(mine):
+            group.append(begin(k, image))
+            if len(group) >= K_LAUNCH:
+                inflight.append(group); group = []
+                if len(inflight) > lag:
+                    finish(inflight.popleft())
+        if group:
+            inflight.append(group)
+        while inflight:
+            finish(inflight.popleft())
+    finally:                                                                    # (also when a view raised: the next scan of this process finds the slots free)
+        if pool:
+            pool.shutdown(wait=False, cancel_futures=True)
+        if feeder is not None:
+            torch.cuda.synchronize(device)                                      # (no upload still reads a slot)
+            feeder.close()
     say(f"-> Image processing loop finished in {time.time() - t_loop:.2f}s.")
 
     report = {"views": num_views, "dense_points": 0, "removed": 0, "timings": stage, "loop_detail": detail, "loop_seconds": time.time() - t_loop}

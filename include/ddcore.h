@@ -330,7 +330,8 @@ const char *dd_ingest_last_error(void);
  * the four types), goes to byte offset offsets[i] of the job's slot -- and returns its ticket (0, 1, 2 ...; job t uses slot t mod
  * slots).  dd_prefetch_wait blocks until the job is done and returns its status, the slot's address and the element types found;
  * dd_prefetch_release gives the slot back: it is refilled once `event` (a hipEvent_t the caller recorded behind its last read of the
- * slot, e.g. through dd_upload_async; NULL = at once) has passed.  Jobs are released by their owner, at most `slots` in flight. */
+ * slot, e.g. through dd_upload_async; NULL = at once) has passed.  Jobs are released by their owner, at most `slots` in flight.
+ * dd_prefetch_destroy joins the threads and frees the slots: no call on `p` may be in flight or follow. */
 typedef struct DDPrefetcher DDPrefetcher;
 int dd_prefetch_create(int32_t threads, int32_t slots, int64_t slot_bytes, DDPrefetcher **out);
 int64_t dd_prefetch_submit(DDPrefetcher *p, int32_t n, const char *const *paths, const int32_t *expect_dtype, const int32_t *ndim,

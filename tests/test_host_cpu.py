@@ -100,6 +100,29 @@ def test_the_plan_does_not_depend_on_the_callers_stack(tmp_path):
     assert run.returncode == 0 and "OK" in run.stdout, run.stdout + run.stderr
 
 
+@pytest.mark.parametrize("sanitizer", ["thread", "address,undefined"])
+def test_the_prefetcher_under_sanitizers(tmp_path, sanitizer):
+    """csrc/ddingest.hip's prefetcher (native threads, a mutex, a condition variable, slots handed back and forth) compiled for the host
+    with ThreadSanitizer and with AddressSanitizer + UBSan and driven by tests/c_client/prefetch_stress.cpp: 1-8 workers, 2-9 slots,
+    changing file sizes, missing files, over-submission, destroy with jobs in every state.  (Sanitizers run on the CPU build only.)"""
+    import subprocess
+    clang = Path("/opt/rocm/lib/llvm/bin/clang++")
+    if not clang.exists():
+        pytest.skip("no clang++ under /opt/rocm")
+    exe = tmp_path / "prefetch_stress"
+    build = subprocess.run([str(clang), "-std=c++17", "-O1", "-g", f"-fsanitize={sanitizer}", "-fno-omit-frame-pointer", "-fno-sanitize-recover=all",
+                            "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", f"-I{ROOT / 'include'}", "-x", "c++",
+                            str(ROOT / "depthdensifier_amd" / "csrc" / "ddingest.hip"), str(ROOT / "tests" / "c_client" / "prefetch_stress.cpp"),
+                            "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-o", str(exe)], capture_output=True, text=True)
+    if build.returncode != 0 and "sanitizer" in build.stderr.lower() and "unsupported" in build.stderr.lower():
+        pytest.skip(build.stderr[-300:])
+    assert build.returncode == 0, build.stderr[-1500:]
+    data = tmp_path / "files"
+    data.mkdir()
+    run = subprocess.run([str(exe), str(data), "120"], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and "prefetch_stress ok" in run.stdout and "Sanitizer" not in run.stderr, run.stdout[-500:] + run.stderr[-3000:]
+
+
 def test_struct_layout_matches_header(libmod):
     # DDViewParams is 32 floats; DDViewBatch / DDCloudOut sizes for the LP64 layout in the header
     assert C.sizeof(libmod.DDViewBatch) == 4 * 4 + 6 * 8 + 6 * 4 + 8 + 2 * 8      # (+ chain, chain_seq: ABI 12)
@@ -408,3 +431,50 @@ def test_native_npy_reader_and_prefetcher(libmod, tmp_path):
         assert submit(0) >= 0
     assert submit(0) == -3 and b"released" in L.dd_ingest_last_error()
     assert L.dd_prefetch_destroy(handle) == 0
+
+
+def test_a_feeder_left_open_gives_its_slots_to_the_next_scan(libmod, tmp_path):
+    """depth_source.NativeFeeder keeps one native prefetcher per process across scans.  A scan that ended in an exception may leave its
+    feeder open with views read ahead: the next scan's feeder gives those jobs back first (same slot size), or replaces the prefetcher
+    (larger views) -- and the old feeder's late close is harmless either way.  No GPU: slots are ordinary memory."""
+    import gc
+    from depthdensifier_amd.depth_source import CachedSource, NativeFeeder, _PREFETCHERS
+    rng = np.random.default_rng(5)
+
+    def scan(folder, n, h, w):
+        folder.mkdir()
+        want = {}
+        for v in range(n):
+            want[f"im{v}.png"] = maps = {"depth": rng.uniform(0.5, 5, (h, w)).astype(np.float32), "mask": rng.uniform(size=(h, w)) < 0.6,
+                                         "normal": rng.normal(size=(h, w, 3)).astype(np.float32), "rgb": rng.integers(0, 256, (h, w, 3), dtype=np.uint8)}
+            for k, a in maps.items():
+                np.save(folder / f"im{v}_{k}.npy", a)
+        return CachedSource(folder), want
+
+    def read_all(feeder, want, upto=None):
+        for k, name in enumerate(list(want)[:upto]):
+            rgb, maps, slot = feeder.get(k)
+            for key, a in want[name].items():
+                got = np.frombuffer((C.c_char * a.nbytes).from_address(slot.pointer(key)), dtype=a.dtype).reshape(a.shape)
+                assert np.array_equal(got, a), (name, key)
+            assert rgb.shape == want[name]["rgb"].shape and maps["depth"].dtype == np.float32
+            slot.released_natively()
+
+    src_a, want_a = scan(tmp_path / "a", 7, 6, 10)
+    a = NativeFeeder(src_a, list(want_a), {n: (10, 6) for n in want_a}, threads=2, ahead=3)
+    read_all(a, want_a, upto=2)                      # ... and the scan "fails" here: views 2-4 are read ahead, the feeder stays open
+    handle = _PREFETCHERS[(2, 5)][0]
+    src_b, want_b = scan(tmp_path / "b", 6, 6, 10)
+    b = NativeFeeder(src_b, list(want_b), {n: (10, 6) for n in want_b}, threads=2, ahead=3)
+    assert a._h is None and _PREFETCHERS[(2, 5)][0] is handle          # the same prefetcher, the old feeder closed
+    read_all(b, want_b)
+    with pytest.raises((RuntimeError, KeyError)):
+        a.get(2)                                     # the old feeder is of no use any more, and says so
+    # larger views with the second feeder still open: a new prefetcher; the old feeders' finalisers touch nothing that is gone
+    src_c, want_c = scan(tmp_path / "c", 4, 9, 16)
+    c = NativeFeeder(src_c, list(want_c), {n: (16, 9) for n in want_c}, threads=2, ahead=3)
+    assert b._h is None and _PREFETCHERS[(2, 5)][0] is not handle
+    del a, b
+    gc.collect()
+    read_all(c, want_c)
+    c.close()
