@@ -1135,22 +1135,29 @@ def main() -> None:
                 torch.cuda.empty_cache()      # (blocks torch keeps cached -- the verification's temporaries -- are not free memory to the driver)
                 if torch.cuda.mem_get_info(device)[0] < 1.15 * cloud_bytes + (4 << 30):
                     break                     # no room for a second cloud beside the timed one (2000 views on one GPU)
-                b2 = dd.CloudBuilder(batch.max_points, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index, device=device,
-                                     placement=args.placement)
-                b2.speculate_dense = not args.no_dense_guess
-                for _ in range(2):
-                    b2.reset(); b2.append(batch)
-                ts = []
-                for _ in range(5):
-                    b2.reset()
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(); b2.append(batch); b2.join(); e1.record()
-                    torch.cuda.synchronize(device)
-                    ts.append(e0.elapsed_time(e1))
-                alloc_ms.append(float(np.median(ts)))
-                alloc_how.append("first" if b2.placement is None else f"{b2.placement.mode[:120]} / {b2.placement.layout}")
-                if args.placement == "first":
-                    keep.append(torch.empty((r + 1) << 30, dtype=torch.uint8, device=device))    # the next allocation starts elsewhere
+                b2 = None
+                try:      # (a courtesy figure: ranks that share a card -- rehearsals -- may both have seen the room and not both get it; no collective in here)
+                    b2 = dd.CloudBuilder(batch.max_points, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index, device=device,
+                                         placement=args.placement)
+                    b2.speculate_dense = not args.no_dense_guess
+                    for _ in range(2):
+                        b2.reset(); b2.append(batch)
+                    ts = []
+                    for _ in range(5):
+                        b2.reset()
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(); b2.append(batch); b2.join(); e1.record()
+                        torch.cuda.synchronize(device)
+                        ts.append(e0.elapsed_time(e1))
+                    alloc_ms.append(float(np.median(ts)))
+                    alloc_how.append("first" if b2.placement is None else f"{b2.placement.mode[:120]} / {b2.placement.layout}")
+                    if args.placement == "first":
+                        keep.append(torch.empty((r + 1) << 30, dtype=torch.uint8, device=device))    # the next allocation starts elsewhere
+                except (torch.OutOfMemoryError, MemoryError) as e:
+                    print(f"[bench] rank {rank}: fresh-allocation round {r} left out ({type(e).__name__})", file=sys.stderr)
+                    del b2
+                    torch.cuda.empty_cache()
+                    break
                 del b2
                 torch.cuda.empty_cache()
             del keep
