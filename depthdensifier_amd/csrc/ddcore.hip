@@ -2182,13 +2182,23 @@ void launch_lean(const KArgs &a, hipStream_t s, int sp_pxt) {
     else launch_lean3<DepthT, SP, false, false>(a, s, sp_pxt);
 }
 
+// the fused refine instantiation's shape: the tile is the large single-pass tile (12288 pixels) whichever way it is cut into waves
+#ifndef DD_REFINE_NW
+#define DD_REFINE_NW DD_SP_WAVES
+#endif
+#ifndef DD_REFINE_PXT
+#define DD_REFINE_PXT DD_L_PXT
+#endif
+constexpr int RF_NW = DD_REFINE_NW, RF_PXT = DD_REFINE_PXT;
+static_assert(RF_NW * RF_PXT == SP_WAVES * L_PXT && RF_NW <= 16, "the fused refine stage keeps the large tile's size (make_plan counts tiles by it)");
+
 void launch_refine(const KArgs &a, hipStream_t s) {
-    const dim3 grid(a.num_tiles + (a.scan_service ? 1u : 0u)), block(64 * SP_WAVES);
+    const dim3 grid(a.num_tiles + (a.scan_service ? 1u : 0u)), block(64 * RF_NW);
     const bool hn = a.out_normal != nullptr, hc = a.rgb && (a.out_rgb || a.out_packed);
-    if (hn && hc) hipLaunchKernelGGL((compact_lean<float, false, true, true, true, SP_WAVES, true>), grid, block, 0, s, a);
-    else if (hn) hipLaunchKernelGGL((compact_lean<float, false, true, true, false, SP_WAVES, true>), grid, block, 0, s, a);
-    else if (hc) hipLaunchKernelGGL((compact_lean<float, false, true, false, true, SP_WAVES, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((compact_lean<float, false, true, false, false, SP_WAVES, true>), grid, block, 0, s, a);
+    if (hn && hc) hipLaunchKernelGGL((compact_lean<float, false, true, true, true, RF_NW, true, RF_PXT>), grid, block, 0, s, a);
+    else if (hn) hipLaunchKernelGGL((compact_lean<float, false, true, true, false, RF_NW, true, RF_PXT>), grid, block, 0, s, a);
+    else if (hc) hipLaunchKernelGGL((compact_lean<float, false, true, false, true, RF_NW, true, RF_PXT>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((compact_lean<float, false, true, false, false, RF_NW, true, RF_PXT>), grid, block, 0, s, a);
 }
 
 template <bool SP>
