@@ -946,6 +946,14 @@ def main() -> None:
         V = len(view_ids)
         H, W = cfg["H"], cfg["W"]
 
+        # The cloud's arrays are allocated BEFORE the maps (capacity = every pixel of the shard, known from the shapes alone): with the
+        # device still empty the zone arena has its pick of all three classes of HBM; behind 83 GB of maps it may not find enough
+        # chunks of each (round 6: 'degraded' placement and 0.75 instead of 0.77 on one box in three).  A caller of the library
+        # can do the same -- pipeline.main creates its CloudBuilder before the image loop.  DD_BENCH_CLOUD_FIRST=0: the old order.
+        early_builder = None
+        if not multi and V > 0 and os.environ.get("DD_BENCH_CLOUD_FIRST", "1") == "1":
+            early_builder = dd.CloudBuilder(V * H * W, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index,
+                                            device=device, placement=args.placement)
         scene = make_scene(cfg, view_ids, device)
         params = np.tile([0.8 * W, 0.8 * W, W / 2.0, H / 2.0], (V, 1))
         E = ring_poses(view_ids, total_views)
@@ -979,8 +987,10 @@ def main() -> None:
             batch = view_batch(scene, params, E, lo)
             # capacity = every visited pixel: no sizing pass exists anywhere, timed or not (SURVEY.md 8d defines the metric over
             # count + scan + unproject + compact, which the fused kernel does in its one pass)
-            builder = dd.CloudBuilder(batch.max_points, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index,
-                                      device=device, placement=args.placement)
+            builder = early_builder if early_builder is not None and early_builder.capacity == batch.max_points else \
+                dd.CloudBuilder(batch.max_points, normals=cfg["normal"], colors=cfg["rgb"], pixel_index=args.pixel_index,
+                                device=device, placement=args.placement)
+            early_builder = None
             builder.speculate_dense = not args.no_dense_guess
 
         ev = []
