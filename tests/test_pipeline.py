@@ -500,3 +500,57 @@ def test_resident_stacks_give_the_same_model(tmp_path, monkeypatch, early_exit, 
         assert rep["views"] == 10
         outs.append((tmp_path / f"out_{ring}" / "points3D.bin").read_bytes())
     assert outs[0] == outs[1] and len(outs[0]) > 1000
+
+
+@pytest.mark.gpu
+def test_a_scan_that_raises_leaves_the_process_fit_for_the_next(tmp_path, monkeypatch):
+    """scripts/run_batch.py runs scan after scan in one process and goes on when one fails.  A scan that raises in the middle of its image
+    loop -- views read ahead in the native prefetcher's slots, uploads in flight on the copy stream -- must leave nothing behind that the next
+    scan trips over: its feeder is closed in a ``finally`` (the slots are free), and the next scan's model is the model of a fresh process."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from PIL import Image as PILImage
+    from scan_factory import make_scan
+    from depthdensifier_amd import pipeline as P
+    from depthdensifier_amd import depth_source as DS
+    from depthdensifier_amd.depth_refiner import DepthRefiner
+    scan, cache, _ = make_scan(tmp_path, "s", V=12, H=72, W=96, seed=11)
+    npy = scan / "cache_npy"
+    npy.mkdir()
+    for f in sorted(cache.glob("*.npz")):
+        with np.load(f) as z:
+            for k in z.files:
+                np.save(npy / f"{f.stem}_{k}.npy", z[k])
+    for img in sorted((scan / "images").iterdir()):
+        np.save(npy / f"{img.stem}_rgb.npy", np.array(PILImage.open(img).convert("RGB")))
+
+    def config(tag):
+        cfg = P.ScriptConfig()
+        cfg.paths = P.PathsConfig(recon_path=scan / "sparse" / "0", image_dir=scan / "images", output_model_dir=tmp_path / f"out_{tag}")
+        cfg.moge.cache_dir = npy
+        cfg.processing.downsample_density = 1
+        cfg.processing.views_per_launch = 2
+        cfg.refiner.verbose = 0
+        cfg.refiner.adaptive_correspondences = False
+        return cfg
+
+    P.main(config("clean"))
+    want = (tmp_path / "out_clean" / "points3D.bin").read_bytes()
+    real, calls = DepthRefiner.begin_refine, {"n": 0}
+
+    def failing(self, *a, **kw):
+        calls["n"] += 1
+        if calls["n"] == 6:
+            raise RuntimeError("the sixth view of this scan cannot be refined")
+        return real(self, *a, **kw)
+
+    monkeypatch.setattr(DepthRefiner, "begin_refine", failing)
+    with pytest.raises(RuntimeError, match="sixth view"):
+        P.main(config("failed"))
+    monkeypatch.setattr(DepthRefiner, "begin_refine", real)
+    for entry in DS._PREFETCHERS.values():                    # the failed scan's feeder is closed: no job of it is left in a slot
+        user = entry[3]() if entry[3] is not None else None
+        assert user is None or user._h is None
+    P.main(config("after"))
+    assert (tmp_path / "out_after" / "points3D.bin").read_bytes() == want and len(want) > 1000
