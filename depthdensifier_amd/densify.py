@@ -12,6 +12,7 @@ the built library these functions raise.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional, Sequence, Union
 
@@ -643,10 +644,11 @@ class CloudBuilder:
     # workgroups then write three classes at once -- 0.72 instead of 0.66 of the roofline on BASELINE configs[4] with the count
     # pass included, 0.815 for the scatter kernel alone (0.81 for the whole step where the count pass is guessed away: fuse_tuning).
     # Below this many rows (3 GiB of points) the count pass costs more than the interleaving wins back.
-    CHAIN_MAX_TILES = 700            # small appends up to this many 12288-pixel tiles (4 views of 1080p) are chained across the two side streams:
-                                     # 1 view per call 0.40 -> 0.60 of the roofline, 2 views 0.52 -> 0.57, 4 views 0.61 -> 0.65; from 8 views on a call's
-                                     # scan is over only ~9 us before its last rows are written and the gate in front of the next call wins nothing
-                                     # (profiles/r05_streaming_chained_two_streams.txt)
+    CHAIN_MAX_TILES = int(os.environ.get("DD_CHAIN_MAX_TILES", "700"))      # small appends up to this many 12288-pixel tiles (4 views of 1080p) are chained
+                                     # across the two side streams.  us per call on 185 x 1080p, one stream / chained (profiles/r06_early_gate.txt):
+                                     # 1 view 20.8 / 16.8, 2 views 34.3 / 31.7, 4 views 62.3 / 62.2, 8 views 117.4 / 118.8, 16 views 223.3 / 224.4 --
+                                     # a call's scan is over only a few us before its last rows are written, so from 4 views on there is no tail left
+                                     # to hide a launch behind.  (With the gate of ABI 12-14, which opened at the scan's end: 32.3 / 65.5 / 123.2 / 227.4.)
     INTERLEAVE_MIN_ROWS = 256 << 20
     GUESS_MIN_PIXELS = 4 << 20       # unmasked batches from this size on run count-free (1.41x the single pass at 24 M pixels, 1.22x at 61 M, 1.11x at
                                      # 244 M, 1.23x at 6.1 G: profiles/r04_ab_count_free_small_batches.txt); below, a launch is a few microseconds either way
@@ -744,7 +746,7 @@ class CloudBuilder:
         self._side: list = []                        # two side streams + their workspaces, made at the first chained append
         self.side_stream_probes = 0                  # candidates tried until two streams ran side by side (_ensure_side)
         self._side_ws: list = []
-        self._chain = None                           # (1,) int64 device: the chain word
+        self._chain = None                           # (2,) int64 device: the chain word, the announcement word
         self._chain_seq = 0
         self._side_busy = False                      # chained calls are in flight on the side streams: join before anything else
         self._fork_ev = None
@@ -812,7 +814,8 @@ class CloudBuilder:
                 return False
         self._side = [first, second]
         self._side_raw = [s.cuda_stream for s in self._side]
-        self._chain = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._chain = torch.zeros(2, dtype=torch.int64, device=self.device)     # the chain word; behind it: which call has all its workgroups running (ABI 15)
+        self._chain_start = torch.tensor([-1], dtype=torch.int64, device=self.device)
         self._chain_ptr = self._chain.data_ptr()
         self._fork_ev = torch.cuda.Event()
         self._fork_ev.record(torch.cuda.current_stream(self.device))      # (creates the underlying event)
@@ -937,7 +940,8 @@ class CloudBuilder:
         (``tools/experiments/two_stream_chains.py``)."""
         self._side_workspaces(batch.workspace_bytes())
         if not self._side_busy:
-            self._chain.copy_(self.cursor, non_blocking=True)      # sequence 0, the row this chain starts from
+            self._chain[0:1].copy_(self.cursor, non_blocking=True)      # sequence 0, the row this chain starts from
+            self._chain[1:2].copy_(self._chain_start, non_blocking=True)   # no call of this chain has announced itself yet
             self._chain_seq = 0
         k = self._chain_seq & 1
         side, ws = self._side_raw[k], self._side_ws[k]

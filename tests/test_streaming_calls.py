@@ -429,7 +429,8 @@ N_STREAM_SEEDS = int(__import__("os").environ.get("DD_STREAM_SEEDS", "16"))     
 def test_random_chains_of_appends_write_the_one_batch_cloud(dd, seed):
     """Random view sizes / dtypes / fields, the views cut at random into calls of 1-5 views, appended with checks, joins and resets
     thrown in, on a shared GPU (tickets, one stream) or an exclusive one (by index; small calls chained across two streams, waiting
-    inside their scan or behind a gate): always the cloud of ONE batch, bit for bit."""
+    inside their scan or behind a gate that opens when the previous call's workgroups are all running -- or, one chain in five, when
+    its scan is over): always the cloud of ONE batch, bit for bit."""
     import torch
     rng = np.random.default_rng(70_000 + seed)
     if rng.uniform() < 0.12:
@@ -447,6 +448,9 @@ def test_random_chains_of_appends_write_the_one_batch_cloud(dd, seed):
     ref.speculate_dense = False
     ref.append(whole)
     want = ref.finish()
+    if rng.uniform() < 0.2:                                                   # the gate of ABI 12-14 (opens at the end of the previous call's scan) now and then
+        from depthdensifier_amd import _lib
+        whole.lab |= _lib.DD_LAB_LATE_GATE
     b = dd.CloudBuilder(whole.max_points, pixel_index=True, exclusive_gpu=bool(rng.uniform() < 0.7), **fields)
     b.speculate_dense = False
     for _ in range(2):
@@ -478,7 +482,7 @@ def test_the_ungated_chain_limit_follows_the_device(dd):
     if cus == 256:
         assert limit == 384
     out = (C.c_int32 * 8)()
-    word = torch.zeros(1, dtype=torch.int64, device="cuda")
+    word = torch.zeros(2, dtype=torch.int64, device="cuda")
 
     def gate(tiles):                                  # a one-view batch of `tiles` 6144-pixel tiles, chained
         px = tiles * 6144
