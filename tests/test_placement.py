@@ -159,3 +159,33 @@ def test_arena_churn_without_python(gpu, tmp_path):
     assert build.returncode == 0, build.stderr[-2000:]
     run = subprocess.run([str(exe), "1500", "1"], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0 and "arena churn OK" in run.stdout, run.stdout[-2000:] + run.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_set_pool_releases_nothing(gpu):
+    """``dd_arena_set_pool`` (ABI 14; ``placement.keep_everything``: a process under rocprofv3 must not give chunks back, they would
+    be lost): it only moves the number of spare chunks kept per class -- unlike ``dd_arena_trim`` nothing is released at the call, and
+    arrays freed afterwards stay with the arena, every chunk of them."""
+    import torch
+    from depthdensifier_amd import placement as pl
+    from depthdensifier_amd._lib import lib
+    arena = pl.ZoneArena(torch.device(gpu))                    # an arena of its own: the process-wide one keeps its settings
+    chunk = arena.stats()["chunk_bytes"]
+    rows = 2 * (chunk // 12) + 1000                            # three chunks per array
+    t, _ = arena.alloc({"a": ((rows, 3), torch.float32, 0), "b": ((rows, 3), torch.float32, 1), "c": ((rows, 3), torch.float32, 2)})
+    before = arena.stats()
+    assert lib.dd_arena_set_pool(arena._handle, 1 << 20) == 0
+    mid = arena.stats()
+    assert mid["chunks_released"] == before["chunks_released"] and mid["chunks_held"] == before["chunks_held"]      # nothing moved at the call
+    del t
+    gc.collect()
+    after = arena.stats()
+    assert after["chunks_released"] == before["chunks_released"], (before, after)                                  # ... nor when the arrays go
+    assert sum(after["chunks_held"]) >= 9
+    t2, degraded = arena.alloc({"d": ((rows, 3), torch.float32, 0), "e": ((rows, 3), torch.float32, 1)})           # served from what was kept
+    assert not degraded and arena.stats()["chunks_created"] == after["chunks_created"]
+    assert lib.dd_arena_set_pool(arena._handle, -1) < 0                                                           # a negative pool is refused
+    del t2
+    gc.collect()
+    arena.trim(0)
+    assert sum(arena.stats()["chunks_pooled"]) == 0
