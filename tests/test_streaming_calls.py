@@ -372,6 +372,41 @@ def test_small_appends_chained_across_two_streams_write_the_same_cloud(dd, shape
     assert torch.equal(got.points, want.points[:len(got)]) and len(got) == int(want.view_offsets[6])
 
 
+@pytest.mark.parametrize("late", (False, True))
+def test_gated_chained_appends_write_the_same_cloud(dd, late):
+    """Appends of two to four 1080p views are chained across the two side streams behind a GATE (they are too large to wait inside their
+    own workgroups: dd_chain_workgroup_limit): the gate opens when the previous call's workgroups are all running (ABI 15) -- or, with the
+    lab switch, when its scan is over (ABI 12-14).  Either way the cloud of one batch, bit for bit, over and over."""
+    import ctypes as C
+    from depthdensifier_amd import _lib
+    H, W, V = 1080, 1920, 14
+    depth, mask, normal, rgb, params, E = _case(77, V, H, W)
+    whole = dd.ViewBatch(depth, params, E, mask=mask, normal=normal, rgb=rgb)
+    ref = dd.CloudBuilder(whole.max_points, normals=True, colors=True, pixel_index=True)
+    ref.append(whole)
+    want = ref.finish()
+    if late:
+        whole.lab |= _lib.DD_LAB_LATE_GATE
+    cuts = [0, 2, 4, 7, 11, 14]                                              # calls of 2, 2, 3, 4 and 3 views
+    subs = [whole.slice(a, b) for a, b in zip(cuts, cuts[1:])]
+    out = (C.c_int32 * 8)()
+    cb = subs[0].c_struct()
+    cb.chain, cb.chain_seq = 0x1000, 0                                       # (what the plan of such a call says once it is chained)
+    with _lib.lab_switches(subs[0].lab):
+        assert _lib.lib.dd_debug_plan(C.byref(cb), out) == 0 and out[6] == 1 # gated
+    cb.chain, cb.chain_seq = None, 0
+    b = dd.CloudBuilder(whole.max_points, normals=True, colors=True, pixel_index=True, exclusive_gpu=True)
+    chained, inner = [], b._append_chained
+    b._append_chained = lambda batch, *a, **kw: (chained.append(batch.num_views), inner(batch, *a, **kw))[1]
+    for rep in range(6):
+        b.reset()
+        for s in subs:
+            b.append(s)
+        _equal(b.finish(), want)
+    assert (chained == [2, 2, 3, 4, 3] * 6 and len(b._side) == 2) or not b.overlap_small      # (every one of them went through the side streams)
+    assert b.healed == 0
+
+
 def test_side_streams_are_probed_before_calls_are_chained_across_them(dd, monkeypatch):
     """ABI 13: two HIP streams may share a hardware queue and then run strictly in order (``dd_streams_overlap``): a stream beside
     itself never overlaps; the pair a builder settles on does; and a builder that finds no pair does not chain -- same cloud."""
