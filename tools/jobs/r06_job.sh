@@ -47,7 +47,6 @@ sweeps)
   if [ "${LONG:-0}" = 1 ]; then      # the protocols that depend on timing (scan service, chained calls), at length
     run "DD_STREAM_SEEDS=6000" tests/test_streaming_calls.py -k random_chains
     run "DD_RANDOM_SEEDS=60000" tests/test_gpu_random.py
-    run "DD_RANDOM_SEEDS=3000 DD_RANDOM_SCALE=6" tests/test_gpu_random.py
   fi
   ;;
 driver_cmd)
