@@ -644,7 +644,7 @@ class CloudBuilder:
     # workgroups then write three classes at once -- 0.72 instead of 0.66 of the roofline on BASELINE configs[4] with the count
     # pass included, 0.815 for the scatter kernel alone (0.81 for the whole step where the count pass is guessed away: fuse_tuning).
     # Below this many rows (3 GiB of points) the count pass costs more than the interleaving wins back.
-    CHAIN_MAX_TILES = int(os.environ.get("DD_CHAIN_MAX_TILES", "700"))      # small appends up to this many 12288-pixel tiles (4 views of 1080p) are chained
+    CHAIN_MAX_TILES = 700            # (DD_CHAIN_MAX_TILES overrides) small appends up to this many 12288-pixel tiles (4 views of 1080p) are chained
                                      # across the two side streams.  us per call on 185 x 1080p, one stream / chained (profiles/r06_early_gate.txt):
                                      # 1 view 20.8 / 16.8, 2 views 34.3 / 31.7, 4 views 62.3 / 62.2, 8 views 117.4 / 118.8, 16 views 223.3 / 224.4 --
                                      # a call's scan is over only a few us before its last rows are written, so from 4 views on there is no tail left
