@@ -178,3 +178,21 @@ def test_c_abi_allgatherv_schedule_on_a_fake_rccl(tmp_path):
     assert build.returncode == 0, build.stderr[-3000:]
     run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0 and "exchanges OK" in run.stdout, run.stdout[-2000:] + run.stderr[-2000:]
+
+
+def test_c_abi_allgatherv_schedule_under_sanitizers(tmp_path):
+    """The same schedule with ``csrc/ddcomm.hip`` compiled for the host under AddressSanitizer + UBSan (world 2 / 3 / 8, ragged and
+    empty shards, gather-to-owner): no out-of-bounds offset, no overflow in the byte arithmetic of > 4 GiB clouds.  (``function`` is left
+    out of UBSan: the FAKE's entry points return int where RCCL's return an enum.)  Sanitizers run on the CPU build only."""
+    clang = Path("/opt/rocm/lib/llvm/bin/clang++")
+    if not clang.exists():
+        pytest.skip("no clang++ under /opt/rocm")
+    exe = tmp_path / "fake_rccl_asan"
+    build = subprocess.run([str(clang), "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize=function", "-fno-omit-frame-pointer",
+                            "-fno-sanitize-recover=all", "-rdynamic", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", f"-I{ROOT / 'include'}", "-x", "c++",
+                            str(ROOT / "depthdensifier_amd" / "csrc" / "ddcomm.hip"), str(ROOT / "tests" / "c_client" / "fake_rccl.cpp"),
+                            "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-ldl", "-lpthread", "-o", str(exe)], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-3000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and "exchanges OK" in run.stdout and "Sanitizer" not in run.stderr, run.stdout[-1000:] + run.stderr[-3000:]
+

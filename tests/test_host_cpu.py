@@ -359,10 +359,11 @@ def test_arena_layout_planning(tmp_path):
     if shutil.which("g++") is None:
         pytest.skip("g++ not installed")
     exe = tmp_path / "arena_plan_test"
-    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", f"-I{ROOT / 'include'}", f"-I{ROOT / 'depthdensifier_amd' / 'csrc'}",
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    f"-I{ROOT / 'include'}", f"-I{ROOT / 'depthdensifier_amd' / 'csrc'}",
                     "-o", str(exe), str(ROOT / "tests" / "c_client" / "arena_plan_test.cpp")], check=True, timeout=120)
-    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
-    assert out.returncode == 0 and "plan OK" in out.stdout, out.stdout + out.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)             # (under AddressSanitizer + UBSan)
+    assert out.returncode == 0 and "plan OK" in out.stdout and "Sanitizer" not in out.stderr, out.stdout + out.stderr
 
 
 def test_native_npy_reader_and_prefetcher(libmod, tmp_path):
