@@ -2052,8 +2052,8 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
     a.depth = b->depth; a.mask = b->mask; a.conf = b->conf; a.normal = b->normal; a.rgb = b->rgb;
     a.params = b->params;
     a.hw = hw; a.V = b->num_views; a.H = b->height; a.W = b->width; a.stride = b->stride;
-    a.Hs = (b->height + b->stride - 1) / b->stride;
-    a.Ws = (b->width + b->stride - 1) / b->stride;
+    a.Hs = (int)(((long long)b->height + b->stride - 1) / b->stride);      // (64-bit: height + stride may pass 2^31 -- tests/c_client/host_limits_test.cpp)
+    a.Ws = (int)(((long long)b->width + b->stride - 1) / b->stride);
     a.P = (unsigned)((long long)a.Hs * a.Ws);
     a.conf_thr = b->conf_threshold; a.flags = b->flags; a.conf_f16 = (b->conf_dtype == DD_F16);
     a.view_base = b->view_index_base;

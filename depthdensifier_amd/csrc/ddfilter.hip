@@ -709,9 +709,10 @@ const char *dd_filter_last_error(void) { return g_ferr; }
 
 int64_t dd_votes_workspace_bytes(int32_t num_views, int64_t n_points) {
     if (num_views <= 0 || n_points < 0) return DD_ERR_INVALID_ARG;
+    if (n_points > ((int64_t)1 << 48)) return DD_ERR_UNSUPPORTED;      // (beyond any memory: keeps the arithmetic below inside 64 bits)
     const int64_t blocks = (n_points + 255) / 256;
     // two 256-byte tables per view, the decision counters, one mask of V bits per 65 536 points (level 1 of the cull)
-    return (int64_t)num_views * 512 + 64 + ((blocks + SUPER - 1) / SUPER) * (int64_t)((num_views + 63) / 64) * 8;
+    return (int64_t)num_views * 512 + 64 + ((blocks + SUPER - 1) / SUPER) * (((int64_t)num_views + 63) / 64) * 8;
 }
 
 int dd_floater_votes(const DDFilterViews *views, const float *xyz, const float *normal, int64_t n,
@@ -721,6 +722,7 @@ int dd_floater_votes(const DDFilterViews *views, const float *xyz, const float *
     if (views->num_views <= 0 || views->height <= 0 || views->width <= 0) return fail("num_views/height/width must be positive");
     if (!views->depth || !views->cams) return fail("depth / cams is NULL");
     if (n < 0) return fail("n is negative");
+    if (n > ((int64_t)1 << 48) || views->num_views > (1 << 24)) return fail("more than 2^48 points or 2^24 views");      // (keeps the size arithmetic below inside its types)
     if (views->mode < 0 || views->mode > 4) return fail("mode must be 0 .. 4");
     if (views->mode == 2) return fail("mode 2 (the float32 first pass and its verify build) was removed in ABI 9");
     if (n > 0 && (!xyz || !normal || !votes_dev)) return fail("xyz / normal / votes_dev is NULL");
@@ -775,6 +777,7 @@ int dd_floater_votes(const DDFilterViews *views, const float *xyz, const float *
 
 int64_t dd_compact_workspace_bytes(int64_t n) {
     if (n < 0) return DD_ERR_INVALID_ARG;
+    if (n > ((int64_t)1 << 48)) return DD_ERR_UNSUPPORTED;
     const int64_t tiles = (n + C_TILE - 1) / C_TILE, groups = (tiles + C_GROUP - 1) / C_GROUP;
     return 16 + tiles * 8 + groups * 16;
 }
@@ -793,6 +796,7 @@ int dd_compact_cloud(const DDCloudOut *in, int64_t n, const int32_t *votes_dev, 
     if (out->capacity < 0) return fail("out->capacity is negative");
     if ((old_view_offsets_dev == nullptr) != (new_view_offsets_dev == nullptr)) return fail("old/new view offsets must be given together");
     const int64_t need = dd_compact_workspace_bytes(n);
+    if (need < 0) return fail("more than 2^48 rows");
     if (!workspace || workspace_bytes < need || ((uintptr_t)workspace % 16)) {
         snprintf(g_ferr, sizeof(g_ferr), "workspace is NULL, mis-aligned or smaller than dd_compact_workspace_bytes()");
         return DD_ERR_WORKSPACE;

@@ -73,6 +73,7 @@ int dd_format_points3d(const float *xyz, const uint8_t *rgb, const uint32_t *xyz
     auto fail = [](const char *m) { snprintf(g_merr, sizeof(g_merr), "%s", m); return DD_ERR_INVALID_ARG; };
     if (n < 0) return fail("n is negative");
     if (n == 0) return DD_OK;
+    if (n > ((int64_t)1 << 48)) return fail("too many points for one launch; split the call");
     if (!xyz && !xyz_rgba) return fail("xyz and xyz_rgba are both NULL");
     if (xyz_rgba && ((uintptr_t)xyz_rgba % 16) != 0) return fail("xyz_rgba must be 16-byte aligned");
     if (!out || ((uintptr_t)out % 16) != 0) return fail("out is NULL or not 16-byte aligned");

@@ -123,6 +123,30 @@ def test_the_prefetcher_under_sanitizers(tmp_path, sanitizer):
     assert run.returncode == 0 and "prefetch_stress ok" in run.stdout and "Sanitizer" not in run.stderr, run.stdout[-500:] + run.stderr[-3000:]
 
 
+def test_host_planning_at_its_limits_under_sanitizers(tmp_path):
+    """The HOST code of csrc/ddcore.hip and csrc/ddfilter.hip built with AddressSanitizer + UBSan (``-fno-gpu-sanitize``: the kernels are
+    compiled as usual and never run here) and driven by tests/c_client/host_limits_test.cpp: plans and workspace sizes from one pixel
+    to views of 2^31 - 1 pixels, 2^31 - 1 views, every stride and caller's tuning, chained and not, point counts up to INT64_MAX -- a
+    sane answer or a clean refusal, no overflow on the way.  (Round 6: ``height + stride - 1`` was added in 32 bits.)"""
+    import shutil
+    import subprocess
+    clang = Path("/opt/rocm/lib/llvm/bin/clang++")
+    if shutil.which("hipcc") is None or not clang.exists():
+        pytest.skip("no hipcc / clang++")
+    lib = tmp_path / "libddcore_asan.so"
+    san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all"]
+    build = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O0", "-std=c++17", "-fPIC", "-shared", *san, "-fno-gpu-sanitize", f"-I{ROOT / 'include'}",
+                            str(ROOT / "depthdensifier_amd" / "csrc" / "ddcore.hip"), str(ROOT / "depthdensifier_amd" / "csrc" / "ddfilter.hip"), "-o", str(lib)],
+                           capture_output=True, text=True, timeout=600)
+    assert build.returncode == 0, build.stderr[-2000:]
+    exe = tmp_path / "host_limits"
+    build = subprocess.run([str(clang), "-std=c++17", "-O1", "-g", *san, f"-I{ROOT / 'include'}", str(ROOT / "tests" / "c_client" / "host_limits_test.cpp"),
+                            f"-L{tmp_path}", "-lddcore_asan", f"-Wl,-rpath,{tmp_path}", "-o", str(exe)], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and "host limits OK" in run.stdout and "Sanitizer" not in run.stderr, run.stdout[-800:] + run.stderr[-3000:]
+
+
 def test_struct_layout_matches_header(libmod):
     # DDViewParams is 32 floats; DDViewBatch / DDCloudOut sizes for the LP64 layout in the header
     assert C.sizeof(libmod.DDViewBatch) == 4 * 4 + 6 * 8 + 6 * 4 + 8 + 2 * 8      # (+ chain, chain_seq: ABI 12)
