@@ -89,6 +89,7 @@ int parse_npy(int fd, const char *path, NpyInfo &info) {
         char *end;
         const long long v = strtoll(s, &end, 10);
         if (end == s || v < 0) return ifail(DD_ERR_INVALID_ARG, "%s: malformed shape", path);
+        if (v > ((long long)1 << 40) || (v > 0 && elems > ((long long)1 << 48) / v)) return ifail(DD_ERR_UNSUPPORTED, "%s: array too large", path);
         info.shape[info.ndim++] = v;
         elems *= v;
         s = end;

@@ -93,6 +93,32 @@ int main(int argc, char **argv) {
         }
         CHECK(dd_prefetch_destroy(p) == 0, "destroy");
     }
+    // the header parser on damaged files: a valid file with a few header bytes changed, or cut short -- an error or a header, never a crash,
+    // and a read into a buffer of the size the caller expects never writes past it (AddressSanitizer watches)
+    {
+        const std::string good = dir + "/v0_depth.npy", bad = dir + "/fuzz.npy";
+        std::vector<unsigned char> bytes;
+        { FILE *f = fopen(good.c_str(), "rb"); unsigned char buf[4096]; size_t n; while ((n = fread(buf, 1, sizeof(buf), f)) > 0) bytes.insert(bytes.end(), buf, buf + n); fclose(f); }
+        const char *snippets[] = {"(99999999999999999999, 9)", "(9223372036854775807, 9223372036854775807)", "(-3, 4)", "(,)", "((((", "'descr': '<f8'", "True", "'shape': 7", ""};
+        std::vector<unsigned char> dst((size_t)(hs[0] * ws[0] * 4));
+        long parsed = 0, refused = 0;
+        for (int it = 0; it < 3000; ++it) {
+            std::vector<unsigned char> m = bytes;
+            const int kind = (int)(rnd() % 4);
+            if (kind == 0) for (int k = 0; k < 1 + (int)(rnd() % 6); ++k) m[rnd() % 128] = (unsigned char)rnd();
+            else if (kind == 1) m.resize(rnd() % 140);
+            else if (kind == 2) { const char *sn = snippets[rnd() % 9]; size_t at = 10 + rnd() % 60; for (size_t k = 0; sn[k] && at + k < 128; ++k) m[at + k] = (unsigned char)sn[k]; }
+            else { m[8] = (unsigned char)rnd(); m[9] = (unsigned char)rnd(); if (rnd() & 1) m[6] = (unsigned char)(1 + rnd() % 3); }
+            FILE *f = fopen(bad.c_str(), "wb"); fwrite(m.data(), 1, m.size(), f); fclose(f);
+            int32_t dt = -7, nd = -7; int64_t shape[4] = {-7, -7, -7, -7}, off = -7;
+            const int rc = dd_npy_header(bad.c_str(), &dt, &nd, shape, &off);
+            if (rc == 0) { ++parsed; CHECK(dt >= 0 && dt <= 3 && nd >= 0 && nd <= 4 && off >= 10, "a header that parses gives dtype %d ndim %d offset %lld", dt, nd, (long long)off); }
+            else ++refused;
+            int64_t want[4] = {hs[0], ws[0], 1, 1};
+            (void)dd_npy_read(bad.c_str(), -1, 2, want, dst.data(), (int64_t)dst.size());
+        }
+        printf("header fuzz: %ld parsed, %ld refused\n", parsed, refused);
+    }
     printf("prefetch_stress ok: %d rounds, %lld bytes compared\n", rounds, checked);
     return 0;
 }
