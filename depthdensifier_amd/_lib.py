@@ -21,7 +21,7 @@ import torch  # noqa: F401  (load order, see above)
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("DDCORE_LIB", _HERE / "libddcore.so"))
 
-DD_ABI_VERSION = 15
+DD_ABI_VERSION = 14
 DD_OK = 0
 DD_F32, DD_F16 = 0, 1
 DD_NPY_F32, DD_NPY_F16, DD_NPY_U8, DD_NPY_BOOL = 0, 1, 2, 3
@@ -156,7 +156,7 @@ def DD_TUNE_INTERLEAVE(k: int) -> int:
 
 # include/ddcore_lab.h: the thread-local experiment switches (tests, A/B tools) -- never set by the product path
 DD_LAB_LIST_ORDER, DD_LAB_FAULT_INJECT, DD_LAB_POLL_LANES_32, DD_LAB_POLL_LANES_64 = 1, 2, 4, 8
-DD_LAB_LOOKBACK, DD_LAB_LATE_GATE, DD_LAB_APPLY_PLAIN = 16, 32, 128
+DD_LAB_LOOKBACK, DD_LAB_APPLY_PLAIN = 16, 128
 
 
 def DD_LAB_APPLY_WGS(n: int) -> int:

@@ -68,7 +68,7 @@ struct WsHeader {          // 64 bytes at the start of the workspace
     unsigned int ticket;
     unsigned int done;
     unsigned int epoch;
-    unsigned int started;      // ABI 15, chained calls with tiles by workgroup index: workgroups of the call that have started (by ticket: `ticket` says so)
+    unsigned int pad2;
     long long pad3[4];
 };
 static_assert(sizeof(WsHeader) == 64, "workspace header");
@@ -110,7 +110,6 @@ struct KArgs {
     unsigned long long *chain;    // ABI 12: the word that chains this call behind the previous one of the same cloud on another stream (or NULL)
     unsigned chain_seq;           // ... and the sequence number the word must show before this call's scan may start
     int chain_gated;              // ... the call is preceded by chain_gate (too large to wait inside its own workgroups)
-    int chain_early;              // ... its scan says in chain[1] when every workgroup of the launch is running (0: only at the scan's end; DD_LAB_LATE_GATE)
     TileCO *tiles;                // two-pass: count and first row of every tile (NULL in dd_count_valid)
     unsigned long long ws_words;  // 8-byte words of the caller's workspace behind the header (what a wrap of the epoch zeroes)
     unsigned long long *counts;   // per-view counts (dd_count_valid)
@@ -683,22 +682,6 @@ __device__ __forceinline__ void scan_service(const KArgs &a, const unsigned epoc
     long long running = base;                         // first row of tile f
     unsigned spins = 0;
     bool poison = false;                              // from here on the rows are unknown (a tile never published; fault injection)
-    // ABI 15: the word behind the chain word says which call of the chain has ALL its workgroups running -- from then on the call needs no
-    // further slot to finish, and the gate in front of the next call (chain_gate) may let that call's workgroups in beside this call's
-    // last ones: a call's launch latency and ramp are hidden behind its predecessor's tail.  Workgroups count themselves in at their
-    // start (the ticket they draw, or `started` when tiles go by workgroup index); the scan looks at the count while it polls.
-    bool announced = a.chain == nullptr;
-    const unsigned all_wgs = T + 1u;
-    auto announce = [&](const bool force) {
-        if (announced) return;
-        if (!force) {
-            if (!a.chain_early) return;
-            const unsigned there = __hip_atomic_load(a.static_tiles ? &a.hdr->started : &a.hdr->ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (there < all_wgs) return;
-        }
-        if (lane == 0) st_state(a.chain + 1, (unsigned long long)((a.chain_seq + 1u) & CHAIN_SEQ_MASK));
-        announced = true;
-    };
     if (a.chain) {
         // chained behind the previous call of this cloud, which runs on another stream and may not have finished its scan yet: the
         // batch starts where that call says it ends.  (This call's tiles load and count meanwhile; nothing of the previous call waits
@@ -708,7 +691,6 @@ __device__ __forceinline__ void scan_service(const KArgs &a, const unsigned epoc
             w = ld_state(a.chain);
             if ((unsigned)(w >> CHAIN_SHIFT) == (a.chain_seq & CHAIN_SEQ_MASK)) break;
             if (++spins > limit) { poison = true; break; }
-            announce(false);
             __builtin_amdgcn_s_sleep(DD_LB_SLEEP);
         }
         spins = 0;
@@ -755,7 +737,6 @@ __device__ __forceinline__ void scan_service(const KArgs &a, const unsigned epoc
             }
         }
         f += got;
-        announce(false);
         if (got) { spins = 0; continue; }
         if (++spins > limit) {                        // a tile never published its count: everything from here on is unknown
             poison = true;
@@ -773,7 +754,6 @@ __device__ __forceinline__ void scan_service(const KArgs &a, const unsigned epoc
         for (unsigned long long i = (unsigned long long)lane; i < a.ws_words; i += 64ull) a.gran[i] = 0ull;
         if (lane == 0) a.hdr->done = 0u;
     }
-    announce(true);                                   // (the scan is over: every tile has published, so every workgroup is running -- or has given up)
     if (lane == 0) {
         const long long end = poison ? POISON_ROW : running;
         a.view_offsets[a.V] = poison ? -1ll : running;
@@ -783,7 +763,6 @@ __device__ __forceinline__ void scan_service(const KArgs &a, const unsigned epoc
             __hip_atomic_store(a.cursor_out, end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             a.hdr->ticket = 0u;
-            a.hdr->started = 0u;                      // (every workgroup has counted itself in long ago: each did so before it published its count)
             a.hdr->epoch = epoch == EPOCH_MAX ? 0u : epoch + 1u;
             st_state(a.chain, ((unsigned long long)((a.chain_seq + 1u) & CHAIN_SEQ_MASK) << CHAIN_SHIFT) | (unsigned long long)end);
         } else {
@@ -1207,8 +1186,6 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
         base = load_cursor(a.cursor);          // the row the batch starts from, read before this tile publishes anything
         if (a.static_tiles) {
             t = blockIdx.x;
-            // (a chained call: counted in at the start, fire and forget -- the scan of this call reads the count, nobody waits for it)
-            if (a.chain && tid == 0) (void)__hip_atomic_fetch_add(&a.hdr->started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             if (tid == 0) s_ticket = atomicAdd(&a.hdr->ticket, 1u);
             __syncthreads();
@@ -1770,10 +1747,7 @@ __global__ __launch_bounds__(64 * NW, DD_LEAN_WGS) void compact_lean(const KArgs
 // then waits once more, and poisons the call if the word still does not come.) ----
 __global__ __launch_bounds__(64) void chain_gate(const unsigned long long *chain, const unsigned seq) {
     unsigned spins = 0;
-    // (ABI 15) ... or when the word behind it says that every workgroup of the previous call is running: that call then finishes
-    // without another slot, and this call's workgroups start beside its last ones instead of behind them
-    while ((unsigned)(__hip_atomic_load(chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> CHAIN_SHIFT) != (seq & CHAIN_SEQ_MASK)
-           && __hip_atomic_load(chain + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned long long)(seq & CHAIN_SEQ_MASK)) {
+    while ((unsigned)(__hip_atomic_load(chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> CHAIN_SHIFT) != (seq & CHAIN_SEQ_MASK)) {
         if (++spins > SPIN_LIMIT) break;
         __builtin_amdgcn_s_sleep(8);
     }
@@ -2130,7 +2104,6 @@ int make_plan(const DDViewBatch *b, KArgs &a, Plan &p) {
             // that this call's workgroups exist only once they have nothing to wait for
             p.chain_gate = wgs > (unsigned long long)chain_wg_limit();
             a.chain_gated = p.chain_gate ? 1 : 0;
-            a.chain_early = (lab & DD_LAB_LATE_GATE) ? 0 : 1;
             a.chain = reinterpret_cast<unsigned long long *>(b->chain);
             a.chain_seq = (unsigned)(b->chain_seq & (int64_t)CHAIN_SEQ_MASK);
         }

@@ -646,9 +646,10 @@ class CloudBuilder:
     # Below this many rows (3 GiB of points) the count pass costs more than the interleaving wins back.
     CHAIN_MAX_TILES = 700            # (DD_CHAIN_MAX_TILES overrides) small appends up to this many 12288-pixel tiles (4 views of 1080p) are chained
                                      # across the two side streams.  us per call on 185 x 1080p, one stream / chained (profiles/r06_early_gate.txt):
-                                     # 1 view 20.8 / 16.8, 2 views 34.3 / 31.7, 4 views 62.3 / 62.2, 8 views 117.4 / 118.8, 16 views 223.3 / 224.4 --
+                                     # 1 view 21.2 / 16.1, 2 views 35.1 / 30.8, 4 views 63.1 / 62.5, 8 views 118.6 / 120.0, 16 views 226.1 / 225.8 --
                                      # a call's scan is over only a few us before its last rows are written, so from 4 views on there is no tail left
-                                     # to hide a launch behind.  (With the gate of ABI 12-14, which opened at the scan's end: 32.3 / 65.5 / 123.2 / 227.4.)
+                                     # to hide a launch behind.  (A gate that opens earlier -- when the previous call's workgroups are all running --
+                                     # was built and measured in round 6: the counting costs more than the earlier start wins.)
     INTERLEAVE_MIN_ROWS = 256 << 20
     GUESS_MIN_PIXELS = 4 << 20       # unmasked batches from this size on run count-free (1.41x the single pass at 24 M pixels, 1.22x at 61 M, 1.11x at
                                      # 244 M, 1.23x at 6.1 G: profiles/r04_ab_count_free_small_batches.txt); below, a launch is a few microseconds either way
@@ -746,7 +747,7 @@ class CloudBuilder:
         self._side: list = []                        # two side streams + their workspaces, made at the first chained append
         self.side_stream_probes = 0                  # candidates tried until two streams ran side by side (_ensure_side)
         self._side_ws: list = []
-        self._chain = None                           # (2,) int64 device: the chain word, the announcement word
+        self._chain = None                           # (1,) int64 device: the chain word
         self._chain_seq = 0
         self._side_busy = False                      # chained calls are in flight on the side streams: join before anything else
         self._fork_ev = None
@@ -814,8 +815,7 @@ class CloudBuilder:
                 return False
         self._side = [first, second]
         self._side_raw = [s.cuda_stream for s in self._side]
-        self._chain = torch.zeros(2, dtype=torch.int64, device=self.device)     # the chain word; behind it: which call has all its workgroups running (ABI 15)
-        self._chain_start = torch.tensor([-1], dtype=torch.int64, device=self.device)
+        self._chain = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._chain_ptr = self._chain.data_ptr()
         self._fork_ev = torch.cuda.Event()
         self._fork_ev.record(torch.cuda.current_stream(self.device))      # (creates the underlying event)
@@ -940,8 +940,7 @@ class CloudBuilder:
         (``tools/experiments/two_stream_chains.py``)."""
         self._side_workspaces(batch.workspace_bytes())
         if not self._side_busy:
-            self._chain[0:1].copy_(self.cursor, non_blocking=True)      # sequence 0, the row this chain starts from
-            self._chain[1:2].copy_(self._chain_start, non_blocking=True)   # no call of this chain has announced itself yet
+            self._chain.copy_(self.cursor, non_blocking=True)      # sequence 0, the row this chain starts from
             self._chain_seq = 0
         k = self._chain_seq & 1
         side, ws = self._side_raw[k], self._side_ws[k]

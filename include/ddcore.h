@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 15
+#define DD_ABI_VERSION 14
 
 enum {
     DD_OK = 0,
@@ -116,21 +116,19 @@ typedef struct DDViewBatch {
                                  choice writes the same rows; reserved bits must be zero (DD_ERR_INVALID_ARG) */
     float *refined_out;       /* DD_REFINE: NULL, or (V,H,W) float32 receiving the refined, mask-zeroed depth -- the map the
                                  reference caches for the multi-view filter (scripts/test.py:194, 197-201) */
-    int64_t *chain;           /* ABI 12 / 15: NULL, or (2) int64 device words that chain consecutive calls of ONE cloud across TWO streams, so
+    int64_t *chain;           /* ABI 12: NULL, or (1) int64 device word that chains consecutive calls of ONE cloud across TWO streams, so
                                  that call n + 1 runs beside the tail of call n instead of behind it (a streaming caller's small calls --
                                  scripts/test.py:131: one view per iteration -- are bound by the launch-to-launch latency of a stream, not by
                                  their kernels).  The word holds [63:44] a sequence number, [43:0] the row the next call starts from; the
-                                 caller initialises it to (0, first row) and the word behind it to -1.  A call with chain != NULL takes its first row from the word --
+                                 caller initialises it to (0, first row).  A call with chain != NULL takes its first row from the word --
                                  its scan workgroup polls until the sequence equals chain_seq (mod 2^20) -- not from *cursor_dev, and when
                                  its scan is over stores (chain_seq + 1, row after the batch) there, and the row in *cursor_dev as usual.
                                  Calls that may be in flight together need a workspace and a view_offsets array each; two in flight at
                                  most, on a GPU the process has to itself.  A call of fewer than dd_chain_workgroup_limit() tiles of 6144 pixels
                                  (383 on a whole MI355X: a 1080p view) starts at once and waits inside its scan workgroup -- its tiles load
                                  and count meanwhile, and could never occupy every slot; a larger one is preceded by a one-wave gate kernel on its stream that returns
-                                 when every workgroup of the earlier call is running (ABI 15: that call's scan says so in chain[1], by its
-                                 sequence number + 1; the earlier call then needs no further slot, and this call starts beside its tail) or its
-                                 scan is over, so that its workgroups never hold a slot another launch is waiting for.
-                                 Stride-1 maps and the scan service only (DD_ERR_UNSUPPORTED otherwise) */
+                                 when the earlier call's scan is over, so that its workgroups never hold a slot while they wait for
+                                 another launch.  Stride-1 maps and the scan service only (DD_ERR_UNSUPPORTED otherwise) */
     int64_t chain_seq;
 } DDViewBatch;
 

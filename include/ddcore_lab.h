@@ -23,7 +23,6 @@ extern "C" {
 #define DD_LAB_POLL_LANES_32   0x4u   /* decoupled look-back: 32 polling lanes instead of 16 */
 #define DD_LAB_POLL_LANES_64   0x8u   /* ... 64 */
 #define DD_LAB_LOOKBACK        0x10u  /* single pass: the decoupled look-back of rounds 1-4 instead of the scan service */
-#define DD_LAB_LATE_GATE       0x20u  /* chained calls: a call says that all its workgroups are running only when its scan is over (ABI 12-14) */
 #define DD_LAB_APPLY_PLAIN     0x80u  /* dd_refine_apply: the one-tile-per-workgroup kernel of round 4 */
 #define DD_LAB_APPLY_WGS(n)    (((uint32_t)(n) & 0x1fffu) << 8)   /* dd_refine_apply: at most n workgroups (0 = the default, 4096) */
 

@@ -151,10 +151,10 @@ int main() {
             if (!seen) { printf("mode 4: no pair of streams that run side by side in 8 tries: chaining skipped\n"); }
             else {
                 void *d_chain, *d_ws2[2]; hipEvent_t ev;
-                CK(hipMalloc(&d_chain, 16)); CK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                CK(hipMalloc(&d_chain, 8)); CK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
                 for (int k = 0; k < 2; ++k) { CK(hipMalloc(&d_ws2[k], (size_t)wsb)); CK(hipMemset(d_ws2[k], 0, (size_t)wsb)); }
                 for (int rep = 0; rep < 3; ++rep) {
-                    CK(hipMemsetAsync(d_cur, 0, 8, stream)); CK(hipMemsetAsync(d_chain, 0, 8, stream)); CK(hipMemsetAsync((char *)d_chain + 8, 0xff, 8, stream));      // sequence 0 starts at row 0
+                    CK(hipMemsetAsync(d_cur, 0, 8, stream)); CK(hipMemsetAsync(d_chain, 0, 8, stream));      // sequence 0 starts at row 0
                     for (int k = 0; k < 2; ++k) DD(dd_stream_fork(ev, stream, side[k]));                      // both side streams behind that
                     for (int v = 0; v < V; ++v) {
                         DDViewBatch one = b;

@@ -372,11 +372,10 @@ def test_small_appends_chained_across_two_streams_write_the_same_cloud(dd, shape
     assert torch.equal(got.points, want.points[:len(got)]) and len(got) == int(want.view_offsets[6])
 
 
-@pytest.mark.parametrize("late", (False, True))
-def test_gated_chained_appends_write_the_same_cloud(dd, late):
+def test_gated_chained_appends_write_the_same_cloud(dd):
     """Appends of two to four 1080p views are chained across the two side streams behind a GATE (they are too large to wait inside their
-    own workgroups: dd_chain_workgroup_limit): the gate opens when the previous call's workgroups are all running (ABI 15) -- or, with the
-    lab switch, when its scan is over (ABI 12-14).  Either way the cloud of one batch, bit for bit, over and over."""
+    own workgroups: dd_chain_workgroup_limit) that opens when the previous call's scan is over: the cloud of one batch, bit for bit, over
+    and over."""
     import ctypes as C
     from depthdensifier_amd import _lib
     H, W, V = 1080, 1920, 14
@@ -385,8 +384,6 @@ def test_gated_chained_appends_write_the_same_cloud(dd, late):
     ref = dd.CloudBuilder(whole.max_points, normals=True, colors=True, pixel_index=True)
     ref.append(whole)
     want = ref.finish()
-    if late:
-        whole.lab |= _lib.DD_LAB_LATE_GATE
     cuts = [0, 2, 4, 7, 11, 14]                                              # calls of 2, 2, 3, 4 and 3 views
     subs = [whole.slice(a, b) for a, b in zip(cuts, cuts[1:])]
     out = (C.c_int32 * 8)()
@@ -464,8 +461,7 @@ N_STREAM_SEEDS = int(__import__("os").environ.get("DD_STREAM_SEEDS", "16"))     
 def test_random_chains_of_appends_write_the_one_batch_cloud(dd, seed):
     """Random view sizes / dtypes / fields, the views cut at random into calls of 1-5 views, appended with checks, joins and resets
     thrown in, on a shared GPU (tickets, one stream) or an exclusive one (by index; small calls chained across two streams, waiting
-    inside their scan or behind a gate that opens when the previous call's workgroups are all running -- or, one chain in five, when
-    its scan is over): always the cloud of ONE batch, bit for bit."""
+    inside their scan or behind a gate): always the cloud of ONE batch, bit for bit."""
     import torch
     rng = np.random.default_rng(70_000 + seed)
     if rng.uniform() < 0.12:
@@ -483,9 +479,6 @@ def test_random_chains_of_appends_write_the_one_batch_cloud(dd, seed):
     ref.speculate_dense = False
     ref.append(whole)
     want = ref.finish()
-    if rng.uniform() < 0.2:                                                   # the gate of ABI 12-14 (opens at the end of the previous call's scan) now and then
-        from depthdensifier_amd import _lib
-        whole.lab |= _lib.DD_LAB_LATE_GATE
     b = dd.CloudBuilder(whole.max_points, pixel_index=True, exclusive_gpu=bool(rng.uniform() < 0.7), **fields)
     b.speculate_dense = False
     for _ in range(2):
@@ -517,7 +510,7 @@ def test_the_ungated_chain_limit_follows_the_device(dd):
     if cus == 256:
         assert limit == 384
     out = (C.c_int32 * 8)()
-    word = torch.zeros(2, dtype=torch.int64, device="cuda")
+    word = torch.zeros(1, dtype=torch.int64, device="cuda")
 
     def gate(tiles):                                  # a one-view batch of `tiles` 6144-pixel tiles, chained
         px = tiles * 6144

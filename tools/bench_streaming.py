@@ -134,8 +134,7 @@ def main():
 
                 def chain_abi2():
                     builder.cursor.zero_()
-                    builder._chain[0:1].copy_(builder.cursor, non_blocking=True)
-                    builder._chain[1:2].fill_(-1)
+                    builder._chain.copy_(builder.cursor, non_blocking=True)
                     for sd in builder._side_raw:
                         assert lib.dd_stream_fork(builder._fork_raw, sp, sd) == 0
                     for i, (cs, offs) in enumerate(structs2):

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Chains of k-view appends over a 185-view 1080p scan, three ways: one stream (calls behind one another), chained across the two side streams
-with the gate of ABI 12-14 (opens when the previous call's scan is over: DD_LAB_LATE_GATE), and with the gate of ABI 15 (opens when every
-workgroup of the previous call is running).  GPU box only.   python tools/experiments/early_gate.py [--per-call 2,4,8,16]"""
+"""Chains of k-view appends over a 185-view 1080p scan: one stream (calls behind one another) against chained across the two side streams.  On a
+tree with tools/experiments/r06_early_gate.patch applied (a gate that opens when every workgroup of the previous call is running: built and
+measured in round 6, not kept -- profiles/r06_early_gate.txt) the chained chain runs with both gates.  GPU box only.
+    python tools/experiments/early_gate.py [--per-call 2,4,8,16]"""
 import argparse, sys
 from pathlib import Path
 import numpy as np, torch
@@ -22,7 +23,8 @@ E = bench.ring_poses(ids, V)
 alg = None
 for k in [int(x) for x in a.per_call.split(",")]:
     res = {}
-    for mode in ("one stream", "late gate", "early gate"):
+    patched = hasattr(_lib, "DD_LAB_LATE_GATE")
+    for mode in (("one stream", "late gate", "early gate") if patched else ("one stream", "chained")):
         lab = _lib.DD_LAB_LATE_GATE if mode == "late gate" else 0
         subs = [dd.ViewBatch(scene["depth"][i:i + k], params[i:i + k], E[i:i + k], mask=scene["mask"][i:i + k], normal=scene["normal"][i:i + k],
                              rgb=scene["rgb"][i:i + k], view_index_base=i, device=dev, lab=lab) for i in range(0, V, k)]
