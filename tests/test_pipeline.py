@@ -554,3 +554,43 @@ def test_a_scan_that_raises_leaves_the_process_fit_for_the_next(tmp_path, monkey
         assert user is None or user._h is None
     P.main(config("after"))
     assert (tmp_path / "out_after" / "points3D.bin").read_bytes() == want and len(want) > 1000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("density", (1, 3))
+def test_two_view_sizes_through_the_native_read_path(tmp_path, density, monkeypatch):
+    """A scan whose views come in two sizes (two cameras, one with an odd pixel count): no resident stacks (they hold one size), but the
+    native prefetcher and the one-call uploads still carry every view -- slots sized for the larger, a job per view in its own shape.
+    The model must be the model of the Python read path (the .npz cache), byte for byte."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from PIL import Image as PILImage
+    from scan_factory import make_scan
+    from depthdensifier_amd import pipeline as P
+    scan, cache, _ = make_scan(tmp_path, "s", V=9, H=72, W=96, seed=21, second_size=(71, 103))
+    npy = scan / "cache_npy"
+    npy.mkdir()
+    for f in sorted(cache.glob("*.npz")):
+        with np.load(f) as z:
+            for k in z.files:
+                np.save(npy / f"{f.stem}_{k}.npy", z[k])
+    for img in sorted((scan / "images").iterdir()):
+        np.save(npy / f"{img.stem}_rgb.npy", np.array(PILImage.open(img).convert("RGB")))
+    from depthdensifier_amd import depth_source as DS
+    taken, real_get = [], DS.NativeFeeder.get
+    monkeypatch.setattr(DS.NativeFeeder, "get", lambda self, k: (taken.append(k), real_get(self, k))[1])
+    outs = []
+    for tag, cache_dir in (("native", npy), ("python", cache)):
+        cfg = P.ScriptConfig()
+        cfg.paths = P.PathsConfig(recon_path=scan / "sparse" / "0", image_dir=scan / "images", output_model_dir=tmp_path / f"out_{tag}")
+        cfg.moge.cache_dir = cache_dir
+        cfg.processing.downsample_density = density
+        cfg.processing.views_per_launch = 4
+        cfg.refiner.verbose = 0
+        cfg.refiner.adaptive_correspondences = False
+        rep = P.main(cfg)
+        assert rep["views"] == 9
+        outs.append((tmp_path / f"out_{tag}" / "points3D.bin").read_bytes())
+    assert taken == list(range(9))                         # every view of the first run came through the native prefetcher, none of the second
+    assert outs[0] == outs[1] and len(outs[0]) > 1000
