@@ -594,3 +594,41 @@ def test_two_view_sizes_through_the_native_read_path(tmp_path, density, monkeypa
         outs.append((tmp_path / f"out_{tag}" / "points3D.bin").read_bytes())
     assert taken == list(range(9))                         # every view of the first run came through the native prefetcher, none of the second
     assert outs[0] == outs[1] and len(outs[0]) > 1000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("refiner_fp16", (False, True))
+def test_resident_stacks_with_a_half_precision_cache(tmp_path, monkeypatch, refiner_fp16):
+    """A cache that holds the depth maps as float16 (``dump_cache(fp16_depth=True)``): the resident stack keeps the maps in the cache's type
+    and -- when the refiner works in another precision -- a second stack in the refiner's; with both in float16 they are ONE array.  Either way
+    the model of the run without stacks, byte for byte."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from PIL import Image as PILImage
+    from scan_factory import make_scan
+    from depthdensifier_amd import pipeline as P
+    scan, cache, _ = make_scan(tmp_path, "s", V=8, H=72, W=96, seed=13)
+    npy = scan / "cache_npy"
+    npy.mkdir()
+    for f in sorted(cache.glob("*.npz")):
+        with np.load(f) as z:
+            for k in z.files:
+                np.save(npy / f"{f.stem}_{k}.npy", z[k].astype(np.float16) if k == "depth" else z[k])
+    for img in sorted((scan / "images").iterdir()):
+        np.save(npy / f"{img.stem}_rgb.npy", np.array(PILImage.open(img).convert("RGB")))
+    outs = []
+    for ring in ("1", "0"):
+        monkeypatch.setenv("DD_GROUP_RING", ring)
+        cfg = P.ScriptConfig()
+        cfg.paths = P.PathsConfig(recon_path=scan / "sparse" / "0", image_dir=scan / "images", output_model_dir=tmp_path / f"out_{ring}")
+        cfg.moge.cache_dir = npy
+        cfg.processing.downsample_density = 1
+        cfg.processing.views_per_launch = 3
+        cfg.refiner.verbose = 0
+        cfg.refiner.adaptive_correspondences = False
+        cfg.refiner.use_fp16 = refiner_fp16
+        rep = P.main(cfg)
+        assert rep["views"] == 8
+        outs.append((tmp_path / f"out_{ring}" / "points3D.bin").read_bytes())
+    assert outs[0] == outs[1] and len(outs[0]) > 1000
