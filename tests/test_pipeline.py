@@ -243,10 +243,11 @@ def test_view_sharded_scan_with_downsample_factor_and_a_late_camera(tmp_path):
 
 
 @pytest.mark.gpu
-def test_view_sharded_scan_matches_single_gpu(tmp_path):
+@pytest.mark.parametrize("layout", ("npz", "npy+rgb"))
+def test_view_sharded_scan_matches_single_gpu(tmp_path, layout):
     """``scripts/test.py`` under torchrun: 2 ranks (sharing this box's one GPU, gloo collectives) shard the views, filter
     sharded by points, all-gatherv the surviving clouds; the model written by rank 0 equals the one-process model
-    byte for byte."""
+    byte for byte -- with the cache read by Python threads (``npz``) and by every rank's own native prefetcher (``npy+rgb``)."""
     import os
     import socket
     import subprocess
@@ -256,6 +257,17 @@ def test_view_sharded_scan_matches_single_gpu(tmp_path):
         pytest.skip("no GPU")
     from scan_factory import make_scan
     scan, cache, _ = make_scan(tmp_path / "scans", "plane", V=7, seed=3, floaters=0.03, second_size=(71, 103))   # two view sizes, one with an odd pixel count
+    if layout == "npy+rgb":
+        from PIL import Image as PILImage
+        npy = scan / "cache_npy"
+        npy.mkdir()
+        for f in sorted(cache.glob("*.npz")):
+            with np.load(f) as z:
+                for k in z.files:
+                    np.save(npy / f"{f.stem}_{k}.npy", z[k])
+        for img in sorted((scan / "images").iterdir()):
+            np.save(npy / f"{img.stem}_rgb.npy", np.array(PILImage.open(img).convert("RGB")))
+        cache = npy
     root = Path(__file__).resolve().parent.parent
     args = ["--paths.recon-path", str(scan / "sparse" / "0"), "--paths.image-dir", str(scan / "images"),
             "--moge.cache-dir", str(cache), "--processing.downsample-density", "1", "--refiner.no-use-fp16",
